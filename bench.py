@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- decompressed MB/s of the batched Brotli decode hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (brx_decode_batch through the C ABI) over one batch of synthetic input
+already resident in HBM.  Workload at every N: BASELINE.json configs[1], "4096 x data/alice29.txt.compressed"
+PER GPU (weak scaling: independent streams shard across ranks with no data-path collective; the RCCL
+scatter/gather of SURVEY 8e is timed separately, never inside `value`).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GOLD = os.path.join(ROOT, "tests", "golden", "data")
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (fixture, streams per GPU)
+    "alice29x4096": ("alice29.txt", 4096),
+    "backward65536x4096": ("backward65536", 4096),
+    "quickfox_repeatedx8192": ("quickfox_repeated", 8192),
+    "compressed_repeatedx4096": ("compressed_repeated", 4096),
+}
+
+
+def cpu_baseline(comp, expect, seconds=12.0):
+    """The oracle (CPU restatement of the reference, canonical-lookup mode) on ONE host core, on a bounded
+    sample of the same workload: repeated decodes of the same stream for ~`seconds` of CPU time."""
+    import ctypes
+    import oracle_py
+    L = oracle_py.lib()
+    cap = len(expect) + 64
+    buf = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(0)
+    st = oracle_py.Stats()
+    rc = L.bro_decode(comp, len(comp), buf, cap, ctypes.byref(n), 0, ctypes.byref(st))
+    assert rc == 0 and buf.raw[:n.value] == expect
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(8):
+            L.bro_decode(comp, len(comp), buf, cap, ctypes.byref(n), 0, None)
+        reps += 8
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": round(reps * len(expect) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "%d sequential decodes of %d B -> %d B in %.1f s, single thread, oracle canonical mode"
+                      % (reps, len(comp), len(expect), dt)}, st.as_dict()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="alice29x4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--verify", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from brotli_rs_amd import brx
+    ctx = brx.Context(local_rank)
+
+    fixture, n = WORKLOADS[args.workload]
+    if args.streams:
+        n = args.streams
+    comp = open(os.path.join(GOLD, fixture + ".compressed"), "rb").read()
+    expect = open(os.path.join(GOLD, fixture), "rb").read()
+    cap = (len(expect) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
+
+    # synthetic batch: the stream replicated n times into distinct HBM regions, distinct output regions
+    one = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
+    blob = one.repeat(n).contiguous()
+    in_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * len(comp)).contiguous()
+    out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap).contiguous()
+    out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(timing=False):
+        ctx.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
+                                out_len.data_ptr(), status.data_ptr(), timing=timing)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timing=True)  # HIP events around the kernel, on the stream it is launched on
+        kernel_ms.append(ctx.last_timing_ms(1))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # parity on the timed output: status, lengths, and every stream's bytes (checksum of checksums by equality)
+    ok = True
+    if args.verify:
+        ok = bool((status == 0).all().item()) and bool((out_len == len(expect)).all().item())
+        want = torch.frombuffer(bytearray(expect), dtype=torch.uint8).to(dev)
+        got = out.view(n, cap)[:, :len(expect)]
+        ok = ok and bool((got == want.unsqueeze(0)).all().item())
+    if world > 1:
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        ok = bool(f.item())
+
+    if rank == 0:
+        total_out = float(len(expect)) * n * world
+        ms_per_step = dt / args.steps * 1e3
+        value = total_out * args.steps / dt / 1e6
+        res = {"metric": "decompressed MB/s (whole node), %s batch" % args.workload, "value": round(value, 1),
+               "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic (reference fixture %s.compressed replicated)" % fixture,
+               "config": {"workload": "%d x data/%s.compressed per GPU" % (n, fixture), "streams_per_gpu": n,
+                          "in_bytes_per_stream": len(comp), "out_bytes_per_stream": len(expect),
+                          "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
+               "bit_exact": ok}
+        cb, st = (None, None)
+        if not args.no_cpu_baseline:
+            cb, st = cpu_baseline(comp, expect, args.cpu_seconds)
+        else:
+            import oracle_py
+            st = oracle_py.decode(comp, want_stats=True)[2]
+        # ALGORITHMIC bytes per stream: compressed in + decompressed out + window-copy bytes read +
+        # dictionary bytes read; per launch = x streams of one GPU.
+        alg = len(comp) + len(expect) + st["copy_bytes"] + st["dict_bytes"]
+        kms = sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else float("nan")
+        kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
+        achieved = alg * n / (kavg * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "brx_decode_kernel", "achieved": round(achieved, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": None, "algorithmic_bytes_per_launch": alg * n,
+                           "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
+        if cb:
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu_1core"] = round(value / world / cb["value"], 1)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,214 @@
+"""ctypes binding of libbrx.so (include/brx.h) + a `Decompressor` that mirrors the reference's only public
+item, `brotli::Decompressor<R: Read>` (reference src/lib.rs:377-410, 2173-2193).
+
+Plumbing only: every decode goes through the C ABI into the gfx950 kernels.  If the library or a GPU is
+missing this module FAILS LOUDLY (BrxError); there is no CPU fallback anywhere in the product path.
+"""
+import ctypes
+import io
+import os
+
+import numpy as np
+
+from .build import LIB_PATH, build_library
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+OPT_TIMING = 2
+
+OK = 0
+OUTPUT_TOO_SMALL = 25
+REF_PANIC = 26
+
+
+class BrxError(RuntimeError):
+    pass
+
+
+class _Opts(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("hip_stream", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libbrx.so.  torch is imported first on purpose: its bundled libamdhip64 has the same SONAME
+    as the system one, and loading torch first makes both share ONE HIP runtime so device pointers of torch
+    tensors are valid inside libbrx."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the binding itself
+        pass
+    path = build_library()
+    if not os.path.exists(path):
+        raise BrxError("libbrx.so is missing (%s): build it with __graft_entry__.build()" % path)
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    L.brx_ctx_create.restype = ctypes.c_int
+    L.brx_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    L.brx_ctx_destroy.restype = None
+    L.brx_ctx_destroy.argtypes = [ctypes.c_void_p]
+    L.brx_decode_batch.restype = ctypes.c_int
+    L.brx_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.POINTER(_Opts)]
+    L.brx_status_str.restype = ctypes.c_char_p
+    L.brx_status_str.argtypes = [ctypes.c_int32]
+    L.brx_last_error.restype = ctypes.c_char_p
+    L.brx_last_timing.restype = ctypes.c_double
+    L.brx_last_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.brx_synchronize.restype = ctypes.c_int
+    L.brx_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.brx_stream_new.restype = ctypes.c_void_p
+    L.brx_stream_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.brx_stream_read.restype = ctypes.c_int64
+    L.brx_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.brx_stream_free.restype = None
+    L.brx_stream_free.argtypes = [ctypes.c_void_p]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
+                    "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free"]
+
+
+def status_str(code: int) -> str:
+    return load_library().brx_status_str(int(code)).decode("utf-8")
+
+
+class Context:
+    """One brx_ctx: a GPU, its tables, scratch and stream."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.brx_ctx_create(ctypes.byref(h), device)
+        if rc != 0:
+            raise BrxError("brx_ctx_create failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.brx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-memory batch --------------------------------------------------------------------------
+    def decode_batch(self, streams, capacities, timing=False):
+        """Decode a list of compressed byte strings.  `capacities`: per-stream output capacity (int or list).
+        Returns (outputs: list[bytes], status: np.int32[n], out_len: np.uint64[n])."""
+        n = len(streams)
+        if isinstance(capacities, int):
+            capacities = [capacities] * n
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in streams], out=in_off[1:])
+        np.cumsum(capacities, out=out_off[1:])
+        blob = np.frombuffer(b"".join(streams), dtype=np.uint8) if in_off[-1] else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(max(int(out_off[-1]), 1), dtype=np.uint8)
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.full(max(n, 1), -1, dtype=np.int32)
+        opts = _Opts(MEM_HOST | (OPT_TIMING if timing else 0), 0, None)
+        rc = self._lib.brx_decode_batch(self._h, blob.ctypes.data, in_off.ctypes.data, n, out.ctypes.data,
+                                        out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data,
+                                        ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        outs = []
+        for i in range(n):
+            ln = int(out_len[i]) if status[i] == OK else 0
+            outs.append(out[int(out_off[i]):int(out_off[i]) + ln].tobytes())
+        return outs, status[:n], out_len[:n]
+
+    # ---- device-memory batch (pointers are raw device addresses, e.g. torch tensor .data_ptr()) ------
+    def decode_batch_device(self, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
+                            hip_stream=None, timing=False):
+        opts = _Opts(MEM_DEVICE | (OPT_TIMING if timing else 0), 0, hip_stream)
+        rc = self._lib.brx_decode_batch(self._h, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr,
+                                        status_ptr, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+
+    def last_timing_ms(self, which=1):
+        return float(self._lib.brx_last_timing(self._h, which))
+
+    def synchronize(self, hip_stream=None):
+        rc = self._lib.brx_synchronize(self._h, hip_stream)
+        if rc != 0:
+            raise BrxError("brx_synchronize failed: %s" % self._lib.brx_last_error().decode())
+
+    def decode(self, data: bytes):
+        """Decode one stream of unknown size: grow the capacity on OUTPUT_TOO_SMALL.  -> (status, bytes)."""
+        cap = max(1 << 16, 8 * len(data))
+        while True:
+            outs, st, ln = self.decode_batch([data], [cap])
+            if st[0] == OUTPUT_TOO_SMALL:
+                cap = max(cap * 4, int(ln[0]))
+                continue
+            return int(st[0]), outs[0]
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Decompressor(io.RawIOBase):
+    """Mirror of `brotli::Decompressor<R: Read>` (reference src/lib.rs:377-410): wraps a reader of compressed
+    bytes and is itself a reader of decompressed bytes.
+
+        Decompressor(open("x.compressed", "rb")).read()        # == read_to_end
+
+    Semantics of `read` follow the reference's `impl Read` (src/lib.rs:2173-2193): n > 0 bytes, b"" at end of
+    stream forever after, and an error carrying the reference's description string for invalid input --
+    raised as ValueError here (the reference returns io::ErrorKind::InvalidData).  Differences, documented
+    in INTEGRATION.md: the inner reader is drained eagerly on the first read, and nothing is delivered for a
+    stream that fails (the reference delivers an unspecified prefix).
+    """
+
+    def __init__(self, reader, ctx: Context = None):
+        super().__init__()
+        self._reader = reader
+        self._ctx = ctx
+        self._stream = None
+        self._lib = load_library()
+
+    def readable(self):
+        return True
+
+    def readinto(self, b):
+        if self._stream is None:
+            data = self._reader.read() if hasattr(self._reader, "read") else bytes(self._reader)
+            ctx = self._ctx or default_context()
+            self._stream = self._lib.brx_stream_new(ctx._h, data, len(data))
+            if not self._stream:
+                raise BrxError("brx_stream_new failed")
+        mv = memoryview(b).cast("B")
+        buf = (ctypes.c_ubyte * len(mv)).from_buffer(mv) if len(mv) else None
+        n = self._lib.brx_stream_read(self._stream, buf, len(mv))
+        if n < -900:
+            raise BrxError("libbrx failure: %s" % self._lib.brx_last_error().decode())
+        if n < 0:
+            raise ValueError(status_str(-n))  # InvalidData + description, src/lib.rs:2177
+        return int(n)
+
+    def close(self):
+        if self._stream:
+            self._lib.brx_stream_free(self._stream)
+            self._stream = None
+        super().close()

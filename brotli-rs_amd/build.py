@@ -1,0 +1,45 @@
+"""Build libbrx.so (HIP kernels + C ABI) in-tree for gfx950.  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_PATH = os.path.join(PKG, "libbrx.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["brx_kernels.hip", "brx_api.cpp"]
+DEPS = SOURCES + ["brx_device.h", os.path.join("..", "..", "include", "brx.h"),
+                  os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
+                  os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "build.py")]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/ into brotli-rs_amd/libbrx.so.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    if not os.path.exists(HIPCC):
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH  # GPU box without a need to rebuild: use the prebuilt library that travelled
+        raise RuntimeError("hipcc not found at %s and no prebuilt libbrx.so" % HIPCC)
+    gen = os.path.join(CSRC, "_gen", "brx_tables_gen.h")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bin2h.py"), gen, "BRX", "static const"])
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

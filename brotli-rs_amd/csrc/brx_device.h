@@ -1,0 +1,44 @@
+// brx_device.h -- shared definitions between the host side (brx_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+// Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
+#define BRX_WAVE 64
+#define BRX_RING_BYTES 4096u     // LDS sliding-window ring: last 4 KiB of the stream's output
+#define BRX_TM_WORDS 1152u       // LDS table memory (prefix-code tables, context maps): 4608 B
+#define BRX_LENS_BYTES 768u      // LDS scratch for one alphabet's code lengths (<= 704)
+#define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
+#define BRX_FLUSH_LAG 1024u      // a block is flushed once the write cursor is this far past its end
+
+// Per-workgroup spill area in HBM for tables that do not fit the LDS table memory (worst case: 256 trees
+// per category).  Sized for the worst case so allocation can never fail mid-stream.
+#define BRX_SCRATCH_WORDS (224u * 1024u) // 896 KiB per resident wave
+
+// One static-dictionary word transform (spec Appendix B): prefix + elementary op + suffix.
+struct BrxTransform {
+    uint8_t prefix[8];
+    uint8_t suffix[8];
+    uint8_t plen, slen, op, pad;
+};
+
+// Read-only device tables owned by a brx_ctx.
+struct BrxDeviceTables {
+    const uint8_t *dict;        // 122784 B, spec Appendix A
+    const uint8_t *context_lut; // Lut0 | Lut1 | Lut2, 3 x 256 B
+    const BrxTransform *xforms; // 121 entries
+};
+
+struct BrxKernelArgs {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    uint8_t *out;
+    const uint64_t *out_off;
+    uint64_t *out_len;
+    int32_t *status;
+    uint32_t n;
+    uint32_t *work_counter; // zeroed before every launch
+    uint32_t *scratch;      // gridDim.x * BRX_SCRATCH_WORDS
+    BrxDeviceTables t;
+};
+
+void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream);

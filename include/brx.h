@@ -1,0 +1,129 @@
+/*
+ * brx.h -- C ABI of the MI355X-native batched Brotli decompressor (libbrx.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of ende76/brotli-rs: everything behind
+ *     pub struct Decompressor<R: Read>            (reference src/lib.rs:377-394)
+ *     pub fn new(r: R) -> Decompressor<R>          (reference src/lib.rs:398-410)
+ *     impl<R: Read> Read for Decompressor<R>::read (reference src/lib.rs:2173-2193)
+ * i.e. the private decompress() state machine (src/lib.rs:1545-2170) and the primitives under it
+ * (src/bitreader, src/huffman, src/ringbuffer, src/lookuptable, src/dictionary, src/transformation).
+ * The reference has no FFI of its own (pure safe Rust, `#![deny(unsafe_code)]`, src/lib.rs:1); the entry
+ * points below are what a Rust `extern "C"` block for this path binds -- INTEGRATION.md shows the shim.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in the signatures (a hipStream_t travels as void*).
+ * Results are bit-exact with the reference: identical output bytes for valid streams and the identical
+ * error kind (status 1..24 = DecompressorError in declaration order, src/lib.rs:294-319) for invalid ones.
+ */
+#ifndef BRX_H
+#define BRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-stream status codes ------------------------------------------------------------------------
+ * 0 = stream decoded; 1..24 = reference DecompressorError (src/lib.rs:294-319, same order);
+ * 25/26 are additions of this build. */
+enum {
+    BRX_OK = 0,
+    BRX_CODE_LENGTHS_CHECKSUM = 1,
+    BRX_EXPECTED_END_OF_STREAM = 2,
+    BRX_EXCEEDED_EXPECTED_BYTES = 3,
+    BRX_INVALID_BLOCK_COUNT_CODE = 4,
+    BRX_INVALID_BLOCK_SWITCH_COMMAND_CODE = 5,
+    BRX_INVALID_LENGTH_IN_STATIC_DICTIONARY = 6,
+    BRX_INVALID_MSKIP_LEN = 7, /* never observable, exactly like the reference (src/lib.rs:1661-1664) */
+    BRX_INVALID_SYMBOL = 8,
+    BRX_INVALID_TRANSFORM_ID = 9,
+    BRX_INVALID_NON_POSITIVE_DISTANCE = 10,
+    BRX_LESS_THAN_TWO_NON_ZERO_CODE_LENGTHS = 11,
+    BRX_NO_CODE_LENGTH = 12,
+    BRX_NON_ZERO_FILL_BIT = 13,
+    BRX_NON_ZERO_RESERVED_BIT = 14,
+    BRX_NON_ZERO_TRAILER_BIT = 15,
+    BRX_NON_ZERO_TRAILER_NIBBLE = 16,
+    BRX_PARSE_ERROR_CONTEXT_MAP = 17,
+    BRX_PARSE_ERROR_COMPLEX_PREFIX_CODE_LENGTHS = 18,
+    BRX_PARSE_ERROR_DISTANCE_CODE = 19,
+    BRX_PARSE_ERROR_INSERT_AND_COPY_LENGTH = 20,
+    BRX_PARSE_ERROR_INSERT_LITERALS = 21,
+    BRX_RING_BUFFER_ERROR = 22,
+    BRX_RUN_LENGTH_EXCEEDED_SIZE_OF_CONTEXT_MAP = 23,
+    BRX_UNEXPECTED_EOF = 24,
+    BRX_OUTPUT_TOO_SMALL = 25, /* capacity out_off[i+1]-out_off[i] exhausted; out_len[i] = bytes needed so far */
+    BRX_REF_PANIC = 26,        /* the reference would panic here: UppercaseFirst on a dictionary word that
+                                  starts with 0x00 (src/transformation/mod.rs:52-82) */
+    BRX_INTERNAL_WATCHDOG = 27 /* bug guard inside the kernel (a decode loop made no progress); never expected */
+};
+
+/* ---- library-level return codes (not per-stream) ---------------------------------------------------- */
+enum {
+    BRX_SUCCESS = 0,
+    BRX_ERR_INVALID_ARGUMENT = -1,
+    BRX_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init: there is NO CPU fallback */
+    BRX_ERR_HIP = -3,         /* a HIP call failed; brx_last_error() has the text */
+    BRX_ERR_OUT_OF_MEMORY = -4
+};
+
+/* ---- options -------------------------------------------------------------------------------------- */
+#define BRX_MEM_HOST 0u   /* every pointer argument is host memory; the library stages through HBM */
+#define BRX_MEM_DEVICE 1u /* every pointer argument (data, offset tables, out_len, status) is device memory */
+#define BRX_OPT_TIMING 2u /* record HIP-event timings of the kernels of this call (brx_last_timing) */
+
+typedef struct brx_opts {
+    uint32_t flags;   /* BRX_MEM_* | BRX_OPT_* */
+    uint32_t reserved;
+    void *hip_stream; /* hipStream_t to launch on, NULL = the context's own stream */
+} brx_opts;
+
+typedef struct brx_ctx brx_ctx; /* one per (process, GPU): device tables, scratch, a stream */
+
+/* Create a decoder context on HIP device `device` (0-based).  Fails with BRX_ERR_NO_DEVICE when no GPU is
+ * present -- the product path never falls back to a CPU decoder. */
+int brx_ctx_create(brx_ctx **out, int device);
+void brx_ctx_destroy(brx_ctx *ctx);
+
+/* Decode `n` independent Brotli streams (the batch analogue of constructing n reference Decompressors and
+ * calling read_to_end on each: benches/lib.rs:45-46, tests/lib.rs everywhere).
+ *   in       concatenated compressed streams; stream i is in[in_off[i] .. in_off[i+1])
+ *   in_off   n+1 offsets
+ *   out      output arena; stream i may write out[out_off[i] .. out_off[i+1])  (capacity, not size)
+ *   out_off  n+1 offsets
+ *   out_len  n  decoded sizes (valid for status 0; "needed so far" for status 25)
+ *   status   n  per-stream status codes (see above).  One bad stream never affects another.
+ * Synchronous with respect to the host unless opts->hip_stream is given and BRX_MEM_DEVICE is set, in
+ * which case the call only enqueues work on that stream.
+ * Returns BRX_SUCCESS or a BRX_ERR_* code. */
+int brx_decode_batch(brx_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
+                     const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_opts *opts);
+
+/* The reference's exact error description strings (src/lib.rs:331-354, typos included) for 1..24. */
+const char *brx_status_str(int32_t status);
+
+/* Text of the last library-level error on this thread. */
+const char *brx_last_error(void);
+
+/* Timing of the most recent brx_decode_batch call made with BRX_OPT_TIMING (milliseconds, HIP events on
+ * the launch stream).  which: 0 = whole device section, 1 = decode kernel. Returns <0 if unavailable. */
+double brx_last_timing(brx_ctx *ctx, int which);
+
+/* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
+int brx_synchronize(brx_ctx *ctx, void *hip_stream);
+
+/* ---- Read-shaped stream facade (one object = one stream, like one reference Decompressor) ----------
+ * brx_stream_new copies the compressed bytes; the first brx_stream_read decodes the whole stream on the
+ * GPU (batch of one) and later reads serve slices, so:  n>0 bytes read, 0 at end of stream forever after
+ * (reference src/lib.rs:2155-2166), -status on a decode error (the reference returns
+ * io::ErrorKind::InvalidData carrying brx_status_str(status), src/lib.rs:2177). */
+typedef struct brx_stream brx_stream;
+brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
+int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);
+void brx_stream_free(brx_stream *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -401,7 +401,7 @@ typedef struct {
     bro_stats st;
 } Dec;
 
-static const char *const STATUS_STR[27] = {
+static const char *const STATUS_STR[28] = {
     "OK",
     "Code length check sum did not add up in complex prefix code",
     "Expected end-of-stream, but stream did not end",
@@ -429,9 +429,10 @@ static const char *const STATUS_STR[27] = {
     "Encountered unexpected EOF",
     "Output capacity too small",
     "Reference implementation would panic (UppercaseFirst on a word starting with 0x00)",
+    "Internal decode-loop watchdog tripped",
 };
 
-const char *bro_status_str(int s) { return (s >= 0 && s <= 26) ? STATUS_STR[s] : "unknown status"; }
+const char *bro_status_str(int s) { return (s >= 0 && s <= 27) ? STATUS_STR[s] : "unknown status"; }
 
 /* ------------------------------------------------------------------------- */
 /* Header pieces                                                              */

@@ -1,0 +1,67 @@
+"""CPU-side checks of the drop-in boundary: libbrx.so builds for gfx950, loads, exports every symbol that
+include/brx.h declares, and refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import brotli_rs_amd
+from brotli_rs_amd import brx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "brx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(brx_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_builds_for_gfx950():
+    path = brotli_rs_amd.build_library()
+    assert os.path.exists(path)
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob  # the code object targets MI355X
+    assert b"brx_decode_kernel" in blob
+
+
+def test_every_declared_symbol_is_exported():
+    lib = brx.load_library()
+    declared = _declared_functions()
+    assert set(declared) == set(brx.EXPORTED_SYMBOLS), declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_status_strings_are_the_reference_descriptions():
+    """1..24 = DecompressorError descriptions, reference src/lib.rs:331-354 (typos included)."""
+    import oracle_py
+    for code in range(0, 28):
+        assert brx.status_str(code) == oracle_py.status_str(code)
+    assert brx.status_str(24) == "Encountered unexpected EOF"
+    assert brx.status_str(15) == "Enocuntered non-zero bit trailing the stream"
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a HIP device the product path must fail loudly, never decode on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(brx.BrxError):
+        brx.Context(0)
+    with pytest.raises(brx.BrxError):
+        brx.Decompressor(open(os.path.join(ROOT, "tests", "golden", "data", "64x.compressed"), "rb")).read()
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under brotli-rs_amd/ may import, include or link it."""
+    pkg = os.path.join(ROOT, "brotli-rs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_gen" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "brotli_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
+                assert "libbrotli" not in text, os.path.join(dirpath, f)
