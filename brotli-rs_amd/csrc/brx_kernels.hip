@@ -532,7 +532,8 @@ FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len) {
     u32 done = 0, de = dist;
     while (done < len) {
         u32 n = len - done < 64u ? len - done : 64u;
-        u32 off = de >= n ? d.lane : d.lane % de;
+        u32 off = d.lane;
+        if (de < n) off = d.lane % de; // overlapped copy shorter than a chunk: periodic source
         u32 back = de - off; // distance of this lane's source byte from pos
         u32 b = 0;
         if (d.lane < n) {
