@@ -174,6 +174,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.out_len = d_out_len;
     a.status = d_status;
     a.n = n;
+    {
+        const char *e = getenv("BRX_DEBUG_STOP");
+        a.debug_stop = e ? (uint32_t)atoi(e) : 0u;
+    }
     a.work_counter = c->d_counter;
     a.scratch = c->d_scratch;
     a.t.dict = c->d_dict;

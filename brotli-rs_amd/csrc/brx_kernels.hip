@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(BRX_WAVE) void brx_decode_kernel(BrxKernelArgs a) {
     __shared__ Lds s;
     Dec d;
     d.lane = threadIdx.x;
+    if (a.debug_stop == 1u) return;
     d.t_dict = a.t.dict;
     d.t_xforms = a.t.xforms;
     d.scratch = a.scratch + (size_t)blockIdx.x * BRX_SCRATCH_WORDS;
@@ -1018,11 +1019,14 @@ __global__ __launch_bounds__(BRX_WAVE) void brx_decode_kernel(BrxKernelArgs a) {
     d.v_lut0 = ((const u32 *)a.t.context_lut)[d.lane];
     d.v_lut1 = ((const u32 *)a.t.context_lut)[64u + d.lane];
     d.v_lut2 = ((const u32 *)a.t.context_lut)[128u + d.lane];
+    if (a.debug_stop == 2u) return;
     for (;;) {
-        u32 sid = 0;
-        if (d.lane == 0u) sid = atomicAdd(a.work_counter, 1u);
-        sid = rfl(sid);
+        // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
+        // behind the lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63
+        // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
+        u32 sid = rdl(atomicAdd(a.work_counter, d.lane == 0u ? 1u : 0u), 0);
         if (sid >= a.n) break;
+        if (a.debug_stop == 3u) { if (d.lane == 0u) { a.status[sid] = 100; a.out_len[sid] = 0; } continue; }
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
         const u8 *inp = a.in + i0;
@@ -1035,6 +1039,7 @@ __global__ __launch_bounds__(BRX_WAVE) void brx_decode_kernel(BrxKernelArgs a) {
         d.chunkA = in_load_chunk(d, 0);
         d.chunkB = in_load_chunk(d, 64u);
         in_seek(d, 8ull * mis);
+        if (a.debug_stop == 4u) { if (d.lane == 0u) { a.status[sid] = 101; a.out_len[sid] = (u64)d.win; } continue; }
         d.out = a.out + o0;
         const u64 capacity = o1 - o0;
         d.cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
