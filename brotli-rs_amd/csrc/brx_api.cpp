@@ -180,6 +180,11 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     }
     a.work_counter = c->d_counter;
     a.scratch = c->d_scratch;
+    a.debug = nullptr;
+    unsigned long long *dbg = nullptr;
+    if (getenv("BRX_DEBUG_STATS")) {
+        if (hipMalloc(&dbg, (size_t)n * 80) == hipSuccess) { (void)hipMemset(dbg, 0, (size_t)n * 80); a.debug = dbg; }
+    }
     a.t.dict = c->d_dict;
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
@@ -189,6 +194,18 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
+    if (dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)n * 10);
+        (void)hipMemcpy(h.data(), dbg, (size_t)n * 80, hipMemcpyDeviceToHost);
+        static const char *nm[10] = {"hdr", "iac", "lit", "dist", "copy", "ncmd", "nlit", "fastmb", "total", "scr_top"};
+        for (uint32_t i = 0; i < n && i < 2; i++) {
+            fprintf(stderr, "[brx stats] stream %u:", i);
+            for (int q = 0; q < 10; q++) fprintf(stderr, " %s=%llu", nm[q], h[(size_t)i * 10 + q]);
+            fprintf(stderr, "\n");
+        }
+        (void)hipFree(dbg);
+    }
     return BRX_SUCCESS;
 }
 

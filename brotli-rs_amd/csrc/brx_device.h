@@ -5,8 +5,8 @@
 // Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
 #define BRX_WAVE 64
 #define BRX_RING_BYTES 4096u     // LDS sliding-window ring: last 4 KiB of the stream's output
-#define BRX_TM_WORDS 1152u       // LDS table memory (prefix-code tables, context maps): 4608 B
-#define BRX_LENS_BYTES 768u      // LDS scratch for one alphabet's code lengths (<= 704)
+#define BRX_TM_WORDS 1216u       // LDS table memory (prefix-code tables, context maps): 4864 B -> 10 KiB LDS per wave
+#define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 1024u      // a block is flushed once the write cursor is this far past its end
 
@@ -39,6 +39,7 @@ struct BrxKernelArgs {
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
     uint32_t *work_counter; // zeroed before every launch
     uint32_t *scratch;      // gridDim.x * BRX_SCRATCH_WORDS
+    unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr
     BrxDeviceTables t;
 };
 

@@ -47,10 +47,19 @@ enum { LK_OK = 0, LK_NONE = 1, LK_EOF = 2 };
 struct __attribute__((aligned(16))) Lds {
     u8 ring[BRX_RING_BYTES];
     u32 tm[BRX_TM_WORDS];
-    u8 lens[BRX_LENS_BYTES];
+    u8 lens[BRX_LENS_BYTES - 512u]; // code lengths of one alphabet (<= 704), rounded up for 4-byte clears
+    u32 st[48];                      // decoder state parked here across calls into the cold (out-of-line) parts
+    u32 mbw[48];                     // meta-block header results handed from cold_header to the command loop
+    u32 pad[16];                     // profiling accumulators
+    u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
 };
 
+// One Lds per workgroup (= per wave).  File scope, so the out-of-line segments address it as LDS directly (a
+// generic Lds* parameter would turn every access into a flat_* instruction).
+__shared__ Lds g_lds;
+
 #define FI __device__ __attribute__((always_inline)) inline
+#define TICK() (pf.on ? (u64)__builtin_readcyclecounter() : 0ull)
 
 // ---- wave-level primitives ---------------------------------------------------------------------------
 FI u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -92,6 +101,9 @@ struct Dec {
     u32 ww;
     // output side
     u8 *out;             // stream's output base
+    __amdgpu_buffer_rsrc_t out_rsrc; // same, as a buffer resource: far back-references are buffer_load_ubyte
+                                     // (a plain pointer load next to the LDS ring read gets merged into ONE flat
+                                     // load by LLVM, and that trips a backend bug in non-kernel functions)
     u32 cap;             // capacity (clamped to < 2^32-64)
     u32 pos;             // bytes produced (reference: Decompressor.count_output)
     u32 a;               // (uintptr_t)out & 15: ring/global 16-B alignment skew
@@ -102,32 +114,69 @@ struct Dec {
     u32 lds_top, scr_top;
     u32 *scratch;
     // per-lane constant vectors
-    u32 v_ins, v_copy, v_blen;
+    u32 v_ic; // lanes 0..23: insert length codes, lanes 32..55: copy length codes ((base << 5) | extra bits)
     u32 v_lut0, v_lut1, v_lut2;
     u32 needed; // for ST_OUTPUT_TOO_SMALL
     u64 wd, wd_limit; // loop watchdog: every command / meta-block consumes a bit or emits a byte
     const u8 *t_dict;
     const BrxTransform *t_xforms;
+    const u32 *t_lut; // Lut0 | Lut1 | Lut2 as dwords
+};
+
+struct Prof { // bring-up profiling (BRX_DEBUG_STATS=1): cycle totals per section of the command loop
+    u64 tk[8];
+    bool on;
 };
 
 // ---- table memory: LDS first, HBM spill beyond ---------------------------------------------------------
-FI u32 tm_ld32(const Dec &d, const Lds &s, u32 wa) {
-    return wa < BRX_TM_WORDS ? s.tm[wa] : d.scratch[wa - BRX_TM_WORDS];
+// An object lives entirely in LDS (word address < BRX_TM_WORDS) or entirely in the HBM spill arena.  The
+// accessors take the address space as a template flag chosen by ONE wave-uniform branch per object, so
+// the compiler emits real ds_* / global_* instructions (a per-access select makes it fall back to
+// flat_load, which took the v1 kernel to ~4 flat loads per symbol -- profiles/r01a_pmc.csv).
+template <bool INL> FI u32 tm_ld32(const Dec &d, const Lds &s, u32 wa) {
+    if (INL) return s.tm[wa];
+    return __builtin_nontemporal_load(&d.scratch[wa - BRX_TM_WORDS]); // nt: keeps LLVM from merging the two
+                                                                    // address spaces into one flat access
 }
-FI void tm_st32(const Dec &d, Lds &s, u32 wa, u32 v) {
-    if (wa < BRX_TM_WORDS) s.tm[wa] = v; else d.scratch[wa - BRX_TM_WORDS] = v;
+template <bool INL> FI void tm_st32(const Dec &d, Lds &s, u32 wa, u32 v) {
+    if (INL) s.tm[wa] = v; else __builtin_nontemporal_store(v, &d.scratch[wa - BRX_TM_WORDS]);
 }
-FI u32 tm_ld16(const Dec &d, const Lds &s, u32 ha) { // halfword address
-    return ha < BRX_TM_WORDS * 2 ? ((const u16 *)s.tm)[ha] : ((const u16 *)d.scratch)[ha - BRX_TM_WORDS * 2];
+template <bool INL> FI u32 tm_ld16(const Dec &d, const Lds &s, u32 ha) { // halfword address
+    if (INL) return ((const u16 *)s.tm)[ha];
+    return __builtin_nontemporal_load(&((const u16 *)d.scratch)[ha - BRX_TM_WORDS * 2]);
 }
-FI void tm_st16(const Dec &d, Lds &s, u32 ha, u32 v) {
-    if (ha < BRX_TM_WORDS * 2) ((u16 *)s.tm)[ha] = (u16)v; else ((u16 *)d.scratch)[ha - BRX_TM_WORDS * 2] = (u16)v;
+template <bool INL> FI void tm_st16(const Dec &d, Lds &s, u32 ha, u32 v) {
+    if (INL) ((u16 *)s.tm)[ha] = (u16)v; else __builtin_nontemporal_store((u16)v, &((u16 *)d.scratch)[ha - BRX_TM_WORDS * 2]);
 }
-FI u32 tm_ld8(const Dec &d, const Lds &s, u32 ba) {
-    return ba < TM_BYTES ? ((const u8 *)s.tm)[ba] : ((const u8 *)d.scratch)[ba - TM_BYTES];
+template <bool INL> FI u32 tm_ld8(const Dec &d, const Lds &s, u32 ba) {
+    if (INL) return ((const u8 *)s.tm)[ba];
+    return __builtin_nontemporal_load(&((const u8 *)d.scratch)[ba - TM_BYTES]);
 }
-FI void tm_st8(const Dec &d, Lds &s, u32 ba, u32 v) {
-    if (ba < TM_BYTES) ((u8 *)s.tm)[ba] = (u8)v; else ((u8 *)d.scratch)[ba - TM_BYTES] = (u8)v;
+template <bool INL> FI void tm_st8(const Dec &d, Lds &s, u32 ba, u32 v) {
+    if (INL) ((u8 *)s.tm)[ba] = (u8)v; else __builtin_nontemporal_store((u8)v, &((u8 *)d.scratch)[ba - TM_BYTES]);
+}
+// wave-uniform scalar reads (address uniform): dispatch on the address itself
+FI u32 tm_u32(const Dec &d, const Lds &s, u32 wa) {
+    return wa < BRX_TM_WORDS ? rfl(tm_ld32<true>(d, s, wa)) : rfl(tm_ld32<false>(d, s, wa));
+}
+FI u32 tm_u8(const Dec &d, const Lds &s, u32 ba) {
+    return ba < TM_BYTES ? rfl(tm_ld8<true>(d, s, ba)) : rfl(tm_ld8<false>(d, s, ba));
+}
+FI void tm_set8(const Dec &d, Lds &s, u32 ba, u32 v) { // uniform address, lane 0 stores
+    if (ba < TM_BYTES) { if (d.lane == 0u) tm_st8<true>(d, s, ba, v); }
+    else { if (d.lane == 0u) tm_st8<false>(d, s, ba, v); }
+}
+FI void tm_set32(const Dec &d, Lds &s, u32 wa, u32 v) {
+    if (wa < BRX_TM_WORDS) { if (d.lane == 0u) tm_st32<true>(d, s, wa, v); }
+    else { if (d.lane == 0u) tm_st32<false>(d, s, wa, v); }
+}
+FI void tm_zero_words(const Dec &d, Lds &s, u32 wa, u32 n) {
+    if (wa < BRX_TM_WORDS) { for (u32 k = d.lane; k < n; k += 64u) tm_st32<true>(d, s, wa + k, 0u); }
+    else { for (u32 k = d.lane; k < n; k += 64u) tm_st32<false>(d, s, wa + k, 0u); }
+}
+FI void tm_zero_bytes(const Dec &d, Lds &s, u32 ba, u32 n) {
+    if (ba < TM_BYTES) { for (u32 k = d.lane; k < n; k += 64u) tm_st8<true>(d, s, ba + k, 0u); }
+    else { for (u32 k = d.lane; k < n; k += 64u) tm_st8<false>(d, s, ba + k, 0u); }
 }
 // Objects never straddle the LDS / HBM boundary.
 FI u32 tm_alloc(Dec &d, u32 nwords) {
@@ -142,9 +191,14 @@ FI u32 tm_alloc(Dec &d, u32 nwords) {
 }
 
 // ---- bit input (reference: src/bitreader/mod.rs:21-303) -------------------------------------------------
+// Branch-free on purpose (clamped index + select): a per-lane branch here makes LLVM's uniformity analysis
+// treat the scalar reader state that is merged at the same join block (cbase, the bit window ...) as
+// divergent, which moved the WHOLE command loop state into VGPRs (callers guarantee w_end >= 1).
 FI u32 in_load_chunk(const Dec &d, u32 c) {
     u32 i = c + d.lane;
-    return i < d.w_end ? d.in_words[i] : 0u;
+    u32 j = i < d.w_end ? i : d.w_end - 1u;
+    u32 v = d.in_words[j];
+    return i < d.w_end ? v : 0u;
 }
 FI u32 in_word(Dec &d, u32 w) {
     if (w >= d.w_end) return 0u;
@@ -194,6 +248,45 @@ FI u32 in_byte_tail(Dec &d) {
     return v;
 }
 
+// ---- parking the decoder state in LDS ------------------------------------------------------------------
+// The cold parts of the decoder (meta-block header parsing with its code builders; the table-memory command
+// loop for oversized meta-blocks) are real out-of-line functions so that their register needs do not leak
+// into the register allocation of the hot command loop.  State crosses the call through Lds::st.
+FI void put64(Lds &s, u32 i, u64 v) { s.st[i] = (u32)v; s.st[i + 1u] = (u32)(v >> 32); }
+FI u64 get64(const Lds &s, u32 i) { return (u64)rfl(s.st[i]) | ((u64)rfl(s.st[i + 1u]) << 32); }
+FI void dec_store(const Dec &d, Lds &s) {
+    { // every lane stores the same wave-uniform values: no lane-0 branch
+        put64(s, 0, (u64)(uintptr_t)d.in_words); s.st[2] = d.w_end; put64(s, 3, d.bitpos); put64(s, 5, d.bitend);
+        put64(s, 7, (u64)(uintptr_t)d.out); s.st[9] = d.cap; s.st[10] = d.pos; s.st[11] = d.a; s.st[12] = d.vfl;
+        s.st[13] = d.window; s.st[14] = d.dist0; s.st[15] = d.dist1; s.st[16] = d.dist2; s.st[17] = d.dist3;
+        s.st[18] = d.lds_top; s.st[19] = d.scr_top; put64(s, 20, (u64)(uintptr_t)d.scratch); s.st[22] = d.needed;
+        put64(s, 23, (u64)(uintptr_t)d.t_dict); put64(s, 25, (u64)(uintptr_t)d.t_xforms);
+        put64(s, 27, (u64)(uintptr_t)d.t_lut); put64(s, 29, d.wd); put64(s, 31, d.wd_limit);
+    }
+}
+FI void dec_load(Dec &d, const Lds &s) {
+    d.lane = threadIdx.x;
+    d.in_words = (const u32 *)(uintptr_t)get64(s, 0); d.w_end = rfl(s.st[2]);
+    d.bitend = get64(s, 5);
+    d.out = (u8 *)(uintptr_t)get64(s, 7); d.cap = rfl(s.st[9]);
+    d.out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0xffffffff, 0x00020000); d.pos = rfl(s.st[10]); d.a = rfl(s.st[11]);
+    d.vfl = rfl(s.st[12]); d.window = rfl(s.st[13]);
+    d.dist0 = rfl(s.st[14]); d.dist1 = rfl(s.st[15]); d.dist2 = rfl(s.st[16]); d.dist3 = rfl(s.st[17]);
+    d.lds_top = rfl(s.st[18]); d.scr_top = rfl(s.st[19]); d.scratch = (u32 *)(uintptr_t)get64(s, 20);
+    d.needed = rfl(s.st[22]);
+    d.t_dict = (const u8 *)(uintptr_t)get64(s, 23); d.t_xforms = (const BrxTransform *)(uintptr_t)get64(s, 25);
+    d.t_lut = (const u32 *)(uintptr_t)get64(s, 27); d.wd = get64(s, 29); d.wd_limit = get64(s, 31);
+    {
+        u32 ki = K_INS[d.lane < 24u ? d.lane : 23u], kc = K_COPY[(d.lane - 32u) < 24u ? d.lane - 32u : 23u];
+        u32 mi = 0u - (u32)(d.lane < 24u), mc = 0u - (u32)((d.lane - 32u) < 24u); // bitwise selects: branch-free
+        d.v_ic = (ki & mi) | (kc & mc);
+    }
+    d.v_lut0 = d.t_lut[d.lane]; d.v_lut1 = d.t_lut[64u + d.lane]; d.v_lut2 = d.t_lut[128u + d.lane];
+    d.cbase = 0xffffff00u; // force a re-stage of the input chunks
+    d.chunkA = 0; d.chunkB = 0;
+    in_seek(d, get64(s, 3));
+}
+
 // ---- prefix codes ----------------------------------------------------------------------------------------
 // Table layout in table memory (word address h): 16 header words, then the symbols as u16 in
 // (length, symbol) order.  header[0] = kind | max_len << 8 | single_symbol << 16  (kind 0 empty, 1 single,
@@ -202,8 +295,8 @@ FI u32 in_byte_tail(Dec &d) {
 //   base[L]  = offset[L] - first_code[L]  (mod 2^16)
 // Lookup = reference Tree::lookup_symbol (src/huffman/tree/mod.rs:63-93): zero bits for a single-symbol
 // code (Q5); an unassigned codeword of an incomplete code reads max_len+1 bits and yields None (Q15).
-FI u32 decode_sym(Dec &d, const Lds &s, u32 h, u32 &sym) {
-    u32 hv = tm_ld32(d, s, h + (d.lane & 15u)); // per-lane header word
+template <bool INL> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) {
+    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 15u)); // per-lane header word
     u32 h0 = rdl(hv, 0);
     u32 kind = h0 & 3u;
     if (kind == 0u) return LK_NONE;
@@ -224,9 +317,13 @@ FI u32 decode_sym(Dec &d, const Lds &s, u32 h, u32 &sym) {
     if ((u64)L > rem) return LK_EOF;
     u32 base = rdl(hv, L) >> 16;
     u32 idx = ((v >> (15u - L)) + base) & 0xffffu;
-    sym = rfl(tm_ld16(d, s, (h + 16u) * 2u + idx));
+    sym = rfl(tm_ld16<INL>(d, s, (h + 16u) * 2u + idx));
     in_consume(d, L);
     return LK_OK;
+}
+FI u32 decode_sym(Dec &d, const Lds &s, u32 h, u32 &sym) {
+    if (h < BRX_TM_WORDS) return decode_sym_as<true>(d, s, h, sym);
+    return decode_sym_as<false>(d, s, h, sym);
 }
 
 // Build a general code from s.lens[0..n) (canonical assignment, reference src/huffman/mod.rs:19-43; the
@@ -263,14 +360,17 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
     }
     u32 nnz = off;
     u32 h = tm_alloc(d, 16u + ((nnz + 1u) >> 1));
-    if (lane == 0u) hv = 2u | (maxlen << 8);
-    if (lane < 16u) tm_st32(d, s, h + lane, hv);
+    if (lane == 0u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[0]: kind | max_len | number of symbols
+    const bool inl = h < BRX_TM_WORDS;
+    if (inl) { if (lane < 16u) tm_st32<true>(d, s, h + lane, hv); }
+    else { if (lane < 16u) tm_st32<false>(d, s, h + lane, hv); }
     const u64 lt = (1ull << lane) - 1ull;
     for (u32 c = 0; c < n; c += 64u) {
         u32 i = c + lane;
         u32 my = i < n ? s.lens[i] : 0u;
         u64 any = ballot(my != 0u);
         if (any == 0ull) continue;
+        u32 slot = 0xffffffffu; // this lane's position in the sorted symbol list
         u32 pr = present;
         while (pr) {
             u32 l = (u32)__builtin_ctz(pr);
@@ -278,16 +378,20 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
             u64 m = ballot(my == l);
             if (m == 0ull) continue;
             u32 run = rdl(offv, l);
-            if (my == l) tm_st16(d, s, (h + 16u) * 2u + run + (u32)__builtin_popcountll(m & lt), i);
+            if (my == l) slot = run + (u32)__builtin_popcountll(m & lt);
             if (lane == l) offv += (u32)__builtin_popcountll(m);
         }
+        if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + 16u) * 2u + slot, i); }
+        else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + 16u) * 2u + slot, i); }
     }
     return h;
 }
 
 FI u32 build_single(Dec &d, Lds &s, u32 sym) {
     u32 h = tm_alloc(d, 16u);
-    if (d.lane < 16u) tm_st32(d, s, h + d.lane, d.lane == 0u ? (1u | (sym << 16)) : 0u);
+    u32 w = d.lane == 0u ? (1u | (sym << 16)) : 0u;
+    if (h < BRX_TM_WORDS) { if (d.lane < 16u) tm_st32<true>(d, s, h + d.lane, w); }
+    else { if (d.lane < 16u) tm_st32<false>(d, s, h + d.lane, w); }
     return h;
 }
 
@@ -490,17 +594,36 @@ FI u32 read_prefix_code(Dec &d, Lds &s, u32 alphabet, u32 &h) {
 }
 
 // ---- output: LDS ring + aligned flush to HBM --------------------------------------------------------------
+// Per-lane predication WITHOUT per-lane branches (a divergent branch anywhere in the command loop makes LLVM's
+// uniformity analysis give up on the loop-carried decoder state and move all of it into VGPRs):
+//   * LDS byte stores of switched-off lanes are steered to a per-lane trash byte;
+//   * HBM stores / loads go through the stream's buffer resource, whose range check drops (reads as 0) any
+//     access at offset >= num_records, so a switched-off lane simply uses offset 0xffffffff.
+FI void ring_put(const Dec &d, Lds &s, bool on, u32 vpos, u32 byte) {
+    u8 *p = on ? &s.ring[vpos & RMASK] : &s.trash[d.lane];
+    *p = (u8)byte;
+}
+// Flush skewed range [v0, v1) of the ring to HBM: full 16-B units as one 16-B store per lane, ragged head and
+// tail (first / last block of a stream only) as byte stores.  v1 - v0 <= BRX_FLUSH_BLOCK + 15.
 FI void flush_range(Dec &d, const Lds &s, u32 v0, u32 v1) {
-    u8 *gbase = d.out - d.a; // 16-B aligned; skewed coordinate v lives at gbase + v
-    for (u32 u = (v0 >> 4) + d.lane; u < ((v1 + 15u) >> 4); u += 64u) {
-        u32 lo = u * 16u < v0 ? v0 : u * 16u;
-        u32 hi = u * 16u + 16u > v1 ? v1 : u * 16u + 16u;
-        if (hi - lo == 16u) {
-            uint4 q = *(const uint4 *)&s.ring[(u * 16u) & RMASK];
-            *(uint4 *)(gbase + (u64)u * 16u) = q;
-        } else {
-            for (u32 b = lo; b < hi; b++) gbase[b] = s.ring[b & RMASK];
-        }
+    const u32 u0 = (v0 + 15u) >> 4, u1 = v1 >> 4; // full units [u0, u1)
+    for (u32 ub = u0; ub < u1; ub += 64u) { // uniform trip count (1, rarely 2)
+        u32 u = ub + d.lane;
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q = *(const u32x4 *)&s.ring[(u * 16u) & RMASK];
+        u32 off = u < u1 ? u * 16u - d.a : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0);
+    }
+    if (v0 & 15u) { // ragged head: bytes [v0, min(u0*16, v1))
+        u32 e = u0 * 16u < v1 ? u0 * 16u : v1;
+        u32 v = v0 + d.lane;
+        u32 b = s.ring[v & RMASK];
+        __builtin_amdgcn_raw_buffer_store_b8((u8)b, d.out_rsrc, v < e ? v - d.a : 0xffffffffu, 0, 0);
+    }
+    if ((v1 & 15u) && u1 * 16u >= v0 && u1 >= u0) { // ragged tail: bytes [u1*16, v1)
+        u32 v = u1 * 16u + d.lane;
+        u32 b = s.ring[v & RMASK];
+        __builtin_amdgcn_raw_buffer_store_b8((u8)b, d.out_rsrc, v < v1 ? v - d.a : 0xffffffffu, 0, 0);
     }
     d.vfl = v1;
 }
@@ -527,20 +650,31 @@ FI void ctx_bytes(const Dec &d, const Lds &s, u32 &p1, u32 &p2) {
     p2 = d.pos >= 2u ? rfl(b2) : 0u;
 }
 
+// Source byte of one lane of a window copy: `back` = distance from the write cursor.  The ring holds the last
+// BRX_RING_BYTES bytes, anything older is read back from the stream's own HBM output.  The choice between the
+// two is made per wave whenever all lanes agree (almost always), so neither load sits behind a lane branch.
+FI u32 copy_fetch(const Dec &d, const Lds &s, u32 back_max, u32 back_min, u32 back) {
+    if (back_max <= BRX_RING_BYTES) return s.ring[(d.pos - back + d.a) & RMASK];
+    if (back_min > BRX_RING_BYTES) return __builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, d.pos - back, 0, 0);
+    u32 bn = s.ring[(d.pos - back + d.a) & RMASK];
+    u32 bf = __builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, d.pos - back, 0, 0);
+    return back <= BRX_RING_BYTES ? bn : bf;
+}
+
 // Window copy, reference copy_literals src/lib.rs:1491-1505: out[pos+i] = out[pos-dist + (i % dist)].
-FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len) {
+FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
     u32 done = 0, de = dist;
     while (done < len) {
         u32 n = len - done < 64u ? len - done : 64u;
-        u32 off = d.lane;
-        if (de < n) off = d.lane % de; // overlapped copy shorter than a chunk: periodic source
-        u32 back = de - off; // distance of this lane's source byte from pos
-        u32 b = 0;
-        if (d.lane < n) {
-            u32 sp = d.pos - back;
-            b = back <= BRX_RING_BYTES ? (u32)s.ring[(sp + d.a) & RMASK] : (u32)d.out[sp];
-            s.ring[(d.pos + d.lane + d.a) & RMASK] = (u8)b;
-        }
+        u32 lc = d.lane < n ? d.lane : n - 1u; // clamped lane: switched-off lanes redo the last byte
+        u32 off = lc;
+        if (de < n) off = lc % de; // overlapped copy shorter than a chunk: periodic source
+        u32 back = de - off;       // distance of this lane's source byte from pos
+        u32 off_max = de < n ? de - 1u : n - 1u;
+        u32 b = copy_fetch(d, s, de, de - off_max, back);
+        ring_put(d, s, d.lane < n, d.pos + d.lane + d.a, b);
+        if (n >= 2u) { p1 = rdl(b, n - 1u); p2 = rdl(b, n - 2u); }
+        else { p2 = p1; p1 = rdl(b, 0); }
         d.pos += n;
         done += n;
         maybe_flush(d, s);
@@ -556,9 +690,9 @@ FI u32 dict_word(Dec &d, u32 copy_len, u32 word_id, u32 &wl, u32 &wbyte) {
     u32 tid = word_id >> nbits;
     if (tid > 120u) return ST_INVALID_TRANSFORM_ID;
     const u8 *wp = d.t_dict + K_DOFFSET[copy_len] + index * copy_len;
-    u32 w = d.lane < copy_len ? (u32)wp[d.lane] : 0u;
+    u32 w = (u32)wp[d.lane < copy_len ? d.lane : copy_len - 1u]; // clamped, lanes >= copy_len are never selected
     const BrxTransform *x = d.t_xforms + tid;
-    u32 plen = x->plen, slen = x->slen, op = x->op;
+    u32 plen = rfl(x->plen), slen = rfl(x->slen), op = rfl(x->op);
     u32 from = 0, mlen = copy_len, xm = 0;
     if (op == 1u) { // UppercaseFirst, src/transformation/mod.rs:42-82 (Q3: 0x00 first byte -> panic)
         u32 b0 = rdl(w, 0);
@@ -593,11 +727,9 @@ FI u32 dict_word(Dec &d, u32 copy_len, u32 word_id, u32 &wl, u32 &wbyte) {
     wl = plen + mlen + slen;
     u32 j = d.lane;
     u32 mid = (u32)__shfl((int)w, (int)((j - plen + from) & 63u));
-    u32 b;
-    if (j < plen) b = x->prefix[j & 7u];
-    else if (j < plen + mlen) b = mid;
-    else b = x->suffix[(j - plen - mlen) & 7u];
-    wbyte = b;
+    u32 pb = x->prefix[j & 7u], sb = x->suffix[(j - plen - mlen) & 7u]; // unconditional loads + bitwise selects
+    u32 mp = 0u - (u32)(j < plen), mm = (0u - (u32)(j < plen + mlen)) & ~mp;
+    wbyte = (pb & mp) | (mid & mm) | (sb & ~(mp | mm));
     return ST_OK;
 }
 
@@ -623,7 +755,7 @@ FI u32 read_block_count(Dec &d, const Lds &s, u32 h, u32 &blen) {
     u32 sym, e;
     if (decode_sym(d, s, h, sym) != LK_OK) return ST_EOF;
     if (sym > 25u) return ST_INVALID_BLOCK_COUNT_CODE;
-    u32 pk = rdl(d.v_blen, sym);
+    u32 pk = rfl(K_BLEN[sym]);
     if (!in_bits(d, pk & 31u, e)) return ST_EOF;
     blen = (pk >> 5) + e;
     return ST_OK;
@@ -663,10 +795,10 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
             if (!in_bits(d, code, v)) return ST_EOF;
             u32 repeat = (1u << code) + v;
             if (pushed + repeat > len) return ST_RUN_LENGTH_EXCEEDED;
-            for (u32 k = d.lane; k < repeat; k += 64u) tm_st8(d, s, cm + pushed + k, 0u);
+            tm_zero_bytes(d, s, cm + pushed, repeat);
             pushed += repeat;
         } else {
-            if (d.lane == 0u) tm_st8(d, s, cm + pushed, code == 0u ? 0u : code - rlemax);
+            tm_set8(d, s, cm + pushed, code == 0u ? 0u : code - rlemax);
             pushed++;
         }
     }
@@ -674,10 +806,10 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
     if (b) { // inverse_move_to_front_transform, src/lib.rs:1164-1177: the 256-entry list lives 4 per lane
         u32 m0 = d.lane, m1 = d.lane + 64u, m2 = d.lane + 128u, m3 = d.lane + 192u; // mtf[lane + 64*k]
         for (u32 k = 0; k < len; k++) {
-            u32 idx = rfl(tm_ld8(d, s, cm + k));
+            u32 idx = tm_u8(d, s, cm + k);
             u32 q = idx >> 6, l = idx & 63u;
             u32 value = q == 0u ? rdl(m0, l) : q == 1u ? rdl(m1, l) : q == 2u ? rdl(m2, l) : rdl(m3, l);
-            if (d.lane == 0u) tm_st8(d, s, cm + k, value);
+            tm_set8(d, s, cm + k, value);
             // shift mtf[0..idx) up by one, put value in front
             u32 c0 = rdl(m0, 63), c1 = rdl(m1, 63), c2 = rdl(m2, 63);
             u32 s0 = (u32)__shfl_up((int)m0, 1), s1 = (u32)__shfl_up((int)m1, 1), s2 = (u32)__shfl_up((int)m2, 1),
@@ -694,8 +826,353 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
 
 FI u32 lut8(u32 vec, u32 b) { return (rdl(vec, b >> 2) >> ((b & 3u) * 8u)) & 0xffu; }
 
-// One compressed meta-block: header (src/lib.rs:1745-2002) + command loop (src/lib.rs:2003-2141).
-FI u32 compressed_meta_block(Dec &d, Lds &s, u32 mlen) {
+// ---- command loop ------------------------------------------------------------------------------------------
+struct MB { // per-meta-block scalars the command loop needs
+    u32 mlen, npostfix, ndirect, cmode_w, cml, cmd, hl, hi, hd, ntl, ntd;
+};
+
+// Register-resident decode tables (FAST path): every table the command loop touches lives in VGPRs, one
+// entry per lane, and is read with v_readlane -- no LDS round trip on the serial symbol chain.
+//   *H : prefix-code headers, 4 trees per VGPR (lane = 16*(tree&3) + L)
+//   LS : literal symbols, u8 x4 per lane (256 per tree)
+//   DS : distance symbols, u8 x4 per lane, 4 trees per VGPR (lane = 16*(tree&3) + idx/4; alphabet <= 64)
+//   IS : insert&copy symbols of the CURRENT block type, u16 x2 per lane, 6 VGPRs (704 symbols); reloaded
+//        from table memory on the (rare) insert&copy block switch
+//   CMROW: literal context-map row of the current block type (64 B); CMDV: whole distance context map
+struct Fast {
+    u32 LH[2], LS[8], DH[2], DS[2], IH, IS[6], CMROW, CMDV;
+};
+
+FI u32 pick2(const u32 (&a)[2], u32 i) { return i ? a[1] : a[0]; }
+FI u32 pick8(const u32 (&a)[8], u32 i) {
+    u32 x0 = (i & 1u) ? a[1] : a[0], x1 = (i & 1u) ? a[3] : a[2], x2 = (i & 1u) ? a[5] : a[4], x3 = (i & 1u) ? a[7] : a[6];
+    u32 y0 = (i & 2u) ? x1 : x0, y1 = (i & 2u) ? x3 : x2;
+    return (i & 4u) ? y1 : y0;
+}
+
+// Load one tree's header + symbols from table memory (LDS, or the HBM spill arena when the LDS part was
+// full -- the trees are only needed until they sit in registers) into the register tables.
+template <bool INL> FI void fast_load_hdr_as(const Dec &d, const Lds &s, u32 h, u32 t, u32 &hv4) {
+    u32 w = tm_ld32<INL>(d, s, h + (d.lane & 15u));
+    u32 mask = 0u - (u32)((d.lane >> 4) == (t & 3u)); // bitwise select: guaranteed branch-free
+    hv4 = (w & mask) | (hv4 & ~mask);
+}
+FI void fast_load_hdr(const Dec &d, const Lds &s, u32 h, u32 t, u32 &hv4) {
+    if (h < BRX_TM_WORDS) fast_load_hdr_as<true>(d, s, h, t, hv4); else fast_load_hdr_as<false>(d, s, h, t, hv4);
+}
+template <bool INL> FI u32 fast_load_sym8_as(const Dec &d, const Lds &s, u32 h) { // symbols as bytes, 4 per lane
+    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
+    u32 i = d.lane * 2u; // word index into the u16 symbol list: words i, i+1 hold symbols 4*lane .. 4*lane+3
+    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u; // clamp + select: no per-lane branch (see in_load_chunk)
+    u32 w0 = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
+    u32 w1 = tm_ld32<INL>(d, s, h + 16u + (i + 1u < last ? i + 1u : last));
+    w0 = (2u * i < nnz) ? w0 : 0u;
+    w1 = (2u * i + 2u < nnz) ? w1 : 0u;
+    return (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 << 8) & 0xff000000u);
+}
+FI u32 fast_load_sym8(const Dec &d, const Lds &s, u32 h) {
+    return h < BRX_TM_WORDS ? fast_load_sym8_as<true>(d, s, h) : fast_load_sym8_as<false>(d, s, h);
+}
+// same, but every 16-lane quarter holds symbols 0..63 (lane&15 indexes the group of four)
+template <bool INL> FI u32 fast_load_sym8_q_as(const Dec &d, const Lds &s, u32 h) {
+    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
+    u32 i = (d.lane & 15u) * 2u;
+    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u;
+    u32 w0 = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
+    u32 w1 = tm_ld32<INL>(d, s, h + 16u + (i + 1u < last ? i + 1u : last));
+    w0 = (2u * i < nnz) ? w0 : 0u;
+    w1 = (2u * i + 2u < nnz) ? w1 : 0u;
+    return (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 << 8) & 0xff000000u);
+}
+FI u32 fast_load_sym8_q(const Dec &d, const Lds &s, u32 h) {
+    return h < BRX_TM_WORDS ? fast_load_sym8_q_as<true>(d, s, h) : fast_load_sym8_q_as<false>(d, s, h);
+}
+template <bool INL> FI u32 fast_load_sym16_as(const Dec &d, const Lds &s, u32 h, u32 k) { // u16 x2 per lane
+    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
+    u32 i = k * 64u + d.lane;
+    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u;
+    u32 w = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
+    return (2u * i < nnz) ? w : 0u;
+}
+FI u32 fast_load_sym16(const Dec &d, const Lds &s, u32 h, u32 k) {
+    return h < BRX_TM_WORDS ? fast_load_sym16_as<true>(d, s, h, k) : fast_load_sym16_as<false>(d, s, h, k);
+}
+
+// Core of the ballot decode against a 4-trees-per-VGPR header vector.  Returns LK_*; on LK_OK either
+// `single` (kind 1: symbol in idx, zero bits, Q5) or idx = position in the sorted symbol list, L bits taken.
+FI u32 fast_lookup(Dec &d, u32 hv4, u32 slot, u32 &idx, bool &single) {
+    u32 h0 = rdl(hv4, slot * 16u);
+    u32 kind = h0 & 3u;
+    single = false;
+    if (kind != 2u) {
+        if (kind == 0u) return LK_NONE;
+        idx = h0 >> 16;
+        single = true;
+        return LK_OK;
+    }
+    u64 rem = in_remaining(d);
+    u32 peek = in_peek_raw(d) & 0x7fffu;
+    if (rem < 15u) peek &= (1u << (u32)rem) - 1u;
+    u32 v = __brev(peek) >> 17;
+    u32 m = (u32)(ballot(v < (hv4 & 0xffffu)) >> (slot * 16u)) & 0xfffeu;
+    if (m == 0u) {
+        u32 maxlen = (h0 >> 8) & 0xffu;
+        return rem >= (u64)(maxlen + 1u) ? LK_NONE : LK_EOF;
+    }
+    u32 L = (u32)__builtin_ctz(m);
+    if ((u64)L > rem) return LK_EOF;
+    u32 base = rdl(hv4, slot * 16u + L) >> 16;
+    idx = ((v >> (15u - L)) + base) & 0xffffu;
+    in_consume(d, L);
+    return LK_OK;
+}
+
+template <bool FAST> FI u32 command_loop(Dec &d, Lds &s, const MB &m, Cat &L, Cat &I, Cat &D, Prof &pf) {
+    Fast f;
+    u32 rc;
+    bool sw;
+    if (FAST) {
+        for (u32 k = 0; k < 2u; k++) { f.LH[k] = 0; f.DH[k] = 0; f.DS[k] = 0; }
+        f.IH = 0;
+        for (u32 t = 0; t < 8u; t++) {
+            f.LS[t] = 0;
+            if (t < m.ntl) {
+                u32 h = tm_u32(d, s, m.hl + t);
+                fast_load_hdr(d, s, h, t, f.LH[t >> 2]);
+                f.LS[t] = fast_load_sym8(d, s, h);
+            }
+            if (t < m.ntd) {
+                u32 h = tm_u32(d, s, m.hd + t);
+                fast_load_hdr(d, s, h, t, f.DH[t >> 2]);
+                u32 w = fast_load_sym8_q(d, s, h); // lanes 16q..16q+15 all carry the tree's 64 symbols
+                u32 mask = 0u - (u32)((d.lane >> 4) == (t & 3u));
+                f.DS[t >> 2] = (w & mask) | (f.DS[t >> 2] & ~mask);
+            }
+        }
+        for (u32 t = 0; t < 4u; t++)
+            if (t < I.nbl) fast_load_hdr(d, s, tm_u32(d, s, m.hi + t), t, f.IH);
+        {
+            u32 h = tm_u32(d, s, m.hi + I.btype);
+            for (u32 k = 0; k < 6u; k++) f.IS[k] = fast_load_sym16(d, s, h, k);
+        }
+        f.CMROW = s.tm[(m.cml >> 2) + L.btype * 16u + (d.lane & 15u)]; // lanes >= 16 hold copies, never read
+        f.CMDV = s.tm[(m.cmd >> 2) + (d.lane < D.nbl ? d.lane : D.nbl - 1u)];
+    }
+    u32 h_iac = FAST ? 0u : tm_u32(d, s, m.hi + I.btype);
+    u32 cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
+    u32 mb = 0; // MetaBlock.count_output
+    u32 p1, p2;
+    ctx_bytes(d, s, p1, p2);
+
+    // ---- parse_insert_and_copy_length :1179-1208 + decode_insert_and_copy_length :1210-1224 as a lambda-like
+    // block: it runs once before the loop and then as the LOOKAHEAD of every iteration (the next command's
+    // symbol is decoded while the current copy's source bytes are still in flight).
+    u32 insert_len = 0, copy_len = 0;
+    bool implicit_zero = false;
+#define BRX_DECODE_IAC()                                                                                       \
+    do {                                                                                                       \
+        if (++d.wd > d.wd_limit) return ST_WATCHDOG;                                                           \
+        if ((rc = cat_tick(d, s, I, sw))) return rc;                                                           \
+        u32 sym_;                                                                                              \
+        if (FAST) {                                                                                            \
+            if (sw) {                                                                                          \
+                u32 hh_ = tm_u32(d, s, m.hi + I.btype);                                                        \
+                for (u32 kk_ = 0; kk_ < 6u; kk_++) f.IS[kk_] = fast_load_sym16(d, s, hh_, kk_);                \
+            }                                                                                                  \
+            u32 idx_; bool single_;                                                                            \
+            u32 lk_ = fast_lookup(d, f.IH, I.btype, idx_, single_);                                            \
+            if (lk_ == LK_NONE) return ST_PARSE_IAC;                                                           \
+            if (lk_ == LK_EOF) return ST_EOF;                                                                  \
+            if (single_) sym_ = idx_;                                                                          \
+            else {                                                                                             \
+                u32 k_ = idx_ >> 7;                                                                            \
+                u32 w_;                                                                                        \
+                switch (k_) {                                                                                  \
+                case 0: w_ = rdl(f.IS[0], (idx_ >> 1) & 63u); break;                                           \
+                case 1: w_ = rdl(f.IS[1], (idx_ >> 1) & 63u); break;                                           \
+                case 2: w_ = rdl(f.IS[2], (idx_ >> 1) & 63u); break;                                           \
+                case 3: w_ = rdl(f.IS[3], (idx_ >> 1) & 63u); break;                                           \
+                case 4: w_ = rdl(f.IS[4], (idx_ >> 1) & 63u); break;                                           \
+                default: w_ = rdl(f.IS[5], (idx_ >> 1) & 63u); break;                                          \
+                }                                                                                              \
+                sym_ = (w_ >> ((idx_ & 1u) * 16u)) & 0xffffu;                                                  \
+            }                                                                                                  \
+        } else {                                                                                               \
+            if (sw) h_iac = tm_u32(d, s, m.hi + I.btype);                                                      \
+            u32 lk_ = decode_sym(d, s, h_iac, sym_);                                                           \
+            if (lk_ == LK_NONE) return ST_PARSE_IAC;                                                           \
+            if (lk_ == LK_EOF) return ST_EOF;                                                                  \
+        }                                                                                                      \
+        implicit_zero = sym_ < 128u; /* :2012-2015 */                                                          \
+        u32 cell_ = sym_ >> 6;                                                                                 \
+        /* cell -> (insert code offset, copy code offset), one nibble per cell in units of 8:                  \
+           0:(0,0) 1:(0,8) 2:(0,0) 3:(0,8) 4:(8,0) 5:(8,8) 6:(0,16) 7:(16,0) 8:(8,16) 9:(16,8) 10:(16,16) */   \
+        u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                                      \
+        u32 coff_ = (u32)((0x21202101010ull >> (4u * cell_)) & 15u) * 8u;                                      \
+        u32 pki_ = rdl(d.v_ic, ioff_ + ((sym_ >> 3) & 7u));                                                   \
+        u32 pkc_ = rdl(d.v_ic, 32u + coff_ + (sym_ & 7u));                                                         \
+        u32 e_;                                                                                                \
+        if (!in_bits(d, pki_ & 31u, e_)) return ST_EOF;                                                        \
+        insert_len = (pki_ >> 5) + e_;                                                                         \
+        if (!in_bits(d, pkc_ & 31u, e_)) return ST_EOF;                                                        \
+        copy_len = (pkc_ >> 5) + e_;                                                                           \
+    } while (0)
+
+    u64 t0 = TICK();
+    BRX_DECODE_IAC();
+    pf.tk[1] += TICK() - t0;
+    if (FAST) pf.tk[7] += 1;
+    for (;;) {
+        t0 = TICK();
+        if (m.mlen < mb + insert_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2036 (Q4)
+        if (!out_room(d, insert_len)) return ST_OUTPUT_TOO_SMALL;
+        // ---- parse_insert_literals :1286-1365 (+ InsertLiterals state :2048-2081)
+        for (u32 k = 0; k < insert_len; k++) {
+            if ((rc = cat_tick(d, s, L, sw))) return rc;
+            if (sw) {
+                cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
+                if (FAST) f.CMROW = s.tm[(m.cml >> 2) + L.btype * 16u + (d.lane & 15u)];
+            }
+            u32 cid;
+            if (cmode == 3u) cid = (lut8(d.v_lut2, p1) << 3) | lut8(d.v_lut2, p2);
+            else if (cmode == 2u) cid = lut8(d.v_lut0, p1) | lut8(d.v_lut1, p2);
+            else if (cmode == 0u) cid = p1 & 0x3fu;
+            else cid = p1 >> 2;
+            u32 lit;
+            if (FAST) {
+                u32 ti = (rdl(f.CMROW, cid >> 2) >> ((cid & 3u) * 8u)) & 0xffu;
+                u32 idx; bool single;
+                u32 lk = fast_lookup(d, pick2(f.LH, ti >> 2), ti & 3u, idx, single);
+                if (lk == LK_NONE) return ST_PARSE_LITERALS;
+                if (lk == LK_EOF) return ST_EOF;
+                if (single) lit = idx;
+                else lit = (rdl(pick8(f.LS, ti), idx >> 2) >> ((idx & 3u) * 8u)) & 0xffu;
+            } else {
+                u32 ti = tm_u8(d, s, m.cml + L.btype * 64u + cid);
+                u32 h = tm_u32(d, s, m.hl + ti);
+                u32 lk = decode_sym(d, s, h, lit);
+                if (lk == LK_NONE) return ST_PARSE_LITERALS;
+                if (lk == LK_EOF) return ST_EOF;
+            }
+            ring_put(d, s, d.lane == 0u, d.pos + d.a, lit);
+            d.pos++;
+            p2 = p1;
+            p1 = lit;
+            if (((d.pos + d.a) & 63u) == 0u) maybe_flush(d, s);
+        }
+        if (insert_len) {
+            mb += insert_len;
+            maybe_flush(d, s);
+        }
+        pf.tk[2] += TICK() - t0;
+        pf.tk[6] += insert_len;
+        if (mb == m.mlen) break; // :2069: the copy part of the last command is ignored
+
+        // ---- parse_distance_code :1367-1410
+        t0 = TICK();
+        u32 dcode;
+        if (implicit_zero) {
+            dcode = 0;
+        } else {
+            if ((rc = cat_tick(d, s, D, sw))) return rc;
+            u32 cid = copy_len >= 5u ? 3u : copy_len - 2u;
+            if (FAST) {
+                u32 ti = (rdl(f.CMDV, D.btype) >> (cid * 8u)) & 0xffu;
+                u32 idx; bool single;
+                u32 lk = fast_lookup(d, pick2(f.DH, ti >> 2), ti & 3u, idx, single);
+                if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
+                if (lk == LK_EOF) return ST_EOF;
+                if (single) dcode = idx;
+                else dcode = (rdl(pick2(f.DS, ti >> 2), (ti & 3u) * 16u + ((idx >> 2) & 15u)) >> ((idx & 3u) * 8u)) & 0xffu;
+            } else {
+                u32 ti = tm_u8(d, s, m.cmd + D.btype * 4u + cid);
+                u32 h = tm_u32(d, s, m.hd + ti);
+                u32 lk = decode_sym(d, s, h, dcode);
+                if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
+                if (lk == LK_EOF) return ST_EOF;
+            }
+        }
+        // ---- decode_distance :1412-1481
+        u32 distance, e;
+        if (dcode <= 3u) {
+            distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
+        } else if (dcode <= 15u) {
+            long long basev = dcode <= 9u ? (long long)d.dist0 : (long long)d.dist1;
+            long long delta = dcode <= 9u ? (long long)((dcode - 2u) >> 1) : (long long)((dcode - 8u) >> 1);
+            long long r = (dcode & 1u) ? basev + delta : basev - delta;
+            if (r <= 0) return ST_NON_POSITIVE_DISTANCE;
+            distance = (u32)r;
+        } else if (dcode <= 15u + m.ndirect) {
+            distance = dcode - 15u;
+        } else {
+            u32 x = dcode - m.ndirect - 16u;
+            u32 ndistbits = 1u + (x >> (m.npostfix + 1u));
+            if (!in_bits(d, ndistbits, e)) return ST_EOF;
+            u32 hcode = x >> m.npostfix;
+            u32 lcode = x & ((1u << m.npostfix) - 1u);
+            u32 offset = ((2u + (hcode & 1u)) << ndistbits) - 4u;
+            distance = ((offset + e) << m.npostfix) + lcode + m.ndirect + 1u;
+        }
+        const u32 max_allowed = d.pos < d.window ? d.pos : d.window;
+        if (dcode > 0u && distance <= max_allowed) { // :1476-1478
+            d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
+        }
+        pf.tk[3] += TICK() - t0;
+        t0 = TICK();
+        pf.tk[5] += 1;
+        // ---- copy_literals :1483-1542 (+ CopyLiterals state :2102-2141)
+        if (distance <= max_allowed) {
+            if (m.mlen < mb + copy_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2105
+            if (!out_room(d, copy_len)) return ST_OUTPUT_TOO_SMALL;
+            mb += copy_len;
+            if (copy_len <= 64u && distance >= copy_len) {
+                // the common case, software pipelined: issue the source read (LDS ring or the stream's own
+                // HBM output), decode the NEXT command while the bytes are in flight, then land them.
+                const u32 cl = copy_len; // the lookahead below overwrites insert_len / copy_len / implicit_zero
+                const u32 lc = d.lane < cl ? d.lane : cl - 1u; // switched-off lanes redo the last byte
+                const u32 b = copy_fetch(d, s, distance, distance - (cl - 1u), distance - lc);
+                const bool more = mb != m.mlen;
+                if (more) BRX_DECODE_IAC();
+                ring_put(d, s, d.lane < cl, d.pos + d.lane + d.a, b);
+                d.pos += cl;
+                p1 = rdl(b, cl - 1u); // cl >= 2 always (copy length codes start at 2)
+                p2 = rdl(b, cl - 2u);
+                maybe_flush(d, s);
+                pf.tk[4] += TICK() - t0;
+                if (!more) break; // :2128
+                continue;
+            }
+            window_copy(d, s, distance, copy_len, p1, p2);
+        } else {
+            if (copy_len < 4u || copy_len > 24u) return ST_INVALID_DICT_LENGTH;
+            u32 wl, wb;
+            if ((rc = dict_word(d, copy_len, distance - max_allowed - 1u, wl, wb))) return rc;
+            if (m.mlen < mb + wl) return ST_EXCEEDED_EXPECTED_BYTES; // :2105 on the transformed length (Q4)
+            if (!out_room(d, wl)) return ST_OUTPUT_TOO_SMALL;
+            ring_put(d, s, d.lane < wl, d.pos + d.lane + d.a, wb);
+            d.pos += wl;
+            mb += wl;
+            if (wl >= 2u) { p1 = rdl(wb, wl - 1u); p2 = rdl(wb, wl - 2u); }
+            else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
+            maybe_flush(d, s);
+        }
+        pf.tk[4] += TICK() - t0;
+        if (mb == m.mlen) break; // :2128
+        t0 = TICK();
+        BRX_DECODE_IAC();
+        pf.tk[1] += TICK() - t0;
+    }
+#undef BRX_DECODE_IAC
+    return ST_OK;
+}
+
+// Meta-block header (reference states NBltypesL .. PrefixCodesDistances, src/lib.rs:1745-2002), out of line.
+// Input: decoder state in Lds::st.  Output: status; on ST_OK the header results sit in Lds::mbw and the
+// advanced input cursor / table-memory tops in Lds::st.
+__device__ __noinline__ u32 cold_header() {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
     Cat L, I, D, cur;
     u32 rc, v;
     d.lds_top = 0;
@@ -744,11 +1221,11 @@ FI u32 compressed_meta_block(Dec &d, Lds &s, u32 mlen) {
             cmode_w = tm_alloc(d, (L.nbl + 3u) >> 2); // context modes, 2 bits per literal block type :562
             for (u32 i = 0; i < L.nbl; i++) {
                 if (!in_bits(d, 2, v)) return ST_EOF;
-                if (d.lane == 0u) tm_st8(d, s, cmode_w * 4u + i, v);
+                tm_set8(d, s, cmode_w * 4u + i, v);
             }
             if ((rc = read_n_bltypes(d, ntl))) return rc; // parse_n_trees_l :575
             cml = tm_alloc(d, 16u * L.nbl) * 4u; // 64 bytes per block type, zero = tree 0
-            for (u32 k = d.lane; k < 16u * L.nbl; k += 64u) tm_st32(d, s, (cml >> 2) + k, 0u);
+            tm_zero_words(d, s, cml >> 2, 16u * L.nbl);
             if (ntl >= 2u) {
                 cm = cml; cm_len = 64u * L.nbl; which = 0;
                 step = S_CM;
@@ -760,7 +1237,7 @@ FI u32 compressed_meta_block(Dec &d, Lds &s, u32 mlen) {
         } else if (step == S_NTD) {
             if ((rc = read_n_bltypes(d, ntd))) return rc; // parse_n_trees_d :582
             cmd = tm_alloc(d, D.nbl) * 4u; // 4 bytes per block type
-            for (u32 k = d.lane; k < D.nbl; k += 64u) tm_st32(d, s, (cmd >> 2) + k, 0u);
+            tm_zero_words(d, s, cmd >> 2, D.nbl);
             if (ntd >= 2u) {
                 cm = cmd; cm_len = 4u * D.nbl; which = 1;
                 step = S_CM;
@@ -776,7 +1253,7 @@ FI u32 compressed_meta_block(Dec &d, Lds &s, u32 mlen) {
             step = S_CODE;
             alphabet = 256u; // parse_prefix_codes_literals :1016
         } else if (step == S_CODE) {
-            if (d.lane == 0u) tm_st32(d, s, ht + idx, h);
+            tm_set32(d, s, ht + idx, h);
             idx++;
             if (idx == total) break;
             // :1016 literals (256), :1034 insert&copy (704), :1052 distances (16 + NDIRECT + 48<<NPOSTFIX)
@@ -805,185 +1282,155 @@ FI u32 compressed_meta_block(Dec &d, Lds &s, u32 mlen) {
         if ((rc = read_prefix_code(d, s, alphabet, h))) return rc;
     }
     const u32 hl = ht, hi = ht + ntl, hd = ht + ntl + I.nbl;
-
-    u32 mb = 0; // MetaBlock.count_output
-    u32 h_iac = rfl(tm_ld32(d, s, hi + I.btype));
-    u32 cmode = rfl(tm_ld8(d, s, cmode_w * 4u + L.btype));
-    bool sw;
-    for (;;) {
-        if (++d.wd > d.wd_limit) return ST_WATCHDOG;
-        // ---- parse_insert_and_copy_length :1179-1208
-        if ((rc = cat_tick(d, s, I, sw))) return rc;
-        if (sw) h_iac = rfl(tm_ld32(d, s, hi + I.btype));
-        u32 sym;
-        u32 lk = decode_sym(d, s, h_iac, sym);
-        if (lk == LK_NONE) return ST_PARSE_IAC;
-        if (lk == LK_EOF) return ST_EOF;
-        const bool implicit_zero = sym < 128u; // :2012-2015
-        // ---- decode_insert_and_copy_length :1210-1224 (table = spec section 5)
-        u32 cell = sym >> 6;
-        // cell -> (insert code offset, copy code offset): 0:(0,0) 1:(0,8) 2:(0,0) 3:(0,8) 4:(8,0) 5:(8,8)
-        // 6:(0,16) 7:(16,0) 8:(8,16) 9:(16,8) 10:(16,16); one nibble per cell, in units of 8
-        u32 ioff = (u32)((0x22120110000ull >> (4u * cell)) & 15u) * 8u;
-        u32 coff = (u32)((0x21202101010ull >> (4u * cell)) & 15u) * 8u;
-        u32 pki = rdl(d.v_ins, ioff + ((sym >> 3) & 7u));
-        u32 pkc = rdl(d.v_copy, coff + (sym & 7u));
-        u32 e;
-        if (!in_bits(d, pki & 31u, e)) return ST_EOF;
-        u32 insert_len = (pki >> 5) + e;
-        if (!in_bits(d, pkc & 31u, e)) return ST_EOF;
-        u32 copy_len = (pkc >> 5) + e;
-        if (mlen < mb + insert_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2036 (Q4)
-        if (!out_room(d, insert_len)) return ST_OUTPUT_TOO_SMALL;
-
-        // ---- parse_insert_literals :1286-1365 (+ InsertLiterals state :2048-2081)
-        if (insert_len) {
-            u32 p1, p2;
-            ctx_bytes(d, s, p1, p2);
-            for (u32 k = 0; k < insert_len; k++) {
-                if ((rc = cat_tick(d, s, L, sw))) return rc;
-                if (sw) cmode = rfl(tm_ld8(d, s, cmode_w * 4u + L.btype));
-                u32 cid;
-                if (cmode == 0u) cid = p1 & 0x3fu;
-                else if (cmode == 1u) cid = p1 >> 2;
-                else if (cmode == 2u) cid = lut8(d.v_lut0, p1) | lut8(d.v_lut1, p2);
-                else cid = (lut8(d.v_lut2, p1) << 3) | lut8(d.v_lut2, p2);
-                u32 ti = rfl(tm_ld8(d, s, cml + L.btype * 64u + cid));
-                u32 h = rfl(tm_ld32(d, s, hl + ti));
-                u32 lit;
-                lk = decode_sym(d, s, h, lit);
-                if (lk == LK_NONE) return ST_PARSE_LITERALS;
-                if (lk == LK_EOF) return ST_EOF;
-                if (d.lane == 0u) s.ring[(d.pos + d.a) & RMASK] = (u8)lit;
-                d.pos++;
-                p2 = p1;
-                p1 = lit;
-                if (((d.pos + d.a) & 63u) == 0u) maybe_flush(d, s);
-            }
-            mb += insert_len;
-            maybe_flush(d, s);
-        }
-        if (mb == mlen) break; // :2069: the copy part of the last command is ignored
-
-        // ---- parse_distance_code :1367-1410
-        u32 dcode;
-        if (implicit_zero) {
-            dcode = 0;
-        } else {
-            if ((rc = cat_tick(d, s, D, sw))) return rc;
-            u32 cid = copy_len >= 5u ? 3u : copy_len - 2u;
-            u32 ti = rfl(tm_ld8(d, s, cmd + D.btype * 4u + cid));
-            u32 h = rfl(tm_ld32(d, s, hd + ti));
-            lk = decode_sym(d, s, h, dcode);
-            if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
-            if (lk == LK_EOF) return ST_EOF;
-        }
-        // ---- decode_distance :1412-1481
-        u32 distance;
-        if (dcode <= 3u) {
-            distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
-        } else if (dcode <= 15u) {
-            long long basev = dcode <= 9u ? (long long)d.dist0 : (long long)d.dist1;
-            long long delta = dcode <= 9u ? (long long)((dcode - 2u) >> 1) : (long long)((dcode - 8u) >> 1);
-            long long r = (dcode & 1u) ? basev + delta : basev - delta;
-            if (r <= 0) return ST_NON_POSITIVE_DISTANCE;
-            distance = (u32)r;
-        } else if (dcode <= 15u + ndirect) {
-            distance = dcode - 15u;
-        } else {
-            u32 x = dcode - ndirect - 16u;
-            u32 ndistbits = 1u + (x >> (npostfix + 1u));
-            if (!in_bits(d, ndistbits, e)) return ST_EOF;
-            u32 hcode = x >> npostfix;
-            u32 lcode = x & ((1u << npostfix) - 1u);
-            u32 offset = ((2u + (hcode & 1u)) << ndistbits) - 4u;
-            distance = ((offset + e) << npostfix) + lcode + ndirect + 1u;
-        }
-        const u32 max_allowed = d.pos < d.window ? d.pos : d.window;
-        if (dcode > 0u && distance <= max_allowed) { // :1476-1478
-            d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
-        }
-        // ---- copy_literals :1483-1542 (+ CopyLiterals state :2102-2141)
-        if (distance <= max_allowed) {
-            if (mlen < mb + copy_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2105
-            if (!out_room(d, copy_len)) return ST_OUTPUT_TOO_SMALL;
-            window_copy(d, s, distance, copy_len);
-            mb += copy_len;
-        } else {
-            if (copy_len < 4u || copy_len > 24u) return ST_INVALID_DICT_LENGTH;
-            u32 wl, wb;
-            if ((rc = dict_word(d, copy_len, distance - max_allowed - 1u, wl, wb))) return rc;
-            if (mlen < mb + wl) return ST_EXCEEDED_EXPECTED_BYTES; // :2105 on the transformed length (Q4)
-            if (!out_room(d, wl)) return ST_OUTPUT_TOO_SMALL;
-            if (d.lane < wl) s.ring[(d.pos + d.lane + d.a) & RMASK] = (u8)wb;
-            d.pos += wl;
-            mb += wl;
-            maybe_flush(d, s);
-        }
-        if (mb == mlen) break; // :2128
+    if (d.lane == 0u) {
+        u32 *w = s.mbw;
+        w[0] = npostfix; w[1] = ndirect; w[2] = cmode_w; w[3] = cml; w[4] = cmd; w[5] = hl; w[6] = hi; w[7] = hd;
+        w[8] = ntl; w[9] = ntd; w[10] = dalpha;
+        w[12] = L.nbl; w[13] = L.btype; w[14] = L.btype_prev; w[15] = L.blen; w[16] = L.h_types; w[17] = L.h_counts;
+        w[18] = I.nbl; w[19] = I.btype; w[20] = I.btype_prev; w[21] = I.blen; w[22] = I.h_types; w[23] = I.h_counts;
+        w[24] = D.nbl; w[25] = D.btype; w[26] = D.btype_prev; w[27] = D.blen; w[28] = D.h_types; w[29] = D.h_counts;
+        // Register-resident tables when the meta-block is small enough (the common case).  The trees themselves
+        // may sit in the HBM spill arena (they are copied into registers once); what the loop keeps reading
+        // from LDS are the context maps and context modes, allocated first.
+        w[30] = (ntl <= 8u && ntd <= 8u && I.nbl <= 4u && dalpha <= 64u && D.nbl <= 64u &&
+                 cml + 64u * L.nbl <= TM_BYTES && cmd + 4u * D.nbl <= TM_BYTES) ? 1u : 0u;
     }
+    dec_store(d, s);
     return ST_OK;
 }
 
-// Whole stream: reference decompress(), src/lib.rs:1545-2170.
-FI u32 decode_stream(Dec &d, Lds &s) {
+FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
+    const u32 *w = s.mbw;
+    m.npostfix = rfl(w[0]); m.ndirect = rfl(w[1]); m.cmode_w = rfl(w[2]); m.cml = rfl(w[3]); m.cmd = rfl(w[4]);
+    m.hl = rfl(w[5]); m.hi = rfl(w[6]); m.hd = rfl(w[7]); m.ntl = rfl(w[8]); m.ntd = rfl(w[9]);
+    L.nbl = rfl(w[12]); L.btype = rfl(w[13]); L.btype_prev = rfl(w[14]); L.blen = rfl(w[15]); L.h_types = rfl(w[16]); L.h_counts = rfl(w[17]);
+    I.nbl = rfl(w[18]); I.btype = rfl(w[19]); I.btype_prev = rfl(w[20]); I.blen = rfl(w[21]); I.h_types = rfl(w[22]); I.h_counts = rfl(w[23]);
+    D.nbl = rfl(w[24]); D.btype = rfl(w[25]); D.btype_prev = rfl(w[26]); D.blen = rfl(w[27]); D.h_types = rfl(w[28]); D.h_counts = rfl(w[29]);
+}
+
+// Lds::st slots beyond the Dec fields (dec_store uses 0..32)
+#define ST_STARTED 33 // 0 before the stream header (WBITS) has been read
+#define ST_ISLAST 34  // ISLAST of the meta-block handed to the command loop
+#define ST_MLEN 35    // its MLEN
+#define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
+
+// The table-memory command loop for meta-blocks too large for the register tables, out of line.
+__device__ __noinline__ u32 cold_commands() {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
+    MB m;
+    Cat L, I, D;
+    mb_load(s, m, L, I, D);
+    m.mlen = rfl(s.st[ST_MLEN]);
+    Prof pf;
+    pf.on = false;
+    u32 rc = command_loop<false>(d, s, m, L, I, D, pf);
+    dec_store(d, s);
+    return rc;
+}
+
+// The register-table command loop: THE hot function.  Nothing cold is inlined into it, so its register
+// allocation is its own (the v1 kernel, everything inlined, needed 1000+ SGPR spill slots = 16 VGPRs of spill
+// lanes, which pushed the decode tables into scratch memory: 2000+ cycles per literal, profiles/ r01b notes).
+__device__ __noinline__ u32 hot_commands(u32 prof_on) {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
+    MB m;
+    Cat L, I, D;
+    mb_load(s, m, L, I, D);
+    m.mlen = rfl(s.st[ST_MLEN]);
+    Prof pf;
+    pf.on = rfl(prof_on) != 0u;
+    for (int q = 0; q < 8; q++) pf.tk[q] = 0;
+    u32 rc = command_loop<true>(d, s, m, L, I, D, pf);
+    dec_store(d, s);
+    if (pf.on) { // lanes 0..7 each add one 64-bit counter (two dwords in LDS); other lanes add 0 to slot 7
+        u32 q = d.lane < 8u ? d.lane : 7u;
+        u64 add = 0;
+        for (int k = 0; k < 8; k++) add = q == (u32)k ? pf.tk[k] : add;
+        add = d.lane < 8u ? add : 0ull;
+        u64 cur = (u64)s.pad[2 * q] | ((u64)s.pad[2 * q + 1] << 32);
+        cur += add;
+        s.pad[2 * q] = (u32)cur;
+        s.pad[2 * q + 1] = (u32)(cur >> 32);
+    }
+    return rc;
+}
+
+// Stream framing: reference decompress() states StreamBegin .. IsUncompressed / MLenLiterals and MetaBlockEnd ..
+// StreamEnd (src/lib.rs:1550-1744, 2142-2167).  Runs until the stream ends (returns its final status) or a
+// compressed meta-block starts (returns SEG_NEED_HEADER with MLEN / ISLAST parked in Lds::st).
+__device__ __noinline__ u32 seg_frame() {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
     u32 v, b;
-    // parse_wbits :412-418 over the fixed tree :89-119.  Stream order: 0 -> 16; 1 nnn (n != 0) -> 17+n;
-    // 1 000 mmm: m=0 -> 17, m=1 -> no entry (the reference walks off its array: UnexpectedEOF), m>=2 -> 8+m
-    if (!in_bits(d, 1, b)) return ST_EOF;
-    u32 wbits;
-    if (!b) {
-        wbits = 16;
-    } else {
-        if (!in_bits(d, 3, v)) return ST_EOF;
-        if (v) {
-            wbits = 17u + v;
+    u32 rc = ST_OK;
+    bool finished = false;
+    if (rfl(s.st[ST_STARTED]) == 0u) {
+        // parse_wbits :412-418 over the fixed tree :89-119.  Stream order: 0 -> 16; 1 nnn (n != 0) -> 17+n;
+        // 1 000 mmm: m=0 -> 17, m=1 -> no entry (the reference walks off its array: UnexpectedEOF), m>=2 -> 8+m
+        if (!in_bits(d, 1, b)) return ST_EOF;
+        u32 wbits;
+        if (!b) {
+            wbits = 16;
         } else {
             if (!in_bits(d, 3, v)) return ST_EOF;
-            if (v == 1u) return ST_EOF;
-            wbits = v == 0u ? 17u : 8u + v;
+            if (v) {
+                wbits = 17u + v;
+            } else {
+                if (!in_bits(d, 3, v)) return ST_EOF;
+                if (v == 1u) return ST_EOF;
+                wbits = v == 0u ? 17u : 8u + v;
+            }
         }
+        d.window = (1u << wbits) - 16u;
+        if (d.lane == 0u) s.st[ST_STARTED] = 1u;
+    } else if (rfl(s.st[ST_ISLAST]) != 0u) {
+        finished = true; // back from the command loop of the last meta-block: MetaBlockEnd :2146-2153
     }
-    d.window = (1u << wbits) - 16u;
-    for (;;) {
-        if (++d.wd > d.wd_limit) return ST_WATCHDOG;
+    while (!finished) {
+        if (++d.wd > d.wd_limit) { rc = ST_WATCHDOG; break; }
         u32 is_last;
-        if (!in_bits(d, 1, is_last)) return ST_EOF; // parse_is_last :420
+        if (!in_bits(d, 1, is_last)) { rc = ST_EOF; break; } // parse_is_last :420
         if (is_last) {
-            if (!in_bits(d, 1, b)) return ST_EOF; // parse_is_last_empty :427
+            if (!in_bits(d, 1, b)) { rc = ST_EOF; break; } // parse_is_last_empty :427
             if (b) break;
         }
-        if (!in_bits(d, 2, v)) return ST_EOF; // parse_m_nibbles :434
+        if (!in_bits(d, 2, v)) { rc = ST_EOF; break; } // parse_m_nibbles :434
         u32 mnibbles = v == 3u ? 0u : v + 4u;
         if (mnibbles == 0u) { // metadata block (accepted with ISLAST too, Q9), :1617-1683
-            if (!in_bits(d, 1, b)) return ST_EOF;
-            if (b) return ST_NON_ZERO_RESERVED_BIT;
+            if (!in_bits(d, 1, b)) { rc = ST_EOF; break; }
+            if (b) { rc = ST_NON_ZERO_RESERVED_BIT; break; }
             u32 mskipbytes;
-            if (!in_bits(d, 2, mskipbytes)) return ST_EOF;
+            if (!in_bits(d, 2, mskipbytes)) { rc = ST_EOF; break; }
             if (mskipbytes == 0u) {
-                if (in_byte_tail(d)) return ST_NON_ZERO_FILL_BIT;
+                if (in_byte_tail(d)) { rc = ST_NON_ZERO_FILL_BIT; break; }
             } else {
                 u32 skip = 0, last = 0; // parse_m_skip_len :449-467: byte << i (Q2); errors -> EOF (Q10)
+                bool bad = false;
                 for (u32 i = 0; i < mskipbytes; i++) {
-                    if (!in_bits(d, 8, last)) return ST_EOF;
+                    if (!in_bits(d, 8, last)) { bad = true; break; }
                     skip |= last << i;
                 }
-                if (mskipbytes > 1u && last == 0u) return ST_EOF;
+                if (bad || (mskipbytes > 1u && last == 0u)) { rc = ST_EOF; break; }
                 skip += 1u;
-                if (in_byte_tail(d)) return ST_NON_ZERO_FILL_BIT;
-                if (in_remaining(d) < 8ull * skip) return ST_EOF;
+                if (in_byte_tail(d)) { rc = ST_NON_ZERO_FILL_BIT; break; }
+                if (in_remaining(d) < 8ull * skip) { rc = ST_EOF; break; }
                 in_seek(d, d.bitpos + 8ull * skip);
             }
         } else {
-            if (!in_bits(d, 4u * mnibbles, v)) return ST_EOF; // parse_m_len :469-483
-            if (mnibbles > 4u && (v >> ((mnibbles - 1u) * 4u)) == 0u) return ST_NON_ZERO_TRAILER_NIBBLE;
+            if (!in_bits(d, 4u * mnibbles, v)) { rc = ST_EOF; break; } // parse_m_len :469-483
+            if (mnibbles > 4u && (v >> ((mnibbles - 1u) * 4u)) == 0u) { rc = ST_NON_ZERO_TRAILER_NIBBLE; break; }
             u32 mlen = v + 1u;
             u32 uncompressed = 0;
-            if (!is_last && !in_bits(d, 1, uncompressed)) return ST_EOF; // :1689-1699
+            if (!is_last && !in_bits(d, 1, uncompressed)) { rc = ST_EOF; break; } // :1689-1699
             if (uncompressed) { // :1701-1734
-                if (in_byte_tail(d)) return ST_NON_ZERO_FILL_BIT;
-                if (in_remaining(d) < 8ull * mlen) return ST_EOF;
-                if (!out_room(d, mlen)) return ST_OUTPUT_TOO_SMALL;
+                if (in_byte_tail(d)) { rc = ST_NON_ZERO_FILL_BIT; break; }
+                if (in_remaining(d) < 8ull * mlen) { rc = ST_EOF; break; }
+                if (!out_room(d, mlen)) { rc = ST_OUTPUT_TOO_SMALL; break; }
                 const u8 *src = (const u8 *)d.in_words + (d.bitpos >> 3);
                 for (u32 done = 0; done < mlen; done += 64u) {
                     u32 n = mlen - done < 64u ? mlen - done : 64u;
@@ -992,71 +1439,96 @@ FI u32 decode_stream(Dec &d, Lds &s) {
                     maybe_flush(d, s);
                 }
                 in_seek(d, d.bitpos + 8ull * mlen);
-            } else {
-                u32 rc = compressed_meta_block(d, s, mlen);
-                if (rc) return rc;
+            } else { // compressed meta-block: the dispatcher runs cold_header + a command loop, then comes back
+                if (d.lane == 0u) { s.st[ST_ISLAST] = is_last; s.st[ST_MLEN] = mlen; }
+                dec_store(d, s);
+                return SEG_NEED_HEADER;
             }
         }
         if (is_last) break; // MetaBlockEnd :2146-2153
     }
-    // StreamEnd :2155-2167
-    if (in_byte_tail(d)) return ST_NON_ZERO_TRAILER_BIT;
-    if (d.bitpos < d.bitend) return ST_EXPECTED_END_OF_STREAM;
-    return ST_OK;
+    if (rc == ST_OK) { // StreamEnd :2155-2167
+        if (in_byte_tail(d)) rc = ST_NON_ZERO_TRAILER_BIT;
+        else if (d.bitpos < d.bitend) rc = ST_EXPECTED_END_OF_STREAM;
+    }
+    dec_store(d, s);
+    return rc;
 }
 
-__global__ __launch_bounds__(BRX_WAVE) void brx_decode_kernel(BrxKernelArgs a) {
-    __shared__ Lds s;
+// Drain the ring to HBM at the end of a stream.
+__device__ __noinline__ void seg_finish() {
+    Lds &s = g_lds;
     Dec d;
-    d.lane = threadIdx.x;
+    dec_load(d, s);
+    if (d.vfl < d.pos + d.a) flush_range(d, s, d.vfl, d.pos + d.a);
+}
+
+// The kernel itself is only a dispatcher: per stream it parks the initial state in LDS and then alternates
+// between the out-of-line segments.  Keeping it this small is what lets every segment have its own register
+// allocation (nothing but `a`, `sid` and &s is live across the calls).
+__global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a) {
+    Lds &s = g_lds;
+    const u32 lane = threadIdx.x;
     if (a.debug_stop == 1u) return;
-    d.t_dict = a.t.dict;
-    d.t_xforms = a.t.xforms;
-    d.scratch = a.scratch + (size_t)blockIdx.x * BRX_SCRATCH_WORDS;
-    d.v_ins = d.lane < 24u ? K_INS[d.lane] : 0u;
-    d.v_copy = d.lane < 24u ? K_COPY[d.lane] : 0u;
-    d.v_blen = d.lane < 26u ? K_BLEN[d.lane] : 0u;
-    d.v_lut0 = ((const u32 *)a.t.context_lut)[d.lane];
-    d.v_lut1 = ((const u32 *)a.t.context_lut)[64u + d.lane];
-    d.v_lut2 = ((const u32 *)a.t.context_lut)[128u + d.lane];
-    if (a.debug_stop == 2u) return;
     for (;;) {
         // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
         // behind the lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63
         // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
-        u32 sid = rdl(atomicAdd(a.work_counter, d.lane == 0u ? 1u : 0u), 0);
+        u32 sid = rdl(atomicAdd(a.work_counter, lane == 0u ? 1u : 0u), 0);
         if (sid >= a.n) break;
-        if (a.debug_stop == 3u) { if (d.lane == 0u) { a.status[sid] = 100; a.out_len[sid] = 0; } continue; }
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
-        const u8 *inp = a.in + i0;
-        const u32 mis = (u32)((uintptr_t)inp & 3u);
-        d.in_words = (const u32 *)(inp - mis);
-        const u64 in_len = i1 - i0;
-        d.w_end = (u32)((mis + in_len + 3u) >> 2);
-        d.bitend = 8ull * (mis + in_len);
-        d.cbase = 0;
-        d.chunkA = in_load_chunk(d, 0);
-        d.chunkB = in_load_chunk(d, 64u);
-        in_seek(d, 8ull * mis);
-        if (a.debug_stop == 4u) { if (d.lane == 0u) { a.status[sid] = 101; a.out_len[sid] = (u64)d.win; } continue; }
-        d.out = a.out + o0;
-        const u64 capacity = o1 - o0;
-        d.cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
-        d.pos = 0;
-        d.a = (u32)((uintptr_t)d.out & 15u);
-        d.vfl = d.a;
-        d.dist0 = 4; d.dist1 = 11; d.dist2 = 15; d.dist3 = 16; // src/lib.rs:408
-        d.needed = 0;
-        d.wd = 0;
-        d.wd_limit = 8ull * in_len + (u64)d.cap + 65536ull;
-        d.lds_top = 0;
-        d.scr_top = 0;
-        u32 st = decode_stream(d, s);
-        if (d.vfl < d.pos + d.a) flush_range(d, s, d.vfl, d.pos + d.a); // drain the ring
-        if (d.lane == 0u) {
+        {
+            Dec d;
+            d.lane = lane;
+            const u8 *inp = a.in + i0;
+            const u32 mis = (u32)((uintptr_t)inp & 3u);
+            d.in_words = (const u32 *)(inp - mis);
+            const u64 in_len = i1 - i0;
+            d.w_end = (u32)((mis + in_len + 3u) >> 2);
+            d.bitend = 8ull * (mis + in_len);
+            d.bitpos = 8ull * mis;
+            d.out = a.out + o0;
+            const u64 capacity = o1 - o0;
+            d.cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
+            d.pos = 0;
+            d.a = (u32)((uintptr_t)d.out & 15u);
+            d.vfl = d.a;
+            d.window = 0;
+            d.dist0 = 4; d.dist1 = 11; d.dist2 = 15; d.dist3 = 16; // src/lib.rs:408
+            d.needed = 0;
+            d.wd = 0;
+            d.wd_limit = 8ull * in_len + (u64)d.cap + 65536ull;
+            d.lds_top = 0;
+            d.scr_top = 0;
+            d.scratch = a.scratch + (size_t)blockIdx.x * BRX_SCRATCH_WORDS;
+            d.t_dict = a.t.dict;
+            d.t_xforms = a.t.xforms;
+            d.t_lut = (const u32 *)a.t.context_lut;
+            dec_store(d, s);
+            if (lane == 0u) { s.st[ST_STARTED] = 0u; s.st[ST_ISLAST] = 0u; s.st[ST_MLEN] = 0u; }
+            if (lane < 32u) s.pad[lane] = 0u;
+        }
+        const u32 prof_on = a.debug != nullptr ? 1u : 0u;
+        u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
+        u32 st = seg_frame();
+        while (st == SEG_NEED_HEADER) {
+            st = cold_header();
+            if (st) break;
+            st = rfl(s.mbw[30]) ? hot_commands(prof_on) : cold_commands();
+            if (st) break;
+            st = seg_frame();
+        }
+        seg_finish();
+        u32 pos = rfl(s.st[10]), needed = rfl(s.st[22]);
+        if (prof_on && lane < 8u) a.debug[(size_t)sid * 10u + lane] = (u64)s.pad[2 * lane] | ((u64)s.pad[2 * lane + 1] << 32);
+        if (prof_on && lane == 0u) {
+            a.debug[(size_t)sid * 10u + 8] = (u64)__builtin_readcyclecounter() - tstream;
+            a.debug[(size_t)sid * 10u + 9] = s.st[19];
+        }
+        if (lane == 0u) {
             a.status[sid] = (int)st;
-            a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)d.needed : (u64)d.pos;
+            a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)needed : (u64)pos;
         }
     }
 }
