@@ -1,0 +1,93 @@
+// decompressor.hpp -- C++ host-side mirror of the reference's only public item,
+//
+//     pub struct Decompressor<R: Read>                         (reference src/lib.rs:377-394)
+//     pub fn new(r: R) -> Decompressor<R>                      (reference src/lib.rs:398-410)
+//     impl<R: Read> Read for Decompressor<R> { fn read(..) }   (reference src/lib.rs:2173-2193)
+//
+// on top of the C ABI (include/brx.h).  The reference is Rust; this image has no Rust toolchain, so the
+// host side that sits above the C ABI is written in C++ with the same shape (INTEGRATION.md shows the Rust
+// shim a maintainer of the reference would add).  Header-only; link with -lbrx.
+//
+//   brotli::Decompressor<brotli::SliceReader> d(brotli::SliceReader(ptr, n));
+//   std::vector<uint8_t> out = d.read_to_end();        // == Read::read_to_end
+//
+// Semantics of read(): n > 0 bytes, 0 at end of stream forever after; an invalid stream throws
+// brotli::InvalidData whose what() is the reference's description string (the reference returns
+// io::Error::new(ErrorKind::InvalidData, description), src/lib.rs:2177).  Two documented differences of the
+// whole-stream GPU backend: the inner reader is drained eagerly on the first read, and nothing is delivered
+// for a stream that fails (the reference delivers an unspecified prefix).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/brx.h"
+
+namespace brotli {
+
+struct InvalidData : std::runtime_error {
+    int status;
+    InvalidData(int st, const char *what) : std::runtime_error(what), status(st) {}
+};
+
+// A minimal "Read": any type with  size_t read(uint8_t *buf, size_t len)  returning 0 at EOF works as R.
+class SliceReader {
+    const uint8_t *p_;
+    size_t n_, at_ = 0;
+
+  public:
+    SliceReader(const uint8_t *p, size_t n) : p_(p), n_(n) {}
+    size_t read(uint8_t *buf, size_t len) {
+        size_t k = n_ - at_ < len ? n_ - at_ : len;
+        for (size_t i = 0; i < k; i++) buf[i] = p_[at_ + i];
+        at_ += k;
+        return k;
+    }
+};
+
+inline brx_ctx *default_context() {
+    static brx_ctx *ctx = [] {
+        brx_ctx *c = nullptr;
+        int rc = brx_ctx_create(&c, 0);
+        if (rc != BRX_SUCCESS) throw std::runtime_error(std::string("brx_ctx_create: ") + brx_last_error());
+        return c;
+    }();
+    return ctx;
+}
+
+template <class R> class Decompressor {
+    R inner_;
+    brx_stream *stream_ = nullptr;
+
+  public:
+    explicit Decompressor(R r) : inner_(std::move(r)) {} // infallible and reads nothing, like the reference's new()
+    Decompressor(const Decompressor &) = delete;          // the reference derives Debug only, not Clone
+    Decompressor &operator=(const Decompressor &) = delete;
+    ~Decompressor() { brx_stream_free(stream_); }
+
+    size_t read(uint8_t *buf, size_t len) {
+        if (!stream_) {
+            std::vector<uint8_t> in;
+            uint8_t tmp[65536];
+            for (size_t k; (k = inner_.read(tmp, sizeof tmp)) > 0;) in.insert(in.end(), tmp, tmp + k);
+            stream_ = brx_stream_new(default_context(), in.data(), in.size());
+            if (!stream_) throw std::runtime_error("brx_stream_new failed");
+        }
+        int64_t n = brx_stream_read(stream_, buf, len);
+        if (n < -900) throw std::runtime_error(std::string("libbrx: ") + brx_last_error());
+        if (n < 0) throw InvalidData((int)-n, brx_status_str((int32_t)-n));
+        return (size_t)n;
+    }
+
+    std::vector<uint8_t> read_to_end() {
+        std::vector<uint8_t> out;
+        uint8_t tmp[65536];
+        for (size_t k; (k = read(tmp, sizeof tmp)) > 0;) out.insert(out.end(), tmp, tmp + k);
+        return out;
+    }
+};
+
+} // namespace brotli

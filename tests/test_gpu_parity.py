@@ -171,3 +171,24 @@ def test_device_pointer_path_with_torch(ctx):
     host = out.cpu().numpy().reshape(n, cap)[:, :len(exp)]
     want = np.frombuffer(exp, dtype=np.uint8)
     assert (host == want[None, :]).all()
+
+
+def test_cpp_decompressor_facade(ctx, tmp_path):
+    """The C++ host-side mirror of brotli::Decompressor<R> (brotli-rs_amd/host/decompressor.hpp) on a few
+    reference vectors: positive decodes and one should_panic substring (tests/lib.rs:38, :346)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "decompressor_test")
+    lib = os.path.join(root, "brotli-rs_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tests", "cpp", "decompressor_test.cpp"),
+                           "-o", exe, "-L", lib, "-lbrx", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib",
+                           "-L/opt/rocm/lib", "-lamdhip64"])
+    d = os.path.join(GOLDEN, "data")
+    for name in ("alice29.txt", "monkey", "quickfox_repeated", "empty", "x"):
+        out = subprocess.run([exe, os.path.join(d, name + ".compressed"), os.path.join(d, name)],
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+    bad = tmp_path / "bad.compressed"
+    bad.write_bytes(bytes.fromhex("a103"))
+    out = subprocess.run([exe, str(bad), "-", "non-zero bit"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
