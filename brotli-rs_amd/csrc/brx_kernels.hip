@@ -667,11 +667,60 @@ FI u32 copy_fetch(const Dec &d, const Lds &s, u32 back_max, u32 back_min, u32 ba
     return back <= BRX_RING_BYTES ? bn : bf;
 }
 
+// One KiB of a long copy: every lane moves 16 bytes.  Precondition: (pos + a) is 16-byte aligned, `de` >= 1024
+// (so source and destination of this step do not overlap) and the source is entirely inside the ring
+// (de <= BRX_RING_BYTES) or entirely older than it (de - 1023 > BRX_RING_BYTES; then it is final in HBM).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+FI void bulk_copy_1k(Dec &d, Lds &s, u32 de) {
+    const u32 vdst = d.pos + d.a + 16u * d.lane;
+    u32x4 q;
+    if (de <= BRX_RING_BYTES) {
+        const u32 r = vdst - de; // skewed ring coordinate of this lane's 16 source bytes
+        if ((de & 3u) == 0u) {
+            q.x = *(const u32 *)&s.ring[r & RMASK];
+            q.y = *(const u32 *)&s.ring[(r + 4u) & RMASK];
+            q.z = *(const u32 *)&s.ring[(r + 8u) & RMASK];
+            q.w = *(const u32 *)&s.ring[(r + 12u) & RMASK];
+        } else {
+            u32 w[4];
+            _Pragma("unroll") for (u32 k = 0; k < 4u; k++) {
+                u32 b0 = s.ring[(r + 4u * k) & RMASK], b1 = s.ring[(r + 4u * k + 1u) & RMASK];
+                u32 b2 = s.ring[(r + 4u * k + 2u) & RMASK], b3 = s.ring[(r + 4u * k + 3u) & RMASK];
+                w[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+            q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
+        }
+    } else {
+        q = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, d.pos - de + 16u * d.lane, 0, 0);
+    }
+    *(u32x4 *)&s.ring[vdst & RMASK] = q;
+    d.pos += 1024u;
+}
+
 // Window copy, reference copy_literals src/lib.rs:1491-1505: out[pos+i] = out[pos-dist + (i % dist)].
+// Short copies go 64 bytes per step through the ring.  Long ones switch to 1 KiB steps (bulk_copy_1k) once the
+// write cursor is 16-byte aligned and the effective distance is >= 1024: an overlapping (periodic) copy may use
+// any multiple of its period as distance as soon as that much periodic history exists, so a period-1 or
+// period-43 fill becomes a plain far-enough copy after its first ~1 KiB.
 FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
     u32 done = 0, de = dist;
+    bool bulk_used = false;
     while (done < len) {
-        u32 n = len - done < 64u ? len - done : 64u;
+        const u32 rem = len - done;
+        if (rem >= 2048u && de < 1024u) { // grow the distance to a multiple of the period >= 1024
+            const u32 target = dist * ((1023u + dist) / dist);
+            if (done + dist >= target) de = target;
+        }
+        if (rem >= 1024u && de >= 1024u && ((d.pos + d.a) & 15u) == 0u && (de <= BRX_RING_BYTES || de > BRX_RING_BYTES + 1023u)) {
+            bulk_copy_1k(d, s, de);
+            done += 1024u;
+            bulk_used = true;
+            maybe_flush(d, s);
+            continue;
+        }
+        u32 n = rem < 64u ? rem : 64u;
+        const u32 mis = (d.pos + d.a) & 15u;
+        if (rem >= 1088u && mis) n = 16u - mis; // short step that aligns the cursor for the bulk path
         u32 lc = d.lane < n ? d.lane : n - 1u; // clamped lane: switched-off lanes redo the last byte
         u32 off = lc;
         if (de < n) off = lc % de; // overlapped copy shorter than a chunk: periodic source
@@ -684,8 +733,9 @@ FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
         d.pos += n;
         done += n;
         maybe_flush(d, s);
-        if (de < 64u) de = dist * ((63u + dist) / dist); // period-preserving distance >= 64 once 64 bytes exist
+        if (de < 64u && done + dist >= dist * ((63u + dist) / dist)) de = dist * ((63u + dist) / dist); // period-preserving distance >= 64
     }
+    if (bulk_used) ctx_bytes(d, s, p1, p2);
 }
 
 // Static dictionary word + transform, reference src/lib.rs:1506-1540 and src/transformation/mod.rs:3-209.
