@@ -166,9 +166,20 @@ def main():
         kms = sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else float("nan")
         kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg * n / (kavg * 1e-3) / 1e9
+        # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected by
+        # tools/gpu_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command) and
+        # committed as profiles/hbm_traffic.json.  null when this workload has no committed measurement.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            traffic = tj["workloads"][args.workload]["total_bytes"]
+            traffic_src = "profiles/hbm_traffic.json (%s)" % tj.get("round", "?")
+        except (OSError, KeyError, ValueError):
+            pass
         res["roofline"] = {"bound": "hbm", "kernel": "brx_decode_kernel", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": None, "algorithmic_bytes_per_launch": alg * n,
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": alg * n,
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
         if cb:
             res["cpu_baseline"] = cb
