@@ -23,13 +23,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden", "data")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+C5 = os.path.join(ROOT, "tests", "golden", "config5")
 WORKLOADS = {
-    # name: (fixture, streams per GPU)
-    "alice29x4096": ("alice29.txt", 4096),
-    "backward65536x4096": ("backward65536", 4096),
-    "quickfox_repeatedx8192": ("quickfox_repeated", 8192),
-    "compressed_repeatedx4096": ("compressed_repeated", 4096),
+    # name: (fixtures, streams per GPU); stream i of a batch decodes fixture i mod K
+    "alice29x4096": (["alice29.txt"], 4096),                       # BASELINE configs[1]: the headline
+    "backward65536x4096": (["backward65536"], 4096),               # configs[2]
+    "quickfox_repeatedx8192": (["quickfox_repeated"], 8192),       # configs[3], per-GPU share
+    "compressed_repeatedx4096": (["compressed_repeated"], 4096),   # supplementary long-distance copy
+    "config5_1MiBx1024": (["c5_0", "c5_1", "c5_2", "c5_3"], 1024), # configs[4], per-GPU share
 }
+
+
+def load_fixture(name):
+    """(compressed, expected).  config-5 fixtures carry only a sha256: their expected bytes come from the oracle."""
+    if name.startswith("c5_"):
+        import hashlib
+        import oracle_py
+        comp = open(os.path.join(C5, name + ".compressed"), "rb").read()
+        st, out = oracle_py.decode(comp)[:2]
+        man = {e["name"]: e for e in json.load(open(os.path.join(C5, "manifest.json")))["streams"]}
+        assert st == 0 and hashlib.sha256(out).hexdigest() == man[name]["sha256"]
+        return comp, out
+    return (open(os.path.join(GOLD, name + ".compressed"), "rb").read(), open(os.path.join(GOLD, name), "rb").read())
 
 
 def cpu_baseline(comp, expect, seconds=12.0):
@@ -88,17 +103,25 @@ def main():
     from brotli_rs_amd import brx
     ctx = brx.Context(local_rank)
 
-    fixture, n = WORKLOADS[args.workload]
+    fixtures, n = WORKLOADS[args.workload]
     if args.streams:
         n = args.streams
-    comp = open(os.path.join(GOLD, fixture + ".compressed"), "rb").read()
-    expect = open(os.path.join(GOLD, fixture), "rb").read()
-    cap = (len(expect) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
+    fx = [load_fixture(f) for f in fixtures]
+    K = len(fx)
+    comp, expect = fx[0]
+    cap = (max(len(e) for _, e in fx) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
 
-    # synthetic batch: the stream replicated n times into distinct HBM regions, distinct output regions
-    one = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
-    blob = one.repeat(n).contiguous()
-    in_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * len(comp)).contiguous()
+    # synthetic batch: stream i = fixture i mod K, each in its own HBM region, distinct output regions
+    lens = np.array([len(fx[i % K][0]) for i in range(n)], dtype=np.int64)
+    in_off_h = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=in_off_h[1:])
+    if K == 1:
+        one = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
+        blob = one.repeat(n).contiguous()
+    else:
+        parts = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev) for c, _ in fx]
+        blob = torch.cat([parts[i % K] for i in range(n)]).contiguous()
+    in_off = torch.from_numpy(in_off_h).to(dev)
     out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap).contiguous()
     out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
     out_len = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -133,39 +156,45 @@ def main():
     # parity on the timed output: status, lengths, and every stream's bytes (checksum of checksums by equality)
     ok = True
     if args.verify:
-        ok = bool((status == 0).all().item()) and bool((out_len == len(expect)).all().item())
-        want = torch.frombuffer(bytearray(expect), dtype=torch.uint8).to(dev)
-        got = out.view(n, cap)[:, :len(expect)]
-        ok = ok and bool((got == want.unsqueeze(0)).all().item())
+        ok = bool((status == 0).all().item())
+        for k, (_, e) in enumerate(fx):
+            want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(dev)
+            ok = ok and bool((out_len[k::K] == len(e)).all().item())
+            got = out.view(n, cap)[k::K, :len(e)]
+            ok = ok and bool((got == want.unsqueeze(0)).all().item())
     if world > 1:
         f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
 
     if rank == 0:
-        total_out = float(len(expect)) * n * world
+        out_bytes_gpu = sum(len(fx[i % K][1]) for i in range(n))
+        total_out = float(out_bytes_gpu) * world
         ms_per_step = dt / args.steps * 1e3
         value = total_out * args.steps / dt / 1e6
         res = {"metric": "decompressed MB/s (whole node), %s batch" % args.workload, "value": round(value, 1),
                "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "u8", "data": "synthetic (reference fixture %s.compressed replicated)" % fixture,
-               "config": {"workload": "%d x data/%s.compressed per GPU" % (n, fixture), "streams_per_gpu": n,
-                          "in_bytes_per_stream": len(comp), "out_bytes_per_stream": len(expect),
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic (fixture(s) %s replicated)" % ",".join(fixtures),
+               "config": {"workload": "%d x %s per GPU" % (n, "|".join(f + ".compressed" for f in fixtures)),
+                          "streams_per_gpu": n,
+                          "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
                "bit_exact": ok}
-        cb, st = (None, None)
+        import oracle_py
+        cb = None
         if not args.no_cpu_baseline:
-            cb, st = cpu_baseline(comp, expect, args.cpu_seconds)
-        else:
-            import oracle_py
-            st = oracle_py.decode(comp, want_stats=True)[2]
+            cb, _ = cpu_baseline(comp, expect, args.cpu_seconds)
         # ALGORITHMIC bytes per stream: compressed in + decompressed out + window-copy bytes read +
-        # dictionary bytes read; per launch = x streams of one GPU.
-        alg = len(comp) + len(expect) + st["copy_bytes"] + st["dict_bytes"]
+        # dictionary bytes read; per launch = summed over the streams of one GPU.
+        algs = []
+        for c, e in fx:
+            st = oracle_py.decode(c, want_stats=True)[2]
+            algs.append(len(c) + len(e) + st["copy_bytes"] + st["dict_bytes"])
+        alg_launch = sum(algs[i % K] for i in range(n))
         kms = sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else float("nan")
         kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
-        achieved = alg * n / (kavg * 1e-3) / 1e9
+        achieved = alg_launch / (kavg * 1e-3) / 1e9
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected by
         # tools/gpu_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command) and
         # committed as profiles/hbm_traffic.json.  null when this workload has no committed measurement.
@@ -179,7 +208,7 @@ def main():
         res["roofline"] = {"bound": "hbm", "kernel": "brx_decode_kernel", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": alg * n,
+                           "algorithmic_bytes_per_launch": alg_launch,
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
         if cb:
             res["cpu_baseline"] = cb

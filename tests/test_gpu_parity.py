@@ -192,3 +192,69 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     bad.write_bytes(bytes.fromhex("a103"))
     out = subprocess.run([exe, str(bad), "-", "non-zero bit"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_encoder_streams_batch(ctx):
+    """95 libbrotlienc streams (tests/golden/enc: qualities 0-11, WBITS 10-24, NPOSTFIX/NDIRECT != 0, forced
+    meta-block flushes, 1-symbol trees, uncompressed meta-blocks) as one batch, bit-exact against the manifest."""
+    d = os.path.join(GOLDEN, "enc")
+    man = json.load(open(os.path.join(d, "manifest.json")))["streams"]
+    streams = [open(os.path.join(d, e["name"] + ".compressed"), "rb").read() for e in man]
+    outs, status, out_len = ctx.decode_batch(streams, [e["out_len"] + 16 for e in man])
+    for e, o, st, ln in zip(man, outs, status, out_len):
+        assert st == 0, (e["name"], e["params"], int(st))
+        assert int(ln) == e["out_len"] and hashlib.sha256(o).hexdigest() == e["sha256"], (e["name"], e["params"])
+
+
+def test_config5_streams_batch(ctx):
+    """BASELINE config 5 shape: 1 MiB multi-meta-block text streams (8 forced flushes each), 64 per batch
+    (fixture i mod K), bit-exact against the oracle-verified sha256."""
+    d = os.path.join(GOLDEN, "config5")
+    man = json.load(open(os.path.join(d, "manifest.json")))["streams"]
+    comps = [open(os.path.join(d, e["name"] + ".compressed"), "rb").read() for e in man]
+    n = 64
+    streams = [comps[i % len(comps)] for i in range(n)]
+    outs, status, out_len = ctx.decode_batch(streams, [1 << 20] * n)
+    for i, (o, st, ln) in enumerate(zip(outs, status, out_len)):
+        e = man[i % len(man)]
+        assert st == 0 and int(ln) == 1 << 20, (i, int(st))
+        assert hashlib.sha256(o).hexdigest() == e["sha256"], i
+
+
+def test_random_encoder_fuzz(ctx):
+    """Streams generated here by the system libbrotlienc over random parameters and data (skipped when the library is
+    absent): the HIP path must reproduce the original bytes of every one, in one 1500-stream batch."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import brotli_enc
+    if not brotli_enc.available():
+        pytest.skip("libbrotlienc not in this image")
+    rng = random.Random(99)
+    pool = [_read(f) for f in ("alice29.txt", "lcet10.txt", "plrabn12.txt", "asyoulik.txt")]
+    datas, streams = [], []
+    for it in range(1500):
+        kind = rng.randrange(5)
+        if kind == 0:
+            base = rng.choice(pool)
+            o = rng.randrange(len(base) - 30000)
+            data = base[o:o + rng.randrange(1, 30000)]
+        elif kind == 1:
+            data = bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 2000)))
+        elif kind == 2:
+            unit = bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 300)))
+            data = (unit * (1 + 20000 // len(unit)))[:rng.randrange(1, 20000)]
+        elif kind == 3:
+            base = rng.choice(pool)
+            data = b"".join(base[o:o + 150] for o in (rng.randrange(len(base) - 150) for _ in range(rng.randrange(1, 60))))
+        else:
+            data = bytes(rng.choice(b"ab\n ") for _ in range(rng.randrange(1, 8000)))
+        npf = rng.choice([None, 0, 1, 2, 3])
+        nd = None if npf is None else rng.randrange(0, 16) << npf
+        comp = brotli_enc.compress(data, quality=rng.randrange(0, 12), lgwin=rng.randrange(10, 25), mode=rng.randrange(3),
+                                   npostfix=npf, ndirect=nd, flush_every=rng.choice([0, 0, 0, 300, 4096]))
+        datas.append(data)
+        streams.append(comp)
+    outs, status, out_len = ctx.decode_batch(streams, [len(x) + 16 for x in datas])
+    for i, (d, o, st) in enumerate(zip(datas, outs, status)):
+        assert st == 0, (i, int(st))
+        assert o == d, i

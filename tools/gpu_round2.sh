@@ -10,3 +10,5 @@ for wl in alice29x4096 backward65536x4096 quickfox_repeatedx8192 compressed_repe
   extra="--no-cpu-baseline"; [ $wl = alice29x4096 ] && extra=""
   timeout 600 python bench.py --steps ${STEPS:-10} --warmup 2 --workload $wl $extra 2>&1 | tail -1 | tee gpurun_out/bench_${TAG}_$wl.json
 done
+echo "== bench config5"
+timeout 600 python bench.py --steps 5 --warmup 1 --workload config5_1MiBx1024 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_${TAG}_config5_1MiBx1024.json
