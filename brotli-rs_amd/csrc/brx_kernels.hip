@@ -253,6 +253,21 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_ISLAST 34  // ISLAST of the meta-block handed to the command loop
 #define ST_MLEN 35    // its MLEN
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
+// hot_commands modes / return value, and the Lds::mbw slots that carry a parked command
+#define HC_WHOLE 0u      // run the whole meta-block
+#define HC_START 1u      // first insert&copy symbol only, then park at R1
+#define HC_RESUME_R0 2u  // resume: insert&copy symbol due; one command, park
+#define HC_RESUME_R1 3u  // resume at the loop top; one command, park
+#define HC_RESUME_R2 4u  // resume with the distance known; one command, park
+#define HC_CONTINUE 200u // returned when parked (meta-block not finished)
+#define MBW_ASM 31
+#define MBW_MBLEFT 32
+#define MBW_INS 33
+#define MBW_CPY 34
+#define MBW_IZ 35
+#define MBW_DIST 36
+#define MBW_DISTBAD 37
+#define MBW_EXIT 38
 
 // ---- parking the decoder state in LDS ------------------------------------------------------------------
 // The cold parts of the decoder (meta-block header parsing with its code builders; the table-memory command
@@ -1412,7 +1427,7 @@ FI void ctx_vectors(const Dec &d, u32 cmode, u32 &VA, u32 &VB) {
 //     lands in the ring when its bytes are needed (literal context, an overlapping source, the next far copy).
 // Preconditions established by cold_header (mbw[30]): <= 8 literal / distance trees, <= 4 insert&copy block
 // types, NPOSTFIX = NDIRECT = 0, pos + MLEN <= capacity, input < 2^28 bytes.
-__device__ __noinline__ u32 hot_commands(u32 prof_on) {
+__device__ __noinline__ u32 hot_commands(u32 mode_in) {
     Lds &s = g_lds;
     Dec d;
     dec_load(d, s);
@@ -1420,8 +1435,7 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
     Cat L, I, D;
     mb_load(s, m, L, I, D);
     m.mlen = rfl(s.st[ST_MLEN]);
-    const bool prof = rfl(prof_on) != 0u;
-    const u64 tprof = prof ? (u64)__builtin_readcyclecounter() : 0ull;
+    const u32 mode = rfl(mode_in);
 
     // ---- register tables
     Fast f;
@@ -1492,6 +1506,17 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
                                                // ring positions [pos - pend_n, pos)
     u32 insert_len = 0, copy_len = 0, implicit_zero = 0;
     u32 rc = ST_OK;
+    // Re-entry (the assembly fast loop hands single commands back, see brx_hot.S): resume points
+    //   R0 = an insert&copy symbol is due, R1 = loop top (insert_len / copy_len / implicit_zero valid),
+    //   R2 = the distance of the current command is known (ring of last distances already updated).
+    u32 budget = mode == HC_WHOLE ? 0xffffffffu : mode == HC_START ? 0u : 1u; // commands to run before parking
+    u32 phase2 = mode == HC_RESUME_R2 ? 1u : 0u;
+    u32 distance = 0, dist_bad = 0;
+    if (mode >= HC_RESUME_R0) {
+        mb_left = rfl(s.mbw[MBW_MBLEFT]);
+        insert_len = rfl(s.mbw[MBW_INS]); copy_len = rfl(s.mbw[MBW_CPY]); implicit_zero = rfl(s.mbw[MBW_IZ]);
+        distance = rfl(s.mbw[MBW_DIST]); dist_bad = rfl(s.mbw[MBW_DISTBAD]);
+    }
 
 #define H_PEEK() ((u32)(d.win >> boff))
 #define H_TAKE(n)                                                                      \
@@ -1617,8 +1642,10 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
     if (I.blen == 0xffffffffu) I.blen = 0x7fffffffu;
     if (D.blen == 0xffffffffu) D.blen = 0x7fffffffu;
 
-    H_DECODE_IAC();
-    while (mb_left != 0u) { // single exit: errors zero mb_left
+    if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
+    while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
+      u32 max_allowed;
+      if (phase2 == 0u) {
         if (left < 0) { H_FAIL(ST_EOF); continue; }
         if (insert_len > mb_left) { H_FAIL(ST_EXCEEDED_EXPECTED_BYTES); continue; } // :2036 (Q4)
         // ---- parse_insert_literals :1286-1365
@@ -1678,7 +1705,6 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
                 dcode = (rdl(sel2(f.DS0, f.DS1, ti >> 2), sl + ((idx >> 2) & 15u)) >> ((idx & 3u) * 8u)) & 0xffu;
             }
         }
-        u32 distance;
         if (dcode <= 3u) {
             distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
         } else if (dcode <= 15u) {
@@ -1694,10 +1720,15 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
             H_TAKE(nd);
             distance = (((2u + (x & 1u)) << nd) - 4u) + e + 1u;
         }
-        const u32 max_allowed = d.pos < d.window ? d.pos : d.window;
+        max_allowed = d.pos < d.window ? d.pos : d.window;
         if (dcode > 0u && distance <= max_allowed) { // :1476-1478
             d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
         }
+      } else { // resumed at R2
+        max_allowed = d.pos < d.window ? d.pos : d.window;
+        if (dist_bad) { H_FAIL(ST_NON_POSITIVE_DISTANCE); distance = 1u; }
+      }
+        phase2 = 0u;
         if (mb_left == 0u) continue; // an error was recorded while decoding the distance
         // ---- copy_literals :1483-1542
         if (distance <= max_allowed && copy_len <= 64u && distance >= copy_len) {
@@ -1716,6 +1747,7 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
             pend_n = copy_len;
             d.pos += copy_len;
             mb_left -= copy_len;
+            budget--;
             if (mb_left != 0u) H_DECODE_IAC(); // lookahead (:2128 otherwise): overlaps the fetch above
             // the block being flushed ends >= BRX_FLUSH_LAG bytes behind the cursor: never the pending bytes
             if (d.pos + d.a >= (d.vfl & ~(BRX_FLUSH_BLOCK - 1u)) + BRX_FLUSH_BLOCK + BRX_FLUSH_LAG) maybe_flush(d, s);
@@ -1740,12 +1772,21 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
             else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
             maybe_flush(d, s);
         }
+        budget--;
         if (mb_left != 0u) H_DECODE_IAC(); // :2128 otherwise
     }
     H_LAND();
     maybe_flush(d, s);
-    if (rc == 0u && left < 0) rc = ST_EOF;
+    const bool parked = mb_left != 0u; // budget ran out (no error: errors zero mb_left): park at R1
+    if (!parked && rc == 0u && left < 0) rc = ST_EOF;
     if (rc == 0u) H_SYNC_OUT();
+    if (parked) {
+        s.mbw[MBW_MBLEFT] = mb_left; s.mbw[MBW_INS] = insert_len; s.mbw[MBW_CPY] = copy_len; s.mbw[MBW_IZ] = implicit_zero;
+        s.mbw[13] = L.btype; s.mbw[14] = L.btype_prev; s.mbw[15] = L.blen;
+        s.mbw[19] = I.btype; s.mbw[20] = I.btype_prev; s.mbw[21] = I.blen;
+        s.mbw[25] = D.btype; s.mbw[26] = D.btype_prev; s.mbw[27] = D.blen;
+        rc = HC_CONTINUE;
+    }
 #undef H_LOAD_LIT
 #undef H_LOAD_DIST
 #undef H_LOAD_IAC_HDR
@@ -1760,12 +1801,6 @@ __device__ __noinline__ u32 hot_commands(u32 prof_on) {
 #undef H_LOOKUP
 #undef H_DECODE_IAC
     dec_store(d, s);
-    if (prof) {
-        u32 *pp = d.lane == 0u ? &s.pad[8] : (u32 *)&s.trash[(d.lane & 15u) * 4u];
-        u64 cur = ((u64)pp[0] | ((u64)pp[1] << 32)) + ((u64)__builtin_readcyclecounter() - tprof);
-        pp[0] = (u32)cur;
-        pp[1] = (u32)(cur >> 32);
-    }
     return rc;
 }
 
@@ -1941,7 +1976,14 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
             if (st) break;
-            st = rfl(s.mbw[30]) ? hot_commands(prof_on) : cold_commands();
+            if (rfl(s.mbw[30]) == 0u) {
+                st = cold_commands();
+            } else if (a.debug_stop == 7u) { // bring-up: the re-entrant C++ loop alone, one command per call
+                st = hot_commands(HC_START);
+                while (st == HC_CONTINUE) st = hot_commands(HC_RESUME_R1);
+            } else {
+                st = hot_commands(HC_WHOLE);
+            }
             if (st) break;
             st = seg_frame();
         }
