@@ -9,7 +9,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["brx_kernels.hip", "brx_api.cpp"]
-DEPS = SOURCES + ["brx_device.h", os.path.join("..", "..", "include", "brx.h"),
+DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "build.py")]
 
@@ -31,6 +31,12 @@ def build_library(force=False, verbose=False):
         raise RuntimeError("hipcc not found at %s and no prebuilt libbrx.so" % HIPCC)
     gen = os.path.join(CSRC, "_gen", "brx_tables_gen.h")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bin2h.py"), gen, "BRX", "static const"])
+    # the hand-written command loop: cpp resolves the register names, the text becomes one asm statement
+    hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp", os.path.join(CSRC, "brx_hot.S")]).decode()
+    assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
+    with open(os.path.join(CSRC, "_gen", "brx_hot_asm.h"), "w") as f:
+        f.write("// generated from brx_hot.S by build.py -- do not edit\n")
+        f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]

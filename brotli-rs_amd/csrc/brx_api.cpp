@@ -41,6 +41,7 @@ struct brx_ctx {
     uint8_t *d_dict = nullptr;
     uint8_t *d_lut = nullptr;
     BrxTransform *d_xforms = nullptr;
+    uint32_t *d_iac = nullptr;
     uint32_t *d_counter = nullptr;
     uint32_t *d_scratch = nullptr;
     unsigned max_grid = 0; // resident waves we size the spill arena for
@@ -129,6 +130,30 @@ extern "C" int brx_ctx_create(brx_ctx **out, int device) {
         p += sl + 1;
     }
     HIP_TRY(hipMemcpy(c->d_xforms, xf.data(), 121 * sizeof(BrxTransform), hipMemcpyHostToDevice));
+    {
+        // Insert&copy alphabet (spec section 5, reference src/lib.rs:962-976 + src/lookuptable/mod.rs:59-123): symbol ->
+        // insert code / copy code through the 11 x 64 cell layout, code -> (base, extra bits).
+        static const uint16_t ins_base[24] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26, 34, 50, 66, 98, 130, 194, 322, 578, 1090, 2114, 6210, 22594};
+        static const uint8_t ins_extra[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
+        static const uint16_t cpy_base[24] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 18, 22, 30, 38, 54, 70, 102, 134, 198, 326, 582, 1094, 2118};
+        static const uint8_t cpy_extra[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
+        static const uint8_t cell_ins[11] = {0, 0, 0, 0, 8, 8, 0, 16, 8, 16, 16}, cell_cpy[11] = {0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16};
+        static const uint8_t ndbits[25] = {0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5};
+        std::vector<uint32_t> t(704 * 2 + 64, 0u);
+        for (unsigned sym = 0; sym < 704; sym++) {
+            unsigned cell = sym >> 6, ic = cell_ins[cell] + ((sym >> 3) & 7u), cc = cell_cpy[cell] + (sym & 7u);
+            t[2 * sym] = ins_base[ic] | ((uint32_t)ins_extra[ic] << 16);
+            t[2 * sym + 1] = cpy_base[cc] | ((uint32_t)cpy_extra[cc] << 16);
+        }
+        uint32_t off = 0;
+        for (unsigned n = 0; n < 25; n++) { // DOFFSET: words of length n start here (spec section 8)
+            t[1408 + n] = off | ((uint32_t)ndbits[n] << 24);
+            if (n >= 4) off += n << ndbits[n];
+        }
+        if (off != sizeof BRX_DICT) return fail(BRX_ERR_HIP, "internal: dictionary size does not match NDBITS");
+        HIP_TRY(hipMalloc(&c->d_iac, t.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_iac, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     *out = c;
     return BRX_SUCCESS;
@@ -141,6 +166,7 @@ extern "C" void brx_ctx_destroy(brx_ctx *c) {
     (void)hipFree(c->d_dict);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_xforms);
+    (void)hipFree(c->d_iac);
     (void)hipFree(c->d_counter);
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->st_in);
@@ -188,6 +214,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.dict = c->d_dict;
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
+    a.t.iac = c->d_iac;
     unsigned grid = n < c->max_grid ? n : c->max_grid;
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, 4, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -202,6 +229,8 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         for (uint32_t i = 0; i < n && i < 2; i++) {
             fprintf(stderr, "[brx stats] stream %u:", i);
             for (int q = 0; q < 10; q++) fprintf(stderr, " %s=%llu", nm[q], h[(size_t)i * 10 + q]);
+            fprintf(stderr, "\n[brx stats] words:");
+            for (int q = 0; q < 8; q++) fprintf(stderr, " %u %u", (unsigned)h[(size_t)i * 10 + q], (unsigned)(h[(size_t)i * 10 + q] >> 32));
             fprintf(stderr, "\n");
         }
         (void)hipFree(dbg);

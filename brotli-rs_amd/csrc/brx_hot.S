@@ -1,0 +1,768 @@
+// brx_hot.S -- the command loop of one compressed meta-block, hand-written for gfx950 (CDNA4).
+//
+// Reference states DataMetaBlockBegin .. CopyLiterals (src/lib.rs:2003-2141): insert&copy symbol, extra bits,
+// context-modelled literals, distance symbol / last-distance ring, window copy.  One wavefront = one stream; all
+// decoder state is wave-uniform and lives in SGPRs, the 64 lanes are used as (a) a 256-byte staging buffer of the
+// compressed input (v_readlane feeds the 64-bit bit window), (b) comparators of the canonical prefix-code lookup
+// (lane L holds the left-aligned exclusive upper bound of the length-L codes: one v_cmp + s_ff1 = code length),
+// (c) byte movers of a copy (one byte per lane, LDS ring or buffer_load of the stream's own HBM output).
+//
+// This file is preprocessed (register names) and pasted into ONE asm statement of brx_kernels.hip
+// (asm_commands()).  It talks to the C++ segments only through the parked state in LDS (Lds::st, Lds::mbw):
+//   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
+//   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
+// Everything unusual leaves through one of those points and is handled by hot_commands() in C++, which runs one
+// command and hands back: block switches, dictionary words with a transform, copies longer than 64 bytes or
+// overlapping their source, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
+// (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
+//
+// Preconditions (hot_commands(HC_START) sets mbw[MBW_ASM]): NPOSTFIX = NDIRECT = 0, every literal / distance /
+// insert&copy tree is a general code (kind 2) resident in LDS table memory, <= 64 literal and <= 64 distance
+// trees, context maps in LDS, input < 2^28 bytes, pos + MLEN <= capacity, flush cursor 1 KiB aligned.
+
+#define LDS_TM 4096
+#define LDS_ST 9728
+#define LDS_MBW 9920
+#define RMASK 4095
+
+// ---- SGPRs
+#define WIN s[36:37]
+#define WINLO s36
+#define NAV s38
+#define WL s39
+#define MAXA s40
+#define WLSTOP s41
+#define INP s[42:43]
+#define WENDM1 s44
+#define WSAFE s45
+#define CBASE s46
+#define DIST s47
+#define RSRC s[48:51]
+#define POS s52
+#define SKEW s53
+#define VFL s54
+#define FLUSHAT s55
+#define WINDOW s56
+#define D0 s57
+#define D1 s58
+#define D2 s59
+#define D3 s60
+#define MBLEFT s61
+#define INS s62
+#define CPY s63
+#define IZ s64
+#define LBLEN s65
+#define IBLEN s66
+#define DBLEN s67
+#define P1 s68
+#define BVAL s69
+#define PENDN s70
+#define HISYM s71
+#define CMDW s72
+#define EXITC s73
+#define IACTAB s[74:75]
+#define DICTP s[76:77]
+#define LBLEN_REAL s78
+#define IBLEN_REAL s79
+#define FLAGS s80
+#define DCODE s81
+#define LINKA s[82:83]
+#define T0 s84
+#define T1 s85
+#define T01 s[84:85]
+#define T2 s86
+#define T3 s87
+#define T4 s88
+#define T5 s89
+#define T6 s90
+#define T7 s91
+#define CLEN s96
+#define LINKB s[98:99]
+#define LINKC s[100:101]
+// ---- VGPRs
+#define VZERO v0
+#define VLANE v1
+#define VLANE4 v2
+#define VLANE16 v3
+#define VCHA v4
+#define VCHB v5
+#define VVA v6
+#define VVB v7
+#define VCMROW v8
+#define VLHOFF v9
+#define VDHOFF v10
+#define VHVIAC v11
+#define VPEND v12
+#define VDICTINFO v13
+#define VQ v[14:17]
+#define VT0 v18
+#define VT1 v19
+#define VT2 v20
+#define VT3 v21
+#define VT4 v22
+
+// Bits are taken from the low end of WIN; NAV = number of valid bits in it (>= 32 after a REFILL_CHECK).
+.macro TAKE n
+    s_lshr_b64 WIN, WIN, \n
+    s_sub_u32 NAV, NAV, \n
+.endm
+.macro REFILL_CHECK id
+    s_cmp_lt_u32 NAV, 32
+    s_cbranch_scc1 .Lrf_stub_\id
+.Lrf_back_\id:
+.endm
+// Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
+.macro REFILL_STUB id
+.Lrf_stub_\id:
+    v_readlane_b32 T0, VCHA, WL
+    s_mov_b32 T1, 0
+    s_lshl_b64 T01, T01, NAV
+    s_or_b64 WIN, WIN, T01
+    s_add_u32 NAV, NAV, 32
+    s_add_u32 WL, WL, 1
+    s_cmp_lg_u32 WL, WLSTOP
+    s_cbranch_scc1 .Lrf_back_\id
+    s_call_b64 LINKA, .Lspecial
+    s_branch .Lrf_back_\id
+.endm
+// byte b of a 256-entry byte table held 4 per lane in VGPR vec -> dst (garbage above bit 7 is left in place)
+.macro LUTB dst, vec, b
+    s_lshr_b32 T6, \b, 2
+    v_readlane_b32 T7, \vec, T6
+    s_lshl_b32 T6, \b, 3
+    s_lshr_b32 \dst, T7, T6
+.endm
+// Canonical prefix-code lookup.  hv = per-lane header words of the tree (lane L: limit[L] | base[L] << 16).
+// Out: CLEN = code length, T4 = index into the tree's sorted symbol list.  Clobbers T0-T3, VT3, vcc.
+// A window that matches no code (incomplete code) branches to \fail with nothing consumed.
+.macro LOOKUP hv, fail
+    s_brev_b32 T0, WINLO
+    s_lshr_b32 T1, T0, 17
+    v_and_b32 VT3, 0xffff, \hv
+    v_cmp_lt_u32 vcc, T1, VT3
+    s_and_b32 T2, vcc_lo, 0xfffe
+    s_cbranch_scc0 \fail
+    s_ff1_i32_b32 CLEN, T2
+    v_readlane_b32 T3, \hv, CLEN
+    s_sub_u32 T2, 32, CLEN
+    s_lshr_b32 T2, T0, T2
+    s_lshr_b32 T3, T3, 16
+    s_add_u32 T4, T2, T3
+    s_and_b32 T4, T4, 0xffff
+.endm
+
+// ======================================================================================================== entry
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    v_mov_b32 VZERO, 0
+    v_mbcnt_lo_u32_b32 VLANE, -1, 0
+    v_mbcnt_hi_u32_b32 VLANE, -1, VLANE
+    v_and_b32 VLANE4, 15, VLANE
+    v_lshlrev_b32 VLANE4, 2, VLANE4
+    v_lshlrev_b32 VLANE16, 4, VLANE
+    // parked decoder state: st[0..17], st[23..28], st[36..37]
+    ds_read_b128 v[20:23], VZERO offset:LDS_ST+0       // in_words lo, hi, w_end, bitpos lo
+    ds_read_b128 v[24:27], VZERO offset:LDS_ST+16      // bitpos hi, bitend lo, bitend hi, out lo
+    ds_read_b128 v[28:31], VZERO offset:LDS_ST+32      // out hi, cap, pos, a
+    ds_read_b128 v[32:35], VZERO offset:LDS_ST+48      // vfl, window, dist0, dist1
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 s42, v20
+    v_readfirstlane_b32 s43, v21
+    v_readfirstlane_b32 T0, v22                         // w_end
+    v_readfirstlane_b32 T1, v23                         // bitpos
+    v_readfirstlane_b32 T2, v25                         // bitend
+    v_readfirstlane_b32 s48, v27
+    v_readfirstlane_b32 s49, v28
+    v_readfirstlane_b32 POS, v30
+    v_readfirstlane_b32 SKEW, v31
+    v_readfirstlane_b32 VFL, v32
+    v_readfirstlane_b32 WINDOW, v33
+    v_readfirstlane_b32 D0, v34
+    v_readfirstlane_b32 D1, v35
+    ds_read_b64 v[20:21], VZERO offset:LDS_ST+64        // dist2, dist3
+    ds_read_b32 v22, VZERO offset:LDS_ST+92             // t_dict (st[23], st[24]: only 4-byte aligned)
+    ds_read_b32 v23, VZERO offset:LDS_ST+96
+    ds_read_b32 v24, VZERO offset:LDS_ST+108            // t_lut (st[27], st[28])
+    ds_read_b32 v25, VZERO offset:LDS_ST+112
+    ds_read_b64 v[26:27], VZERO offset:LDS_ST+144       // insert&copy / dictionary info table
+    s_and_b32 s49, s49, 0xffff
+    s_mov_b32 s50, -1
+    s_mov_b32 s51, 0x00020000
+    s_sub_u32 WENDM1, T0, 1
+    s_lshr_b32 WSAFE, T2, 5
+    s_sub_u32 WSAFE, WSAFE, 8
+    s_cselect_b32 WSAFE, 0, WSAFE                       // borrow -> 0
+    s_lshr_b32 CBASE, T1, 5                             // first staged dword = the one holding the cursor
+    s_and_b32 T3, T1, 31                                // bit offset inside it
+    // stage 2 x 64 input dwords (clamped to the stream's last dword)
+    v_add_u32 VT0, CBASE, VLANE
+    v_min_u32 VT0, WENDM1, VT0
+    v_lshlrev_b32 VT0, 2, VT0
+    global_load_dword VCHA, VT0, INP
+    s_add_u32 T4, CBASE, 64
+    v_add_u32 VT0, T4, VLANE
+    v_min_u32 VT0, WENDM1, VT0
+    v_lshlrev_b32 VT0, 2, VT0
+    global_load_dword VCHB, VT0, INP
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 D2, v20
+    v_readfirstlane_b32 D3, v21
+    v_readfirstlane_b32 s76, v22
+    v_readfirstlane_b32 s77, v23
+    v_readfirstlane_b32 T4, v24
+    v_readfirstlane_b32 T5, v25
+    v_readfirstlane_b32 s74, v26
+    v_readfirstlane_b32 s75, v27
+    // context LUTs (3 x 64 dwords) and the dictionary info vector (dwords 1408.. of the insert&copy table)
+    v_lshlrev_b32 VT0, 2, VLANE
+    s_nop 4                                             // v_readfirstlane -> VMEM address SGPR: 5 wait states
+    global_load_dword v28, VT0, s[88:89]                // Lut0
+    global_load_dword v29, VT0, s[88:89] offset:256     // Lut1
+    global_load_dword v30, VT0, s[88:89] offset:512     // Lut2
+    v_add_u32 VT1, 5632, VT0
+    global_load_dword VDICTINFO, VT1, IACTAB
+    // meta-block words
+    ds_read_b128 v[20:23], VZERO offset:LDS_MBW+0       // npostfix, ndirect, cmode_w, cml
+    ds_read_b128 v[24:27], VZERO offset:LDS_MBW+16      // cmd, hl, hi, hd
+    ds_read_b64 v[32:33], VZERO offset:LDS_MBW+32       // ntl, ntd
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T0, v22                         // cmode_w
+    v_readfirstlane_b32 T1, v23                         // cml
+    v_readfirstlane_b32 T2, v24                         // cmd
+    v_readfirstlane_b32 T6, v25                         // hl
+    v_readfirstlane_b32 T7, v26                         // hi
+    v_readfirstlane_b32 s92, v27                        // hd
+    v_readfirstlane_b32 s93, v32                        // ntl
+    v_readfirstlane_b32 s94, v33                        // ntd
+    ds_read_b32 v20, VZERO offset:LDS_MBW+52            // L.btype
+    ds_read_b32 v21, VZERO offset:LDS_MBW+60            // L.blen
+    ds_read_b32 v22, VZERO offset:LDS_MBW+76            // I.btype
+    ds_read_b32 v23, VZERO offset:LDS_MBW+84            // I.blen
+    ds_read_b32 v24, VZERO offset:LDS_MBW+100           // D.btype
+    ds_read_b32 v25, VZERO offset:LDS_MBW+108           // D.blen
+    ds_read_b128 v[32:35], VZERO offset:LDS_MBW+128     // mb_left, insert_len, copy_len, implicit_zero
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 s95, v20                        // L.btype
+    v_readfirstlane_b32 LBLEN, v21
+    v_readfirstlane_b32 s97, v22                        // I.btype
+    v_readfirstlane_b32 IBLEN, v23
+    v_readfirstlane_b32 DCODE, v24                      // D.btype (DCODE is free until the first distance)
+    v_readfirstlane_b32 DBLEN, v25
+    v_readfirstlane_b32 MBLEFT, v32
+    v_readfirstlane_b32 INS, v33
+    v_readfirstlane_b32 CPY, v34
+    v_readfirstlane_b32 IZ, v35
+    // per-tree descriptors: lane t -> LDS byte address of tree t's header (tm word h -> LDS_TM + 4h), or for a
+    // one-symbol tree (kind 1, zero-bit code, SURVEY Q5) 0x80000000 | symbol
+    s_sub_u32 s93, s93, 1
+    v_min_u32 VT0, s93, VLANE
+    v_add_u32 VT0, T6, VT0
+    v_lshlrev_b32 VT0, 2, VT0
+    ds_read_b32 VLHOFF, VT0 offset:LDS_TM
+    s_sub_u32 s94, s94, 1
+    v_min_u32 VT0, s94, VLANE
+    v_add_u32 VT0, s92, VT0
+    v_lshlrev_b32 VT0, 2, VT0
+    ds_read_b32 VDHOFF, VT0 offset:LDS_TM
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 VLHOFF, 2, VLHOFF
+    v_lshlrev_b32 VDHOFF, 2, VDHOFF
+    ds_read_b32 VT0, VLHOFF offset:LDS_TM               // header word 0: kind | max_len << 8 | symbol << 16
+    ds_read_b32 VT1, VDHOFF offset:LDS_TM
+    v_add_u32 VLHOFF, LDS_TM, VLHOFF
+    v_add_u32 VDHOFF, LDS_TM, VDHOFF
+    s_waitcnt lgkmcnt(0)
+    v_and_b32 VT2, 3, VT0
+    v_lshrrev_b32 VT0, 16, VT0
+    v_or_b32 VT0, 0x80000000, VT0
+    v_cmp_eq_u32 vcc, 1, VT2
+    v_cndmask_b32 VLHOFF, VLHOFF, VT0, vcc
+    v_and_b32 VT2, 3, VT1
+    v_lshrrev_b32 VT1, 16, VT1
+    v_or_b32 VT1, 0x80000000, VT1
+    v_cmp_eq_u32 vcc, 1, VT2
+    v_cndmask_b32 VDHOFF, VDHOFF, VT1, vcc
+    // insert&copy tree of the current block type: header words stay resident
+    s_add_u32 T7, T7, s97
+    s_lshl_b32 T7, T7, 2
+    v_mov_b32 VT0, T7
+    ds_read_b32 VT1, VT0 offset:LDS_TM
+    // literal context map row of the current block type (64 bytes, lanes 0..15), distance map word, context mode
+    s_lshl_b32 T6, s95, 6
+    s_add_u32 T1, T1, T6
+    v_add_u32 VT0, T1, VLANE4
+    ds_read_b32 VCMROW, VT0 offset:LDS_TM
+    s_lshl_b32 T6, DCODE, 2
+    s_add_u32 T2, T2, T6
+    v_mov_b32 VT0, T2
+    ds_read_b32 VT2, VT0 offset:LDS_TM
+    s_lshl_b32 T0, T0, 2
+    s_add_u32 T0, T0, s95
+    v_mov_b32 VT0, T0
+    ds_read_u8 VT3, VT0 offset:LDS_TM
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T7, VT1                         // h of the insert&copy tree
+    v_readfirstlane_b32 CMDW, VT2
+    v_readfirstlane_b32 T0, VT3                         // context mode
+    s_lshl_b32 T7, T7, 2
+    s_add_u32 T7, T7, LDS_TM
+    s_add_u32 HISYM, T7, 64
+    v_add_u32 VT0, T7, VLANE4
+    ds_read_b32 VHVIAC, VT0
+    // context vectors (see ctx_vectors() in brx_kernels.hip): id = (A[p1] | B[p2]) & 63
+    s_waitcnt vmcnt(0)
+    v_lshlrev_b32 VT0, 2, VLANE
+    v_and_b32 VT0, 0x3f, VT0
+    s_mov_b32 T6, 0x01010101
+    v_mul_lo_u32 VT0, VT0, T6
+    v_add_u32 VVA, 0x03020100, VT0                      // mode 0: A = p & 63
+    v_mov_b32 VVB, 0
+    s_cmp_eq_u32 T0, 1
+    s_cbranch_scc0 .Lcm_not1
+    v_mul_lo_u32 VVA, VLANE, T6                         // mode 1: A = p >> 2
+.Lcm_not1:
+    s_cmp_eq_u32 T0, 2
+    s_cbranch_scc0 .Lcm_not2
+    v_mov_b32 VVA, v28                                  // mode 2: A = Lut0, B = Lut1
+    v_mov_b32 VVB, v29
+.Lcm_not2:
+    s_cmp_eq_u32 T0, 3
+    s_cbranch_scc0 .Lcm_not3
+    v_and_b32 VVA, 0x1f1f1f1f, v30                      // mode 3: A = Lut2 << 3, B = Lut2
+    v_lshlrev_b32 VVA, 3, VVA
+    v_mov_b32 VVB, v30
+.Lcm_not3:
+    // bit window
+    v_readlane_b32 s36, VCHA, 0
+    v_readlane_b32 s37, VCHA, 1
+    s_lshr_b64 WIN, WIN, T3
+    s_sub_u32 NAV, 64, T3
+    s_mov_b32 WL, 2
+    s_sub_u32 T0, WSAFE, CBASE
+    s_cselect_b32 T0, 0, T0
+    s_min_u32 WLSTOP, T0, 64
+    s_mov_b32 PENDN, 0
+    s_mov_b32 FLAGS, 0
+    s_mov_b32 EXITC, 1
+    s_and_b32 T0, VFL, 0xfffffc00
+    s_add_u32 T0, T0, 2048
+    s_sub_u32 FLUSHAT, T0, SKEW
+    // literal context of the first literal: last two bytes of the output
+    s_add_u32 T0, POS, SKEW
+    s_sub_u32 T1, T0, 1
+    s_and_b32 T1, T1, RMASK
+    v_mov_b32 VT0, T1
+    ds_read_u8 VT1, VT0
+    s_sub_u32 T1, T0, 2
+    s_and_b32 T1, T1, RMASK
+    v_mov_b32 VT0, T1
+    ds_read_u8 VT2, VT0
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 P1, VT1
+    v_readfirstlane_b32 T5, VT2
+    s_cmp_ge_u32 POS, 1
+    s_cselect_b32 P1, P1, 0
+    s_cmp_ge_u32 POS, 2
+    s_cselect_b32 T5, T5, 0
+    LUTB BVAL, VVB, T5
+    // not enough input left for the fast loop, or ragged flush cursor: hand straight back
+    s_cmp_lt_u32 WLSTOP, 3
+    s_cbranch_scc1 .Lexit
+    s_and_b32 T0, VFL, 1023
+    s_cmp_lg_u32 T0, 0
+    s_cbranch_scc1 .Lexit
+    s_branch .Lr1
+
+// ======================================================================================================== R0
+.Lcmd:
+    s_sub_u32 IBLEN, IBLEN, 1
+    s_cbranch_scc1 .Lx_r0_switch
+    LOOKUP VHVIAC, .Lx_r0_fail
+    s_lshl1_add_u32 T4, T4, HISYM
+    v_mov_b32 VT0, T4
+    ds_read_u16 VT0, VT0
+    TAKE CLEN
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T0, VT0                         // insert&copy symbol
+    s_cmp_lt_u32 T0, 128
+    s_cselect_b32 IZ, 1, 0
+    s_lshl_b32 T0, T0, 3
+    s_load_dwordx2 s[92:93], IACTAB, T0
+    REFILL_CHECK 1
+    s_waitcnt lgkmcnt(0)
+    s_lshr_b32 T2, s92, 16
+    s_and_b32 INS, s92, 0xffff
+    s_bfm_b32 T3, T2, 0
+    s_and_b32 T3, WINLO, T3
+    s_add_u32 INS, INS, T3
+    TAKE T2
+    REFILL_CHECK 2
+    s_lshr_b32 T2, s93, 16
+    s_and_b32 CPY, s93, 0xffff
+    s_bfm_b32 T3, T2, 0
+    s_and_b32 T3, WINLO, T3
+    s_add_u32 CPY, CPY, T3
+    TAKE T2
+    REFILL_CHECK 3
+
+// ======================================================================================================== R1
+.Lr1:
+    s_cmp_gt_u32 INS, MBLEFT
+    s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
+    s_cmp_eq_u32 INS, 0
+    s_cbranch_scc1 .Lafter_lits
+    s_call_b64 LINKB, .Lland
+    s_sub_u32 MBLEFT, MBLEFT, INS
+.Llit:
+    s_sub_u32 LBLEN, LBLEN, 1
+    s_cbranch_scc1 .Lx_lit_switch
+    // context id -> tree
+    LUTB T0, VVA, P1
+    s_or_b32 T0, T0, BVAL
+    s_and_b32 T0, T0, 63
+    LUTB T1, VCMROW, T0
+    s_and_b32 T1, T1, 0xff
+    v_readlane_b32 T5, VLHOFF, T1
+    s_cmp_lt_i32 T5, 0
+    s_cbranch_scc1 .Llit_single
+    v_add_u32 VT0, T5, VLANE4
+    ds_read_b32 VT1, VT0
+    s_waitcnt lgkmcnt(0)
+    LOOKUP VT1, .Lx_lit_fail
+    s_lshl1_add_u32 T4, T4, T5
+    v_mov_b32 VT0, T4
+    ds_read_u16 VT2, VT0 offset:64
+    TAKE CLEN
+.Llit_have:
+    s_add_u32 T0, POS, SKEW
+    s_and_b32 T0, T0, RMASK
+    v_mov_b32 VT0, T0
+    LUTB BVAL, VVB, P1                                  // B[p2] of the next literal
+    s_add_u32 POS, POS, 1
+    s_waitcnt lgkmcnt(0)
+    ds_write_b8 VT0, VT2
+    v_readfirstlane_b32 P1, VT2
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lflush_stub_lit
+.Lflush_back_lit:
+    REFILL_CHECK 4
+    s_sub_u32 INS, INS, 1
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc1 .Llit
+
+.Lafter_lits:
+    s_cmp_eq_u32 MBLEFT, 0
+    s_cbranch_scc1 .Lexit                               // :2069 the copy part of the last command is ignored
+    s_min_u32 MAXA, POS, WINDOW
+    s_cmp_lg_u32 IZ, 0
+    s_cbranch_scc1 .Ldist_zero
+    // ---- distance symbol (reference parse_distance_code :1367-1410)
+    s_sub_u32 DBLEN, DBLEN, 1
+    s_cbranch_scc1 .Lx_dist_switch
+    s_sub_u32 T0, CPY, 2
+    s_min_u32 T0, T0, 3
+    s_lshl_b32 T0, T0, 3
+    s_lshr_b32 T0, CMDW, T0
+    s_and_b32 T0, T0, 0xff
+    v_readlane_b32 T5, VDHOFF, T0
+    s_cmp_lt_i32 T5, 0
+    s_cbranch_scc1 .Ldist_single
+    v_add_u32 VT0, T5, VLANE4
+    ds_read_b32 VT1, VT0
+    s_waitcnt lgkmcnt(0)
+    LOOKUP VT1, .Lx_dist_fail
+    s_lshl1_add_u32 T4, T4, T5
+    v_mov_b32 VT0, T4
+    ds_read_u16 VT2, VT0 offset:64
+    TAKE CLEN
+    REFILL_CHECK 5
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 DCODE, VT2
+.Ldist_have:
+    s_cmp_lt_u32 DCODE, 16
+    s_cbranch_scc1 .Ldist_ring
+    // direct distance: NPOSTFIX = NDIRECT = 0 (decode_distance :1412-1481)
+    s_sub_u32 T0, DCODE, 16
+    s_lshr_b32 T1, T0, 1
+    s_add_u32 T1, T1, 1                                 // extra bits
+    s_and_b32 T0, T0, 1
+    s_add_u32 T0, T0, 2
+    s_lshl_b32 T0, T0, T1
+    s_sub_u32 T0, T0, 3                                 // offset - 4 + 1
+    s_bfm_b32 T2, T1, 0
+    s_and_b32 T2, WINLO, T2
+    s_add_u32 DIST, T0, T2
+    TAKE T1
+    REFILL_CHECK 6
+    s_branch .Ldist_push
+.Ldist_single:
+    s_and_b32 DCODE, T5, 0xffff
+    s_branch .Ldist_have
+.Ldist_ring:
+    s_cmp_eq_u32 DCODE, 0
+    s_cbranch_scc1 .Ldist_zero
+    s_cmp_ge_u32 DCODE, 4
+    s_cbranch_scc1 .Ldist_delta
+    s_mov_b32 DIST, D1
+    s_cmp_eq_u32 DCODE, 2
+    s_cselect_b32 DIST, D2, DIST
+    s_cmp_eq_u32 DCODE, 3
+    s_cselect_b32 DIST, D3, DIST
+    s_branch .Ldist_push
+.Ldist_delta:
+    s_cmp_lt_u32 DCODE, 10
+    s_cselect_b32 T0, D0, D1
+    s_cselect_b32 T1, 2, 8
+    s_sub_u32 T1, DCODE, T1
+    s_lshr_b32 T1, T1, 1
+    s_sub_u32 T2, 0, T1
+    s_bitcmp1_b32 DCODE, 0
+    s_cselect_b32 T1, T1, T2
+    s_add_i32 DIST, T0, T1
+    s_cmp_le_i32 DIST, 0
+    s_cbranch_scc1 .Lx_dist_bad
+.Ldist_push:
+    s_cmp_gt_u32 DIST, MAXA
+    s_cbranch_scc1 .Ldict                               // :1476 not pushed: static dictionary reference
+    s_mov_b32 D3, D2
+    s_mov_b32 D2, D1
+    s_mov_b32 D1, D0
+    s_mov_b32 D0, DIST
+    s_branch .Lcopy
+.Ldist_zero:
+    s_mov_b32 DIST, D0
+    s_cmp_gt_u32 DIST, MAXA
+    s_cbranch_scc1 .Ldict
+
+// ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542)
+.Lcopy:
+    s_cmp_gt_u32 CPY, 64
+    s_cbranch_scc1 .Lx_r2
+    s_cmp_lt_u32 DIST, CPY
+    s_cbranch_scc1 .Lx_r2
+    s_cmp_gt_u32 CPY, MBLEFT
+    s_cbranch_scc1 .Lx_r2
+    s_call_b64 LINKB, .Lland_noctx
+    s_sub_u32 T0, CPY, 1
+    v_min_u32 VT0, T0, VLANE                            // switched-off lanes redo the last byte
+    s_sub_u32 T1, POS, DIST
+    s_cmp_gt_u32 DIST, 4096
+    s_cbranch_scc1 .Lcopy_far
+    s_add_u32 T1, T1, SKEW
+    v_add_u32 VT0, T1, VT0
+    v_and_b32 VT0, RMASK, VT0
+    ds_read_u8 VPEND, VT0
+    s_branch .Lcopy_issued
+.Lcopy_far:
+    s_sub_u32 T2, DIST, T0
+    s_cmp_le_u32 T2, 4096
+    s_cbranch_scc1 .Lx_r2                               // straddles the ring edge: rare
+    v_add_u32 VT0, T1, VT0
+    buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
+.Lcopy_issued:
+    s_mov_b32 PENDN, CPY
+    s_add_u32 POS, POS, CPY
+    s_sub_u32 MBLEFT, MBLEFT, CPY
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lflush_stub_cmd
+.Lflush_back_cmd:
+    s_cmp_eq_u32 MBLEFT, 0
+    s_cbranch_scc0 .Lcmd
+    s_mov_b32 INS, 0
+    s_branch .Lexit
+
+// ---- static dictionary word, identity transform only (src/lib.rs:1506-1540, transformation id 0)
+.Ldict:
+    s_cmp_lt_u32 CPY, 4
+    s_cbranch_scc1 .Lx_r2
+    s_cmp_gt_u32 CPY, 24
+    s_cbranch_scc1 .Lx_r2
+    s_cmp_gt_u32 CPY, MBLEFT
+    s_cbranch_scc1 .Lx_r2
+    v_readlane_b32 T0, VDICTINFO, CPY                   // DOFFSET | NDBITS << 24
+    s_sub_u32 T1, DIST, MAXA
+    s_sub_u32 T1, T1, 1                                 // word id
+    s_lshr_b32 T2, T0, 24
+    s_lshr_b32 T3, T1, T2                               // transform id
+    s_cmp_lg_u32 T3, 0
+    s_cbranch_scc1 .Lx_r2
+    s_and_b32 T0, T0, 0xffffff
+    s_mul_i32 T1, T1, CPY
+    s_add_u32 T0, T0, T1
+    s_call_b64 LINKB, .Lland_noctx
+    s_sub_u32 T1, CPY, 1
+    v_min_u32 VT0, T1, VLANE
+    v_add_u32 VT0, T0, VT0
+    global_load_ubyte VPEND, VT0, DICTP
+    s_branch .Lcopy_issued
+
+.Llit_single:                                           // one-symbol tree: no bits
+    s_and_b32 T4, T5, 0xff
+    v_mov_b32 VT2, T4
+    s_branch .Llit_have
+
+// ======================================================================================================== helpers
+// Land the pending copy in the ring (its bytes sit in lanes 0..PENDN-1 of VPEND).  .Lland also refreshes the
+// literal context (P1, BVAL) from its last two bytes; .Lland_noctx leaves it stale (a copy follows).
+.Lland:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    s_sub_u32 T6, PENDN, 1
+    v_readlane_b32 P1, VPEND, T6
+    s_sub_u32 T6, PENDN, 2
+    v_readlane_b32 T5, VPEND, T6
+    LUTB BVAL, VVB, T5
+    s_branch .Lland_store
+.Lland_noctx:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+.Lland_store:
+    s_sub_u32 T6, POS, PENDN
+    s_add_u32 T6, T6, SKEW
+    v_add_u32 VT4, T6, VLANE
+    v_and_b32 VT4, RMASK, VT4
+    s_sub_u32 T7, 64, PENDN
+    s_lshr_b64 exec, -1, T7
+    ds_write_b8 VT4, VPEND
+    s_mov_b64 exec, -1
+    s_mov_b32 PENDN, 0
+.Lland_ret:
+    s_setpc_b64 LINKB
+
+// Flush 1 KiB blocks of the ring to HBM (64 lanes x 16 B, both sides 16-byte aligned).
+.Lflush:
+    s_and_b32 T6, VFL, RMASK
+    v_add_u32 VT4, T6, VLANE16
+    ds_read_b128 VQ, VT4
+    s_sub_u32 T7, VFL, SKEW
+    v_add_u32 VT4, T7, VLANE16
+    s_waitcnt lgkmcnt(0)
+    buffer_store_dwordx4 VQ, VT4, RSRC, 0 offen
+    s_add_u32 VFL, VFL, 1024
+    s_add_u32 FLUSHAT, FLUSHAT, 1024
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lflush
+    s_setpc_b64 LINKC
+.Lflush_stub_lit:
+    s_call_b64 LINKC, .Lflush
+    s_branch .Lflush_back_lit
+.Lflush_stub_cmd:
+    s_call_b64 LINKC, .Lflush
+    s_branch .Lflush_back_cmd
+
+// Refill reached lane WLSTOP: either the staged chunk is used up (roll the two chunks, request the next one) or
+// the cursor is within 256 bits of the end of the stream (poison the block counters so that the loop leaves at
+// its next R0 / R1 test; the C++ side finishes the stream with the exact end-of-input rules).
+.Lspecial:
+    s_cmp_lg_u32 WL, 64
+    s_cbranch_scc1 .Lnear_end
+    s_waitcnt vmcnt(0)
+    v_mov_b32 VCHA, VCHB
+    s_add_u32 CBASE, CBASE, 64
+    s_add_u32 T0, CBASE, 64
+    v_add_u32 VT4, T0, VLANE
+    v_min_u32 VT4, WENDM1, VT4
+    v_lshlrev_b32 VT4, 2, VT4
+    global_load_dword VCHB, VT4, INP
+    s_mov_b32 WL, 0
+    s_sub_u32 T0, WSAFE, CBASE
+    s_cselect_b32 T0, 0, T0
+    s_min_u32 WLSTOP, T0, 64
+    s_cmp_lg_u32 WLSTOP, 0
+    s_cbranch_scc1 .Lspecial_ret
+.Lnear_end:
+    s_mov_b32 WLSTOP, 64
+    s_bitcmp1_b32 FLAGS, 0
+    s_cbranch_scc1 .Lspecial_ret
+    s_bitset1_b32 FLAGS, 0
+    s_mov_b32 LBLEN_REAL, LBLEN
+    s_mov_b32 IBLEN_REAL, IBLEN
+    s_mov_b32 LBLEN, 0
+    s_mov_b32 IBLEN, 0
+.Lspecial_ret:
+    s_setpc_b64 LINKA
+
+    REFILL_STUB 1
+    REFILL_STUB 2
+    REFILL_STUB 3
+    REFILL_STUB 4
+    REFILL_STUB 5
+    REFILL_STUB 6
+
+// ======================================================================================================== exits
+.Lx_r0_switch:                                          // insert&copy block count exhausted (or poisoned)
+    s_mov_b32 IBLEN, 0
+    s_mov_b32 EXITC, 0
+    s_branch .Lexit
+.Lx_r0_fail:
+    s_add_u32 IBLEN, IBLEN, 1
+    s_mov_b32 EXITC, 0
+    s_branch .Lexit
+.Lx_lit_switch:                                         // literal block count exhausted (or poisoned), mid-run
+    s_mov_b32 LBLEN, 0
+    s_add_u32 MBLEFT, MBLEFT, INS
+    s_branch .Lexit
+.Lx_lit_fail:
+    s_add_u32 LBLEN, LBLEN, 1
+    s_add_u32 MBLEFT, MBLEFT, INS
+    s_branch .Lexit
+.Lx_dist_switch:
+    s_mov_b32 DBLEN, 0
+    s_mov_b32 INS, 0
+    s_branch .Lexit
+.Lx_dist_fail:
+    s_add_u32 DBLEN, DBLEN, 1
+    s_mov_b32 INS, 0
+    s_branch .Lexit
+.Lx_dist_bad:                                           // non-positive distance: raised by the C++ side at R2
+    s_mov_b32 DIST, 0
+    s_mov_b32 EXITC, 3
+    s_branch .Lexit
+.Lx_r2:
+    s_mov_b32 EXITC, 2
+.Lexit:
+    s_call_b64 LINKB, .Lland_noctx
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    // real block counters if they were poisoned
+    s_bitcmp1_b32 FLAGS, 0
+    s_cselect_b32 LBLEN, LBLEN_REAL, LBLEN
+    s_cselect_b32 IBLEN, IBLEN_REAL, IBLEN
+    // bit cursor: 32 * (CBASE + WL) - NAV
+    s_add_u32 T0, CBASE, WL
+    s_lshl_b32 T0, T0, 5
+    s_sub_u32 T0, T0, NAV
+    v_mov_b32 VT0, T0
+    v_mov_b32 VT1, 0
+    ds_write_b32 VZERO, VT0 offset:LDS_ST+12            // bitpos (st[3], st[4])
+    ds_write_b32 VZERO, VT1 offset:LDS_ST+16
+    v_mov_b32 VT0, POS
+    ds_write_b32 VZERO, VT0 offset:LDS_ST+40
+    v_mov_b32 VT0, VFL
+    ds_write_b32 VZERO, VT0 offset:LDS_ST+48
+    v_mov_b32 v20, D0
+    v_mov_b32 v21, D1
+    v_mov_b32 v22, D2
+    v_mov_b32 v23, D3
+    ds_write_b64 VZERO, v[20:21] offset:LDS_ST+56
+    ds_write_b64 VZERO, v[22:23] offset:LDS_ST+64
+    v_mov_b32 VT0, LBLEN
+    ds_write_b32 VZERO, VT0 offset:LDS_MBW+60
+    v_mov_b32 VT0, IBLEN
+    ds_write_b32 VZERO, VT0 offset:LDS_MBW+84
+    v_mov_b32 VT0, DBLEN
+    ds_write_b32 VZERO, VT0 offset:LDS_MBW+108
+    v_mov_b32 v20, MBLEFT
+    v_mov_b32 v21, INS
+    v_mov_b32 v22, CPY
+    v_mov_b32 v23, IZ
+    ds_write_b128 VZERO, v[20:23] offset:LDS_MBW+128
+    s_cmp_eq_u32 EXITC, 3
+    s_cselect_b32 T0, 1, 0
+    s_cselect_b32 EXITC, 2, EXITC
+    v_mov_b32 v20, DIST
+    v_mov_b32 v21, T0
+    v_mov_b32 v22, EXITC
+    ds_write_b64 VZERO, v[20:21] offset:LDS_MBW+144     // distance, distance-is-bad
+    ds_write_b32 VZERO, v22 offset:LDS_MBW+152          // exit point
+    s_waitcnt lgkmcnt(0)

@@ -252,6 +252,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_STARTED 33 // 0 before the stream header (WBITS) has been read
 #define ST_ISLAST 34  // ISLAST of the meta-block handed to the command loop
 #define ST_MLEN 35    // its MLEN
+#define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
 // hot_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
@@ -259,6 +260,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define HC_RESUME_R0 2u  // resume: insert&copy symbol due; one command, park
 #define HC_RESUME_R1 3u  // resume at the loop top; one command, park
 #define HC_RESUME_R2 4u  // resume with the distance known; one command, park
+#define HC_RESUME_R1_WHOLE 5u // resume at the loop top and run the meta-block to its end
 #define HC_CONTINUE 200u // returned when parked (meta-block not finished)
 #define MBW_ASM 31
 #define MBW_MBLEFT 32
@@ -1509,7 +1511,10 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
     // Re-entry (the assembly fast loop hands single commands back, see brx_hot.S): resume points
     //   R0 = an insert&copy symbol is due, R1 = loop top (insert_len / copy_len / implicit_zero valid),
     //   R2 = the distance of the current command is known (ring of last distances already updated).
-    u32 budget = mode == HC_WHOLE ? 0xffffffffu : mode == HC_START ? 0u : 1u; // commands to run before parking
+    u32 budget = (mode == HC_WHOLE || mode == HC_RESUME_R1_WHOLE) ? 0xffffffffu : mode == HC_START ? 0u : 1u; // commands before parking
+    // one-command calls keep going while the flush cursor is ragged (first KiB of a stream with an unaligned output
+    // pointer): the assembly loop only flushes whole aligned blocks
+    const bool oneshot = mode >= HC_RESUME_R0 && mode <= HC_RESUME_R2;
     u32 phase2 = mode == HC_RESUME_R2 ? 1u : 0u;
     u32 distance = 0, dist_bad = 0;
     if (mode >= HC_RESUME_R0) {
@@ -1642,6 +1647,24 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
     if (I.blen == 0xffffffffu) I.blen = 0x7fffffffu;
     if (D.blen == 0xffffffffu) D.blen = 0x7fffffffu;
 
+    if (mode == HC_START) {
+        // Is this meta-block one for the assembly loop (see the preconditions in brx_hot.S)?  The fast-path limits hold
+        // already; what remains: the handle table and every tree in LDS, every tree a general code.
+        const u32 total = m.ntl + I.nbl + m.ntd;
+        u32 ok = (m.hl + total <= BRX_TM_WORDS && (u32)(uintptr_t)&g_lds == 0u) ? 1u : 0u;
+        u32 why = ok ? 0u : 1u;
+        for (u32 i = 0; i < total; i++) {
+            const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
+            if (h_ >= BRX_TM_WORDS - 16u) { ok = 0u; why |= 2u | (i << 8); }
+            else {
+                const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
+                const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
+                if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u | (i << 16); }
+            }
+        }
+        s.mbw[MBW_ASM] = ok;
+        s.pad[0] = why; s.pad[1] = d.lds_top; s.pad[2] = d.scr_top; s.pad[3] = m.hl;
+    }
     if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
     while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
       u32 max_allowed;
@@ -1747,7 +1770,7 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
             pend_n = copy_len;
             d.pos += copy_len;
             mb_left -= copy_len;
-            budget--;
+            budget = (oneshot && (d.vfl & (BRX_FLUSH_BLOCK - 1u)) != 0u) ? budget : budget - 1u;
             if (mb_left != 0u) H_DECODE_IAC(); // lookahead (:2128 otherwise): overlaps the fetch above
             // the block being flushed ends >= BRX_FLUSH_LAG bytes behind the cursor: never the pending bytes
             if (d.pos + d.a >= (d.vfl & ~(BRX_FLUSH_BLOCK - 1u)) + BRX_FLUSH_BLOCK + BRX_FLUSH_LAG) maybe_flush(d, s);
@@ -1772,7 +1795,7 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
             else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
             maybe_flush(d, s);
         }
-        budget--;
+        budget = (oneshot && (d.vfl & (BRX_FLUSH_BLOCK - 1u)) != 0u) ? budget : budget - 1u;
         if (mb_left != 0u) H_DECODE_IAC(); // :2128 otherwise
     }
     H_LAND();
@@ -1802,6 +1825,23 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
 #undef H_DECODE_IAC
     dec_store(d, s);
     return rc;
+}
+
+// The assembly command loop (brx_hot.S).  No operands: it reads and writes the parked state in LDS and returns the
+// resume point it stopped at (0 = R0, 1 = R1, 2 = R2) in mbw[MBW_EXIT].
+__device__ __noinline__ u32 asm_commands() {
+    asm volatile(
+#include "_gen/brx_hot_asm.h"
+        :
+        :
+        : "memory", "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+          "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
+          "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
+          "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
+          "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
+          "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+    return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
 // The table-memory command loop for meta-blocks too large for the register tables, out of line.
@@ -1967,7 +2007,10 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             d.t_xforms = a.t.xforms;
             d.t_lut = (const u32 *)a.t.context_lut;
             dec_store(d, s);
-            if (lane == 0u) { s.st[ST_STARTED] = 0u; s.st[ST_ISLAST] = 0u; s.st[ST_MLEN] = 0u; }
+            if (lane == 0u) {
+                s.st[ST_STARTED] = 0u; s.st[ST_ISLAST] = 0u; s.st[ST_MLEN] = 0u;
+                s.st[ST_IACTAB] = (u32)(uintptr_t)a.t.iac; s.st[ST_IACTAB + 1] = (u32)((u64)(uintptr_t)a.t.iac >> 32);
+            }
             if (lane < 32u) s.pad[lane] = 0u;
         }
         const u32 prof_on = a.debug != nullptr ? 1u : 0u;
@@ -1981,8 +2024,24 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             } else if (a.debug_stop == 7u) { // bring-up: the re-entrant C++ loop alone, one command per call
                 st = hot_commands(HC_START);
                 while (st == HC_CONTINUE) st = hot_commands(HC_RESUME_R1);
-            } else {
+            } else if (a.debug_stop == 8u) { // bring-up: the C++ loop alone, whole meta-block per call
                 st = hot_commands(HC_WHOLE);
+            } else {
+                // Assembly fast loop with the C++ loop as its safety net: the assembly runs until something unusual
+                // comes up, C++ takes exactly one command (or finishes the meta-block), and so on.
+                st = hot_commands(HC_START);
+                if (st == HC_CONTINUE && rfl(s.mbw[MBW_ASM]) == 0u) st = hot_commands(HC_RESUME_R1_WHOLE);
+                while (st == HC_CONTINUE) {
+                    const u32 r = asm_commands();
+                    if (prof_on && lane == 0u) {
+                        s.pad[4 + (r & 3u)]++;
+                        if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) {
+                            for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
+                            s.pad[15] = s.st[10]; s.pad[7] = s.st[3];
+                        }
+                    }
+                    st = hot_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
+                }
             }
             if (st) break;
             st = seg_frame();
