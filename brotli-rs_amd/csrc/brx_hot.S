@@ -100,6 +100,7 @@
 #define VT2 v20
 #define VT3 v21
 #define VT4 v22
+#define VPENB v23
 
 // Bits are taken from the low end of WIN; NAV = number of valid bits in it (>= 32 after a REFILL_CHECK).
 .macro TAKE n
@@ -134,14 +135,13 @@
 .endm
 // Canonical prefix-code lookup.  hv = per-lane header words of the tree (lane L: limit[L] | base[L] << 16).
 // Out: CLEN = code length, T4 = index into the tree's sorted symbol list.  Clobbers T0-T3, VT3, vcc.
-// A window that matches no code (incomplete code) branches to \fail with nothing consumed.
-.macro LOOKUP hv, fail
+// Every code is complete (precondition), so some lane always matches.
+.macro LOOKUP hv
     s_brev_b32 T0, WINLO
     s_lshr_b32 T1, T0, 17
     v_and_b32 VT3, 0xffff, \hv
     v_cmp_lt_u32 vcc, T1, VT3
     s_and_b32 T2, vcc_lo, 0xfffe
-    s_cbranch_scc0 \fail
     s_ff1_i32_b32 CLEN, T2
     v_readlane_b32 T3, \hv, CLEN
     s_sub_u32 T2, 32, CLEN
@@ -149,6 +149,23 @@
     s_lshr_b32 T3, T3, 16
     s_add_u32 T4, T2, T3
     s_and_b32 T4, T4, 0xffff
+.endm
+
+// Wait for the pending copy's bytes.  With -DBRX_ASM_PROF the cycles spent in this wait are summed into s97 and
+// handed out through mbw[39] (bring-up measurement of how much of a stream's time is far-copy latency).
+.macro PROF_WAIT
+#ifdef BRX_ASM_PROF
+    s_waitcnt lgkmcnt(0)
+    s_memtime s[92:93]
+    s_waitcnt lgkmcnt(0)
+    s_waitcnt vmcnt(0)
+    s_memtime s[94:95]
+    s_waitcnt lgkmcnt(0)
+    s_sub_u32 s94, s94, s92
+    s_add_u32 s97, s97, s94
+#else
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+#endif
 .endm
 
 // ======================================================================================================== entry
@@ -343,6 +360,7 @@
     s_mov_b32 PENDN, 0
     s_mov_b32 FLAGS, 0
     s_mov_b32 EXITC, 1
+    s_mov_b32 s97, 0
     s_and_b32 T0, VFL, 0xfffffc00
     s_add_u32 T0, T0, 2048
     s_sub_u32 FLUSHAT, T0, SKEW
@@ -376,7 +394,7 @@
 .Lcmd:
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
-    LOOKUP VHVIAC, .Lx_r0_fail
+    LOOKUP VHVIAC
     s_lshl1_add_u32 T4, T4, HISYM
     v_mov_b32 VT0, T4
     ds_read_u16 VT0, VT0
@@ -419,15 +437,14 @@
     LUTB T0, VVA, P1
     s_or_b32 T0, T0, BVAL
     s_and_b32 T0, T0, 63
-    LUTB T1, VCMROW, T0
-    s_and_b32 T1, T1, 0xff
+    LUTB T1, VCMROW, T0                                 // v_readlane uses bits 5:0 of the lane select only
     v_readlane_b32 T5, VLHOFF, T1
     s_cmp_lt_i32 T5, 0
     s_cbranch_scc1 .Llit_single
     v_add_u32 VT0, T5, VLANE4
     ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP VT1, .Lx_lit_fail
+    LOOKUP VT1
     s_lshl1_add_u32 T4, T4, T5
     v_mov_b32 VT0, T4
     ds_read_u16 VT2, VT0 offset:64
@@ -462,14 +479,13 @@
     s_min_u32 T0, T0, 3
     s_lshl_b32 T0, T0, 3
     s_lshr_b32 T0, CMDW, T0
-    s_and_b32 T0, T0, 0xff
     v_readlane_b32 T5, VDHOFF, T0
     s_cmp_lt_i32 T5, 0
     s_cbranch_scc1 .Ldist_single
     v_add_u32 VT0, T5, VLANE4
     ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP VT1, .Lx_dist_fail
+    LOOKUP VT1
     s_lshl1_add_u32 T4, T4, T5
     v_mov_b32 VT0, T4
     ds_read_u16 VT2, VT0 offset:64
@@ -535,29 +551,37 @@
 
 // ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542)
 .Lcopy:
-    s_cmp_gt_u32 CPY, 64
+    s_min_u32 T0, DIST, 64                              // CPY <= min(64, distance, bytes left) or the C++ side does it
+    s_min_u32 T0, T0, MBLEFT
+    s_cmp_gt_u32 CPY, T0
     s_cbranch_scc1 .Lx_r2
-    s_cmp_lt_u32 DIST, CPY
-    s_cbranch_scc1 .Lx_r2
-    s_cmp_gt_u32 CPY, MBLEFT
-    s_cbranch_scc1 .Lx_r2
-    s_call_b64 LINKB, .Lland_noctx
     s_sub_u32 T0, CPY, 1
     v_min_u32 VT0, T0, VLANE                            // switched-off lanes redo the last byte
     s_sub_u32 T1, POS, DIST
     s_cmp_gt_u32 DIST, 4096
     s_cbranch_scc1 .Lcopy_far
+    s_call_b64 LINKB, .Lland_noctx                      // the source may be the pending bytes
+    s_bitset0_b32 FLAGS, 2
     s_add_u32 T1, T1, SKEW
     v_add_u32 VT0, T1, VT0
     v_and_b32 VT0, RMASK, VT0
     ds_read_u8 VPEND, VT0
     s_branch .Lcopy_issued
-.Lcopy_far:
+.Lcopy_far:                                             // older than the ring: final in HBM, never the pending bytes
     s_sub_u32 T2, DIST, T0
     s_cmp_le_u32 T2, 4096
     s_cbranch_scc1 .Lx_r2                               // straddles the ring edge: rare
     v_add_u32 VT0, T1, VT0
+    s_bitcmp1_b32 FLAGS, 2
+    s_cbranch_scc1 .Lcopy_far_b
+    buffer_load_ubyte VPENB, VT0, RSRC, 0 offen         // request first, THEN wait for and land the older copy
+    s_call_b64 LINKB, .Lland_a_w1
+    s_bitset1_b32 FLAGS, 2
+    s_branch .Lcopy_issued
+.Lcopy_far_b:
     buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
+    s_call_b64 LINKB, .Lland_b_w1
+    s_bitset0_b32 FLAGS, 2
 .Lcopy_issued:
     s_mov_b32 PENDN, CPY
     s_add_u32 POS, POS, CPY
@@ -589,6 +613,7 @@
     s_mul_i32 T1, T1, CPY
     s_add_u32 T0, T0, T1
     s_call_b64 LINKB, .Lland_noctx
+    s_bitset0_b32 FLAGS, 2
     s_sub_u32 T1, CPY, 1
     v_min_u32 VT0, T1, VLANE
     v_add_u32 VT0, T0, VT0
@@ -601,32 +626,59 @@
     s_branch .Llit_have
 
 // ======================================================================================================== helpers
-// Land the pending copy in the ring (its bytes sit in lanes 0..PENDN-1 of VPEND).  .Lland also refreshes the
-// literal context (P1, BVAL) from its last two bytes; .Lland_noctx leaves it stale (a copy follows).
-.Lland:
-    s_cmp_eq_u32 PENDN, 0
-    s_cbranch_scc1 .Lland_ret
-    s_waitcnt vmcnt(0) lgkmcnt(0)
-    s_sub_u32 T6, PENDN, 1
-    v_readlane_b32 P1, VPEND, T6
-    s_sub_u32 T6, PENDN, 2
-    v_readlane_b32 T5, VPEND, T6
-    LUTB BVAL, VVB, T5
-    s_branch .Lland_store
-.Lland_noctx:
-    s_cmp_eq_u32 PENDN, 0
-    s_cbranch_scc1 .Lland_ret
-    s_waitcnt vmcnt(0) lgkmcnt(0)
-.Lland_store:
+// Land the pending copy in the ring: its bytes sit in lanes 0..PENDN-1 of VPEND (FLAGS bit 2 clear) or VPENB (set).
+// Two copies can be in flight: a far copy is requested into the free register BEFORE the older one is waited for
+// (.Lland_[ab]_w1 wait with vmcnt(1): everything but the request just issued).  .Lland also refreshes the literal
+// context (P1, BVAL) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
+.macro LAND_STORE reg
     s_sub_u32 T6, POS, PENDN
     s_add_u32 T6, T6, SKEW
     v_add_u32 VT4, T6, VLANE
     v_and_b32 VT4, RMASK, VT4
     s_sub_u32 T7, 64, PENDN
     s_lshr_b64 exec, -1, T7
-    ds_write_b8 VT4, VPEND
+    ds_write_b8 VT4, \reg
     s_mov_b64 exec, -1
     s_mov_b32 PENDN, 0
+    s_setpc_b64 LINKB
+.endm
+.macro LAND_CTX reg
+    s_sub_u32 T6, PENDN, 1
+    v_readlane_b32 P1, \reg, T6
+    s_sub_u32 T6, PENDN, 2
+    v_readlane_b32 T5, \reg, T6
+    LUTB BVAL, VVB, T5
+.endm
+.Lland:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    PROF_WAIT
+    s_bitcmp1_b32 FLAGS, 2
+    s_cbranch_scc1 .Lland_ctx_b
+    LAND_CTX VPEND
+    LAND_STORE VPEND
+.Lland_ctx_b:
+    LAND_CTX VPENB
+    LAND_STORE VPENB
+.Lland_noctx:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    PROF_WAIT
+    s_bitcmp1_b32 FLAGS, 2
+    s_cbranch_scc1 .Lland_store_b
+    LAND_STORE VPEND
+.Lland_store_b:
+    LAND_STORE VPENB
+.Lland_a_w1:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    s_waitcnt vmcnt(1) lgkmcnt(0)
+    LAND_STORE VPEND
+.Lland_b_w1:
+    s_cmp_eq_u32 PENDN, 0
+    s_cbranch_scc1 .Lland_ret
+    s_waitcnt vmcnt(1) lgkmcnt(0)
+    LAND_STORE VPENB
 .Lland_ret:
     s_setpc_b64 LINKB
 
@@ -695,24 +747,12 @@
     s_mov_b32 IBLEN, 0
     s_mov_b32 EXITC, 0
     s_branch .Lexit
-.Lx_r0_fail:
-    s_add_u32 IBLEN, IBLEN, 1
-    s_mov_b32 EXITC, 0
-    s_branch .Lexit
 .Lx_lit_switch:                                         // literal block count exhausted (or poisoned), mid-run
     s_mov_b32 LBLEN, 0
     s_add_u32 MBLEFT, MBLEFT, INS
     s_branch .Lexit
-.Lx_lit_fail:
-    s_add_u32 LBLEN, LBLEN, 1
-    s_add_u32 MBLEFT, MBLEFT, INS
-    s_branch .Lexit
 .Lx_dist_switch:
     s_mov_b32 DBLEN, 0
-    s_mov_b32 INS, 0
-    s_branch .Lexit
-.Lx_dist_fail:
-    s_add_u32 DBLEN, DBLEN, 1
     s_mov_b32 INS, 0
     s_branch .Lexit
 .Lx_dist_bad:                                           // non-positive distance: raised by the C++ side at R2
@@ -765,4 +805,6 @@
     v_mov_b32 v22, EXITC
     ds_write_b64 VZERO, v[20:21] offset:LDS_MBW+144     // distance, distance-is-bad
     ds_write_b32 VZERO, v22 offset:LDS_MBW+152          // exit point
+    v_mov_b32 v23, s97
+    ds_write_b32 VZERO, v23 offset:LDS_MBW+156          // (BRX_ASM_PROF) cycles waited for copy data
     s_waitcnt lgkmcnt(0)

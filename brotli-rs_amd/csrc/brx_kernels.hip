@@ -1660,10 +1660,15 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
                 const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
                 if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u | (i << 16); }
+                // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
+                // the left-aligned upper bound of its longest codes is then exactly 2^15
+                const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
+                const bool full_ = ballot((hvw_ & 0xffffu) == 0x8000u && (d.lane & 15u) != 0u) != 0ull;
+                if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }
         s.mbw[MBW_ASM] = ok;
-        s.pad[0] = why; s.pad[1] = d.lds_top; s.pad[2] = d.scr_top; s.pad[3] = m.hl;
+        s.pad[0] = why; s.pad[1] = d.lds_top; s.pad[2] = d.scr_top;
     }
     if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
     while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
@@ -2035,6 +2040,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                     const u32 r = asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
+                        s.pad[3] += s.mbw[39];
                         if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) {
                             for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
                             s.pad[15] = s.st[10]; s.pad[7] = s.st[3];
