@@ -226,7 +226,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         std::vector<unsigned long long> h((size_t)n * 10);
         (void)hipMemcpy(h.data(), dbg, (size_t)n * 80, hipMemcpyDeviceToHost);
         static const char *nm[10] = {"hdr", "iac", "lit", "dist", "copy", "ncmd", "nlit", "fastmb", "total", "scr_top"};
-        for (uint32_t i = 0; i < n && i < 2; i++) {
+        for (uint32_t i = 0; i < n && i < (getenv("BRX_DEBUG_STATS_ALL") ? n : 2u); i++) {
             fprintf(stderr, "[brx stats] stream %u:", i);
             for (int q = 0; q < 10; q++) fprintf(stderr, " %s=%llu", nm[q], h[(size_t)i * 10 + q]);
             fprintf(stderr, "\n[brx stats] words:");

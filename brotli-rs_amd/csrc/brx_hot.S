@@ -16,9 +16,10 @@
 // overlapping their source, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
 // (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
 //
-// Preconditions (hot_commands(HC_START) sets mbw[MBW_ASM]): NPOSTFIX = NDIRECT = 0, every literal / distance /
-// insert&copy tree is a general code (kind 2) resident in LDS table memory, <= 64 literal and <= 64 distance
-// trees, context maps in LDS, input < 2^28 bytes, pos + MLEN <= capacity, flush cursor 1 KiB aligned.
+// Preconditions (the HC_START call of hot_commands() / generic_commands() sets mbw[MBW_ASM]): every literal and
+// distance tree is a complete general code or a one-symbol code, every insert&copy tree a complete general code, all
+// of them and the context maps resident in LDS table memory, <= 64 literal and <= 64 distance trees, input < 2^28
+// bytes, pos + MLEN <= capacity.  (A ragged flush cursor at entry hands straight back to the C++ side.)
 
 #define LDS_TM 4096
 #define LDS_ST 9728
@@ -79,6 +80,10 @@
 #define CLEN s96
 #define LINKB s[98:99]
 #define LINKC s[100:101]
+#define NPOST s4
+#define NDIRECT s5
+#define POSTMASK s6
+#define NDIRECT1 s7
 // ---- VGPRs
 #define VZERO v0
 #define VLANE v1
@@ -242,6 +247,8 @@
     ds_read_b128 v[24:27], VZERO offset:LDS_MBW+16      // cmd, hl, hi, hd
     ds_read_b64 v[32:33], VZERO offset:LDS_MBW+32       // ntl, ntd
     s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 NPOST, v20
+    v_readfirstlane_b32 NDIRECT, v21
     v_readfirstlane_b32 T0, v22                         // cmode_w
     v_readfirstlane_b32 T1, v23                         // cml
     v_readfirstlane_b32 T2, v24                         // cmd
@@ -357,6 +364,8 @@
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
     s_min_u32 WLSTOP, T0, 64
+    s_bfm_b32 POSTMASK, NPOST, 0
+    s_add_u32 NDIRECT1, NDIRECT, 1
     s_mov_b32 PENDN, 0
     s_mov_b32 FLAGS, 0
     s_mov_b32 EXITC, 1
@@ -496,19 +505,30 @@
 .Ldist_have:
     s_cmp_lt_u32 DCODE, 16
     s_cbranch_scc1 .Ldist_ring
-    // direct distance: NPOSTFIX = NDIRECT = 0 (decode_distance :1412-1481)
+    // distance codes >= 16 (decode_distance :1412-1481)
     s_sub_u32 T0, DCODE, 16
-    s_lshr_b32 T1, T0, 1
+    s_sub_u32 T0, T0, NDIRECT
+    s_cbranch_scc1 .Ldist_direct                        // 16 <= code < 16 + NDIRECT
+    s_add_u32 T2, NPOST, 1
+    s_lshr_b32 T1, T0, T2
     s_add_u32 T1, T1, 1                                 // extra bits
-    s_and_b32 T0, T0, 1
-    s_add_u32 T0, T0, 2
-    s_lshl_b32 T0, T0, T1
-    s_sub_u32 T0, T0, 3                                 // offset - 4 + 1
-    s_bfm_b32 T2, T1, 0
-    s_and_b32 T2, WINLO, T2
-    s_add_u32 DIST, T0, T2
+    s_lshr_b32 T2, T0, NPOST                            // hcode
+    s_and_b32 T3, T0, POSTMASK                          // lcode
+    s_and_b32 T2, T2, 1
+    s_add_u32 T2, T2, 2
+    s_lshl_b32 T2, T2, T1
+    s_sub_u32 T2, T2, 4                                 // offset
+    s_bfm_b32 T4, T1, 0
+    s_and_b32 T4, WINLO, T4
+    s_add_u32 T2, T2, T4
+    s_lshl_b32 T2, T2, NPOST
+    s_add_u32 T2, T2, T3
+    s_add_u32 DIST, T2, NDIRECT1
     TAKE T1
     REFILL_CHECK 6
+    s_branch .Ldist_push
+.Ldist_direct:
+    s_sub_u32 DIST, DCODE, 15
     s_branch .Ldist_push
 .Ldist_single:
     s_and_b32 DCODE, T5, 0xffff

@@ -1007,247 +1007,6 @@ FI u32 fast_lookup(Dec &d, u32 hv4, u32 slot, u32 &idx, bool &single) {
     return LK_OK;
 }
 
-struct FastLegacy { u32 LH[2], LS[8], DH[2], DS[2], IH, IS[6], CMROW, CMDV; }; // only the (unused) FAST=true instance of
-                                                                               // the template below touches this
-template <bool FAST> FI u32 command_loop(Dec &d, Lds &s, const MB &m, Cat &L, Cat &I, Cat &D, Prof &pf) {
-    FastLegacy f;
-    u32 rc;
-    bool sw;
-    if (FAST) {
-        for (u32 k = 0; k < 2u; k++) { f.LH[k] = 0; f.DH[k] = 0; f.DS[k] = 0; }
-        f.IH = 0;
-        for (u32 t = 0; t < 8u; t++) {
-            f.LS[t] = 0;
-            if (t < m.ntl) {
-                u32 h = tm_u32(d, s, m.hl + t);
-                fast_load_hdr(d, s, h, t, f.LH[t >> 2]);
-                f.LS[t] = fast_load_sym8(d, s, h);
-            }
-            if (t < m.ntd) {
-                u32 h = tm_u32(d, s, m.hd + t);
-                fast_load_hdr(d, s, h, t, f.DH[t >> 2]);
-                u32 w = fast_load_sym8_q(d, s, h); // lanes 16q..16q+15 all carry the tree's 64 symbols
-                u32 mask = 0u - (u32)((d.lane >> 4) == (t & 3u));
-                f.DS[t >> 2] = (w & mask) | (f.DS[t >> 2] & ~mask);
-            }
-        }
-        for (u32 t = 0; t < 4u; t++)
-            if (t < I.nbl) fast_load_hdr(d, s, tm_u32(d, s, m.hi + t), t, f.IH);
-        {
-            u32 h = tm_u32(d, s, m.hi + I.btype);
-            for (u32 k = 0; k < 6u; k++) f.IS[k] = fast_load_sym16(d, s, h, k);
-        }
-        f.CMROW = s.tm[(m.cml >> 2) + L.btype * 16u + (d.lane & 15u)]; // lanes >= 16 hold copies, never read
-        f.CMDV = s.tm[(m.cmd >> 2) + (d.lane < D.nbl ? d.lane : D.nbl - 1u)];
-    }
-    u32 h_iac = FAST ? 0u : tm_u32(d, s, m.hi + I.btype);
-    u32 cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
-    u32 mb = 0; // MetaBlock.count_output
-    u32 p1, p2;
-    ctx_bytes(d, s, p1, p2);
-
-    // ---- parse_insert_and_copy_length :1179-1208 + decode_insert_and_copy_length :1210-1224 as a lambda-like
-    // block: it runs once before the loop and then as the LOOKAHEAD of every iteration (the next command's
-    // symbol is decoded while the current copy's source bytes are still in flight).
-    u32 insert_len = 0, copy_len = 0;
-    bool implicit_zero = false;
-#define BRX_DECODE_IAC()                                                                                       \
-    do {                                                                                                       \
-        if (++d.wd > d.wd_limit) return ST_WATCHDOG;                                                           \
-        if ((rc = cat_tick(d, s, I, sw))) return rc;                                                           \
-        u32 sym_;                                                                                              \
-        if (FAST) {                                                                                            \
-            if (sw) {                                                                                          \
-                u32 hh_ = tm_u32(d, s, m.hi + I.btype);                                                        \
-                for (u32 kk_ = 0; kk_ < 6u; kk_++) f.IS[kk_] = fast_load_sym16(d, s, hh_, kk_);                \
-            }                                                                                                  \
-            u32 idx_; bool single_;                                                                            \
-            u32 lk_ = fast_lookup(d, f.IH, I.btype, idx_, single_);                                            \
-            if (lk_ == LK_NONE) return ST_PARSE_IAC;                                                           \
-            if (lk_ == LK_EOF) return ST_EOF;                                                                  \
-            if (single_) sym_ = idx_;                                                                          \
-            else {                                                                                             \
-                u32 k_ = idx_ >> 7;                                                                            \
-                u32 w_;                                                                                        \
-                switch (k_) {                                                                                  \
-                case 0: w_ = rdl(f.IS[0], (idx_ >> 1) & 63u); break;                                           \
-                case 1: w_ = rdl(f.IS[1], (idx_ >> 1) & 63u); break;                                           \
-                case 2: w_ = rdl(f.IS[2], (idx_ >> 1) & 63u); break;                                           \
-                case 3: w_ = rdl(f.IS[3], (idx_ >> 1) & 63u); break;                                           \
-                case 4: w_ = rdl(f.IS[4], (idx_ >> 1) & 63u); break;                                           \
-                default: w_ = rdl(f.IS[5], (idx_ >> 1) & 63u); break;                                          \
-                }                                                                                              \
-                sym_ = (w_ >> ((idx_ & 1u) * 16u)) & 0xffffu;                                                  \
-            }                                                                                                  \
-        } else {                                                                                               \
-            if (sw) h_iac = tm_u32(d, s, m.hi + I.btype);                                                      \
-            u32 lk_ = decode_sym(d, s, h_iac, sym_);                                                           \
-            if (lk_ == LK_NONE) return ST_PARSE_IAC;                                                           \
-            if (lk_ == LK_EOF) return ST_EOF;                                                                  \
-        }                                                                                                      \
-        implicit_zero = sym_ < 128u; /* :2012-2015 */                                                          \
-        u32 cell_ = sym_ >> 6;                                                                                 \
-        /* cell -> (insert code offset, copy code offset), one nibble per cell in units of 8:                  \
-           0:(0,0) 1:(0,8) 2:(0,0) 3:(0,8) 4:(8,0) 5:(8,8) 6:(0,16) 7:(16,0) 8:(8,16) 9:(16,8) 10:(16,16) */   \
-        u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                                      \
-        u32 coff_ = (u32)((0x21202101010ull >> (4u * cell_)) & 15u) * 8u;                                      \
-        u32 pki_ = rdl(d.v_ic, ioff_ + ((sym_ >> 3) & 7u));                                                   \
-        u32 pkc_ = rdl(d.v_ic, 32u + coff_ + (sym_ & 7u));                                                         \
-        u32 e_;                                                                                                \
-        if (!in_bits(d, pki_ & 31u, e_)) return ST_EOF;                                                        \
-        insert_len = (pki_ >> 5) + e_;                                                                         \
-        if (!in_bits(d, pkc_ & 31u, e_)) return ST_EOF;                                                        \
-        copy_len = (pkc_ >> 5) + e_;                                                                           \
-    } while (0)
-
-    u64 t0 = TICK();
-    BRX_DECODE_IAC();
-    pf.tk[1] += TICK() - t0;
-    if (FAST) pf.tk[7] += 1;
-    for (;;) {
-        t0 = TICK();
-        if (m.mlen < mb + insert_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2036 (Q4)
-        if (!out_room(d, insert_len)) return ST_OUTPUT_TOO_SMALL;
-        // ---- parse_insert_literals :1286-1365 (+ InsertLiterals state :2048-2081)
-        for (u32 k = 0; k < insert_len; k++) {
-            if ((rc = cat_tick(d, s, L, sw))) return rc;
-            if (sw) {
-                cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
-                if (FAST) f.CMROW = s.tm[(m.cml >> 2) + L.btype * 16u + (d.lane & 15u)];
-            }
-            u32 cid;
-            if (cmode == 3u) cid = (lut8(d.v_lut2, p1) << 3) | lut8(d.v_lut2, p2);
-            else if (cmode == 2u) cid = lut8(d.v_lut0, p1) | lut8(d.v_lut1, p2);
-            else if (cmode == 0u) cid = p1 & 0x3fu;
-            else cid = p1 >> 2;
-            u32 lit;
-            if (FAST) {
-                u32 ti = (rdl(f.CMROW, cid >> 2) >> ((cid & 3u) * 8u)) & 0xffu;
-                u32 idx; bool single;
-                u32 lk = fast_lookup(d, pick2(f.LH, ti >> 2), ti & 3u, idx, single);
-                if (lk == LK_NONE) return ST_PARSE_LITERALS;
-                if (lk == LK_EOF) return ST_EOF;
-                if (single) lit = idx;
-                else lit = (rdl(pick8(f.LS, ti), idx >> 2) >> ((idx & 3u) * 8u)) & 0xffu;
-            } else {
-                u32 ti = tm_u8(d, s, m.cml + L.btype * 64u + cid);
-                u32 h = tm_u32(d, s, m.hl + ti);
-                u32 lk = decode_sym(d, s, h, lit);
-                if (lk == LK_NONE) return ST_PARSE_LITERALS;
-                if (lk == LK_EOF) return ST_EOF;
-            }
-            ring_put(d, s, d.lane == 0u, d.pos + d.a, lit);
-            d.pos++;
-            p2 = p1;
-            p1 = lit;
-            if (((d.pos + d.a) & 63u) == 0u) maybe_flush(d, s);
-        }
-        if (insert_len) {
-            mb += insert_len;
-            maybe_flush(d, s);
-        }
-        pf.tk[2] += TICK() - t0;
-        pf.tk[6] += insert_len;
-        if (mb == m.mlen) break; // :2069: the copy part of the last command is ignored
-
-        // ---- parse_distance_code :1367-1410
-        t0 = TICK();
-        u32 dcode;
-        if (implicit_zero) {
-            dcode = 0;
-        } else {
-            if ((rc = cat_tick(d, s, D, sw))) return rc;
-            u32 cid = copy_len >= 5u ? 3u : copy_len - 2u;
-            if (FAST) {
-                u32 ti = (rdl(f.CMDV, D.btype) >> (cid * 8u)) & 0xffu;
-                u32 idx; bool single;
-                u32 lk = fast_lookup(d, pick2(f.DH, ti >> 2), ti & 3u, idx, single);
-                if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
-                if (lk == LK_EOF) return ST_EOF;
-                if (single) dcode = idx;
-                else dcode = (rdl(pick2(f.DS, ti >> 2), (ti & 3u) * 16u + ((idx >> 2) & 15u)) >> ((idx & 3u) * 8u)) & 0xffu;
-            } else {
-                u32 ti = tm_u8(d, s, m.cmd + D.btype * 4u + cid);
-                u32 h = tm_u32(d, s, m.hd + ti);
-                u32 lk = decode_sym(d, s, h, dcode);
-                if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
-                if (lk == LK_EOF) return ST_EOF;
-            }
-        }
-        // ---- decode_distance :1412-1481
-        u32 distance, e;
-        if (dcode <= 3u) {
-            distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
-        } else if (dcode <= 15u) {
-            long long basev = dcode <= 9u ? (long long)d.dist0 : (long long)d.dist1;
-            long long delta = dcode <= 9u ? (long long)((dcode - 2u) >> 1) : (long long)((dcode - 8u) >> 1);
-            long long r = (dcode & 1u) ? basev + delta : basev - delta;
-            if (r <= 0) return ST_NON_POSITIVE_DISTANCE;
-            distance = (u32)r;
-        } else if (dcode <= 15u + m.ndirect) {
-            distance = dcode - 15u;
-        } else {
-            u32 x = dcode - m.ndirect - 16u;
-            u32 ndistbits = 1u + (x >> (m.npostfix + 1u));
-            if (!in_bits(d, ndistbits, e)) return ST_EOF;
-            u32 hcode = x >> m.npostfix;
-            u32 lcode = x & ((1u << m.npostfix) - 1u);
-            u32 offset = ((2u + (hcode & 1u)) << ndistbits) - 4u;
-            distance = ((offset + e) << m.npostfix) + lcode + m.ndirect + 1u;
-        }
-        const u32 max_allowed = d.pos < d.window ? d.pos : d.window;
-        if (dcode > 0u && distance <= max_allowed) { // :1476-1478
-            d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
-        }
-        pf.tk[3] += TICK() - t0;
-        t0 = TICK();
-        pf.tk[5] += 1;
-        // ---- copy_literals :1483-1542 (+ CopyLiterals state :2102-2141)
-        if (distance <= max_allowed) {
-            if (m.mlen < mb + copy_len) return ST_EXCEEDED_EXPECTED_BYTES; // :2105
-            if (!out_room(d, copy_len)) return ST_OUTPUT_TOO_SMALL;
-            mb += copy_len;
-            if (copy_len <= 64u && distance >= copy_len) {
-                // the common case, software pipelined: issue the source read (LDS ring or the stream's own
-                // HBM output), decode the NEXT command while the bytes are in flight, then land them.
-                const u32 cl = copy_len; // the lookahead below overwrites insert_len / copy_len / implicit_zero
-                const u32 lc = d.lane < cl ? d.lane : cl - 1u; // switched-off lanes redo the last byte
-                const u32 b = copy_fetch(d, s, distance, distance - (cl - 1u), distance - lc);
-                const bool more = mb != m.mlen;
-                if (more) BRX_DECODE_IAC();
-                ring_put(d, s, d.lane < cl, d.pos + d.lane + d.a, b);
-                d.pos += cl;
-                p1 = rdl(b, cl - 1u); // cl >= 2 always (copy length codes start at 2)
-                p2 = rdl(b, cl - 2u);
-                maybe_flush(d, s);
-                pf.tk[4] += TICK() - t0;
-                if (!more) break; // :2128
-                continue;
-            }
-            window_copy(d, s, distance, copy_len, p1, p2);
-        } else {
-            if (copy_len < 4u || copy_len > 24u) return ST_INVALID_DICT_LENGTH;
-            u32 wl, wb;
-            if ((rc = dict_word(d, copy_len, distance - max_allowed - 1u, wl, wb))) return rc;
-            if (m.mlen < mb + wl) return ST_EXCEEDED_EXPECTED_BYTES; // :2105 on the transformed length (Q4)
-            if (!out_room(d, wl)) return ST_OUTPUT_TOO_SMALL;
-            ring_put(d, s, d.lane < wl, d.pos + d.lane + d.a, wb);
-            d.pos += wl;
-            mb += wl;
-            if (wl >= 2u) { p1 = rdl(wb, wl - 1u); p2 = rdl(wb, wl - 2u); }
-            else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
-            maybe_flush(d, s);
-        }
-        pf.tk[4] += TICK() - t0;
-        if (mb == m.mlen) break; // :2128
-        t0 = TICK();
-        BRX_DECODE_IAC();
-        pf.tk[1] += TICK() - t0;
-    }
-#undef BRX_DECODE_IAC
-    return ST_OK;
-}
-
 // Meta-block header (reference states NBltypesL .. PrefixCodesDistances, src/lib.rs:1745-2002), out of line.
 // Input: decoder state in Lds::st.  Output: status; on ST_OK the header results sit in Lds::mbw and the
 // advanced input cursor / table-memory tops in Lds::st.
@@ -1668,7 +1427,7 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
             }
         }
         s.mbw[MBW_ASM] = ok;
-        s.pad[0] = why; s.pad[1] = d.lds_top; s.pad[2] = d.scr_top;
+        s.pad[8] = why; s.pad[9] = d.lds_top;
     }
     if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
     while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
@@ -1839,7 +1598,7 @@ __device__ __noinline__ u32 asm_commands() {
 #include "_gen/brx_hot_asm.h"
         :
         :
-        : "memory", "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+        : "memory", "vcc", "scc", "s4", "s5", "s6", "s7", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
           "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
           "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
@@ -1849,18 +1608,202 @@ __device__ __noinline__ u32 asm_commands() {
     return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
-// The table-memory command loop for meta-blocks too large for the register tables, out of line.
-__device__ __noinline__ u32 cold_commands() {
-    Lds &s = g_lds;
-    Dec d;
-    dec_load(d, s);
+// The table-memory command loop (reference states DataMetaBlockBegin .. CopyLiterals, src/lib.rs:2003-2141): every
+// meta-block shape -- any NPOSTFIX / NDIRECT, any number of trees and block types, tables in LDS or in the HBM spill
+// arena, exact end-of-input and capacity checks at every field.  Out of line.  It is also the safety net of the
+// assembly loop for meta-blocks beyond the register-table limits of hot_commands(): same modes, same resume points,
+// same parked state (see HC_* above).  Errors return at once (they are final); `mb_left` counts down like there.
+FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
     MB m;
     Cat L, I, D;
     mb_load(s, m, L, I, D);
     m.mlen = rfl(s.st[ST_MLEN]);
-    Prof pf;
-    pf.on = false;
-    u32 rc = command_loop<false>(d, s, m, L, I, D, pf);
+    u32 rc;
+    bool sw;
+    u32 cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
+    u32 mb_left = m.mlen;
+    u32 p1, p2;
+    ctx_bytes(d, s, p1, p2);
+    u32 insert_len = 0, copy_len = 0, implicit_zero = 0, distance = 0, dist_bad = 0;
+    u32 budget = (mode == HC_WHOLE || mode == HC_RESUME_R1_WHOLE) ? 0xffffffffu : mode == HC_START ? 0u : 1u;
+    const bool oneshot = mode >= HC_RESUME_R0 && mode <= HC_RESUME_R2;
+    u32 phase2 = mode == HC_RESUME_R2 ? 1u : 0u;
+    if (mode >= HC_RESUME_R0) {
+        mb_left = rfl(s.mbw[MBW_MBLEFT]);
+        insert_len = rfl(s.mbw[MBW_INS]); copy_len = rfl(s.mbw[MBW_CPY]); implicit_zero = rfl(s.mbw[MBW_IZ]);
+        distance = rfl(s.mbw[MBW_DIST]); dist_bad = rfl(s.mbw[MBW_DISTBAD]);
+    }
+    if (mode == HC_START) {
+        // Is this meta-block one for the assembly loop (preconditions in brx_hot.S)?
+        const u32 total = m.ntl + I.nbl + m.ntd;
+        u32 ok = (m.hl + total <= BRX_TM_WORDS && (u32)(uintptr_t)&g_lds == 0u && m.ntl <= 64u && m.ntd <= 64u &&
+                  m.cml + 64u * L.nbl <= TM_BYTES && m.cmd + 4u * D.nbl <= TM_BYTES && m.cmode_w * 4u + L.nbl <= TM_BYTES &&
+                  (u64)d.pos + m.mlen <= (u64)d.cap && d.bitend < (1ull << 31)) ? 1u : 0u;
+        for (u32 i = 0; i < total; i++) {
+            const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
+            if (h_ >= BRX_TM_WORDS - 16u) ok = 0u;
+            else {
+                const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
+                const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
+                if (kind_ != 2u && (iac_ || kind_ != 1u)) ok = 0u;
+                // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
+                // the left-aligned upper bound of its longest codes is then exactly 2^15
+                const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
+                const bool full_ = ballot((hvw_ & 0xffffu) == 0x8000u && (d.lane & 15u) != 0u) != 0ull;
+                if (kind_ == 2u && !full_) ok = 0u;
+            }
+        }
+        s.mbw[MBW_ASM] = ok;
+    }
+
+    // parse_insert_and_copy_length :1179-1208 + decode_insert_and_copy_length :1210-1224
+#define G_DECODE_IAC()                                                                     \
+    do {                                                                                   \
+        if (++d.wd > d.wd_limit) return ST_WATCHDOG;                                       \
+        if ((rc = cat_tick(d, s, I, sw))) return rc;                                       \
+        u32 sym_;                                                                          \
+        u32 lk_ = decode_sym(d, s, tm_u32(d, s, m.hi + I.btype), sym_);                    \
+        if (lk_ == LK_NONE) return ST_PARSE_IAC;                                           \
+        if (lk_ == LK_EOF) return ST_EOF;                                                  \
+        implicit_zero = sym_ < 128u ? 1u : 0u; /* :2012-2015 */                            \
+        u32 cell_ = sym_ >> 6;                                                             \
+        u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                  \
+        u32 coff_ = (u32)((0x21202101010ull >> (4u * cell_)) & 15u) * 8u;                  \
+        u32 pki_ = rdl(d.v_ic, ioff_ + ((sym_ >> 3) & 7u));                                \
+        u32 pkc_ = rdl(d.v_ic, 32u + coff_ + (sym_ & 7u));                                 \
+        u32 e_;                                                                            \
+        if (!in_bits(d, pki_ & 31u, e_)) return ST_EOF;                                    \
+        insert_len = (pki_ >> 5) + e_;                                                     \
+        if (!in_bits(d, pkc_ & 31u, e_)) return ST_EOF;                                    \
+        copy_len = (pkc_ >> 5) + e_;                                                       \
+    } while (0)
+#define G_END_OF_COMMAND() budget = (oneshot && (d.vfl & (BRX_FLUSH_BLOCK - 1u)) != 0u) ? budget : budget - 1u
+
+    if (mode <= HC_START || mode == HC_RESUME_R0) G_DECODE_IAC();
+    while (mb_left != 0u && budget != 0u) {
+        u32 max_allowed;
+        if (phase2 == 0u) {
+            if (insert_len > mb_left) return ST_EXCEEDED_EXPECTED_BYTES; // :2036 (Q4)
+            if (!out_room(d, insert_len)) return ST_OUTPUT_TOO_SMALL;
+            // ---- parse_insert_literals :1286-1365 (+ InsertLiterals state :2048-2081)
+            for (u32 k = 0; k < insert_len; k++) {
+                if ((rc = cat_tick(d, s, L, sw))) return rc;
+                if (sw) cmode = tm_u8(d, s, m.cmode_w * 4u + L.btype);
+                u32 cid;
+                if (cmode == 3u) cid = (lut8(d.v_lut2, p1) << 3) | lut8(d.v_lut2, p2);
+                else if (cmode == 2u) cid = lut8(d.v_lut0, p1) | lut8(d.v_lut1, p2);
+                else if (cmode == 0u) cid = p1 & 0x3fu;
+                else cid = p1 >> 2;
+                u32 lit;
+                const u32 ti = tm_u8(d, s, m.cml + L.btype * 64u + cid);
+                const u32 lk = decode_sym(d, s, tm_u32(d, s, m.hl + ti), lit);
+                if (lk == LK_NONE) return ST_PARSE_LITERALS;
+                if (lk == LK_EOF) return ST_EOF;
+                ring_put(d, s, d.lane == 0u, d.pos + d.a, lit);
+                d.pos++;
+                p2 = p1;
+                p1 = lit;
+                if (((d.pos + d.a) & 63u) == 0u) maybe_flush(d, s);
+            }
+            if (insert_len) {
+                mb_left -= insert_len;
+                maybe_flush(d, s);
+            }
+            if (mb_left == 0u) continue; // :2069: the copy part of the last command is ignored
+            // ---- parse_distance_code :1367-1410
+            u32 dcode = 0;
+            if (!implicit_zero) {
+                if ((rc = cat_tick(d, s, D, sw))) return rc;
+                const u32 cid = copy_len >= 5u ? 3u : copy_len - 2u;
+                const u32 ti = tm_u8(d, s, m.cmd + D.btype * 4u + cid);
+                const u32 lk = decode_sym(d, s, tm_u32(d, s, m.hd + ti), dcode);
+                if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
+                if (lk == LK_EOF) return ST_EOF;
+            }
+            // ---- decode_distance :1412-1481
+            if (dcode <= 3u) {
+                distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
+            } else if (dcode <= 15u) {
+                long long basev = dcode <= 9u ? (long long)d.dist0 : (long long)d.dist1;
+                long long delta = dcode <= 9u ? (long long)((dcode - 2u) >> 1) : (long long)((dcode - 8u) >> 1);
+                long long r = (dcode & 1u) ? basev + delta : basev - delta;
+                if (r <= 0) return ST_NON_POSITIVE_DISTANCE;
+                distance = (u32)r;
+            } else if (dcode <= 15u + m.ndirect) {
+                distance = dcode - 15u;
+            } else {
+                u32 e;
+                const u32 x = dcode - m.ndirect - 16u;
+                const u32 ndistbits = 1u + (x >> (m.npostfix + 1u));
+                if (!in_bits(d, ndistbits, e)) return ST_EOF;
+                const u32 hcode = x >> m.npostfix;
+                const u32 lcode = x & ((1u << m.npostfix) - 1u);
+                const u32 offset = ((2u + (hcode & 1u)) << ndistbits) - 4u;
+                distance = ((offset + e) << m.npostfix) + lcode + m.ndirect + 1u;
+            }
+            max_allowed = d.pos < d.window ? d.pos : d.window;
+            if (dcode > 0u && distance <= max_allowed) { // :1476-1478
+                d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
+            }
+        } else { // resumed at R2: the assembly loop decoded the distance (and updated the ring of last distances)
+            max_allowed = d.pos < d.window ? d.pos : d.window;
+            if (dist_bad) return ST_NON_POSITIVE_DISTANCE;
+        }
+        phase2 = 0u;
+        // ---- copy_literals :1483-1542 (+ CopyLiterals state :2102-2141)
+        if (distance <= max_allowed) {
+            if (copy_len > mb_left) return ST_EXCEEDED_EXPECTED_BYTES; // :2105
+            if (!out_room(d, copy_len)) return ST_OUTPUT_TOO_SMALL;
+            mb_left -= copy_len;
+            if (copy_len <= 64u && distance >= copy_len) {
+                // the common case, software pipelined: issue the source read (LDS ring or the stream's own
+                // HBM output), decode the NEXT command while the bytes are in flight, then land them.
+                const u32 cl = copy_len; // the lookahead below overwrites insert_len / copy_len / implicit_zero
+                const u32 lc = d.lane < cl ? d.lane : cl - 1u; // switched-off lanes redo the last byte
+                const u32 b = copy_fetch(d, s, distance, distance - (cl - 1u), distance - lc);
+                G_END_OF_COMMAND();
+                if (mb_left != 0u) G_DECODE_IAC();
+                ring_put(d, s, d.lane < cl, d.pos + d.lane + d.a, b);
+                d.pos += cl;
+                p1 = rdl(b, cl - 1u); // cl >= 2 always (copy length codes start at 2)
+                p2 = rdl(b, cl - 2u);
+                maybe_flush(d, s);
+                continue;
+            }
+            window_copy(d, s, distance, copy_len, p1, p2);
+        } else {
+            if (copy_len < 4u || copy_len > 24u) return ST_INVALID_DICT_LENGTH;
+            u32 wl, wb;
+            if ((rc = dict_word(d, copy_len, distance - max_allowed - 1u, wl, wb))) return rc;
+            if (wl > mb_left) return ST_EXCEEDED_EXPECTED_BYTES; // :2105 on the transformed length (Q4)
+            if (!out_room(d, wl)) return ST_OUTPUT_TOO_SMALL;
+            ring_put(d, s, d.lane < wl, d.pos + d.lane + d.a, wb);
+            d.pos += wl;
+            mb_left -= wl;
+            if (wl >= 2u) { p1 = rdl(wb, wl - 1u); p2 = rdl(wb, wl - 2u); }
+            else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
+            maybe_flush(d, s);
+        }
+        G_END_OF_COMMAND();
+        if (mb_left != 0u) G_DECODE_IAC(); // :2128 otherwise
+    }
+#undef G_DECODE_IAC
+#undef G_END_OF_COMMAND
+    rc = ST_OK;
+    if (mb_left != 0u) { // budget ran out: park at R1
+        s.mbw[MBW_MBLEFT] = mb_left; s.mbw[MBW_INS] = insert_len; s.mbw[MBW_CPY] = copy_len; s.mbw[MBW_IZ] = implicit_zero;
+        s.mbw[13] = L.btype; s.mbw[14] = L.btype_prev; s.mbw[15] = L.blen;
+        s.mbw[19] = I.btype; s.mbw[20] = I.btype_prev; s.mbw[21] = I.blen;
+        s.mbw[25] = D.btype; s.mbw[26] = D.btype_prev; s.mbw[27] = D.blen;
+        rc = HC_CONTINUE;
+    }
+    return rc;
+}
+__device__ __noinline__ u32 generic_commands(u32 mode_in) {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
+    const u32 rc = generic_body(d, s, rfl(mode_in)); // errors return from the middle: park the state here
     dec_store(d, s);
     return rc;
 }
@@ -2024,29 +1967,28 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
             if (st) break;
-            if (rfl(s.mbw[30]) == 0u) {
-                st = cold_commands();
-            } else if (a.debug_stop == 7u) { // bring-up: the re-entrant C++ loop alone, one command per call
-                st = hot_commands(HC_START);
-                while (st == HC_CONTINUE) st = hot_commands(HC_RESUME_R1);
-            } else if (a.debug_stop == 8u) { // bring-up: the C++ loop alone, whole meta-block per call
-                st = hot_commands(HC_WHOLE);
+            const bool fast = rfl(s.mbw[30]) != 0u; // register-table limits of hot_commands() hold
+            if (a.debug_stop == 8u) { // bring-up: the C++ loops alone, whole meta-block per call
+                st = fast ? hot_commands(HC_WHOLE) : generic_commands(HC_WHOLE);
+            } else if (a.debug_stop == 7u) { // bring-up: the C++ loops alone, one command per call
+                st = fast ? hot_commands(HC_START) : generic_commands(HC_START);
+                while (st == HC_CONTINUE) st = fast ? hot_commands(HC_RESUME_R1) : generic_commands(HC_RESUME_R1);
             } else {
-                // Assembly fast loop with the C++ loop as its safety net: the assembly runs until something unusual
+                // Assembly fast loop with a C++ loop as its safety net: the assembly runs until something unusual
                 // comes up, C++ takes exactly one command (or finishes the meta-block), and so on.
-                st = hot_commands(HC_START);
-                if (st == HC_CONTINUE && rfl(s.mbw[MBW_ASM]) == 0u) st = hot_commands(HC_RESUME_R1_WHOLE);
+                st = fast ? hot_commands(HC_START) : generic_commands(HC_START);
+                const bool use_asm = rfl(s.mbw[MBW_ASM]) != 0u;
+                if (prof_on && lane == 0u) s.pad[use_asm ? 2 : fast ? 1 : 0]++;
+                if (st == HC_CONTINUE && !use_asm)
+                    st = fast ? hot_commands(HC_RESUME_R1_WHOLE) : generic_commands(HC_RESUME_R1_WHOLE);
                 while (st == HC_CONTINUE) {
                     const u32 r = asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                         s.pad[3] += s.mbw[39];
-                        if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) {
-                            for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
-                            s.pad[15] = s.st[10]; s.pad[7] = s.st[3];
-                        }
                     }
-                    st = hot_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
+                    const u32 md = HC_RESUME_R0 + (r > 2u ? 1u : r);
+                    st = fast ? hot_commands(md) : generic_commands(md);
                 }
             }
             if (st) break;
