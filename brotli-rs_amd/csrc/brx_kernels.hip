@@ -1406,29 +1406,6 @@ __device__ __noinline__ u32 hot_commands(u32 mode_in) {
     if (I.blen == 0xffffffffu) I.blen = 0x7fffffffu;
     if (D.blen == 0xffffffffu) D.blen = 0x7fffffffu;
 
-    if (mode == HC_START) {
-        // Is this meta-block one for the assembly loop (see the preconditions in brx_hot.S)?  The fast-path limits hold
-        // already; what remains: the handle table and every tree in LDS, every tree a general code.
-        const u32 total = m.ntl + I.nbl + m.ntd;
-        u32 ok = (m.hl + total <= BRX_TM_WORDS && (u32)(uintptr_t)&g_lds == 0u) ? 1u : 0u;
-        u32 why = ok ? 0u : 1u;
-        for (u32 i = 0; i < total; i++) {
-            const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
-            if (h_ >= BRX_TM_WORDS - 16u) { ok = 0u; why |= 2u | (i << 8); }
-            else {
-                const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
-                const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
-                if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u | (i << 16); }
-                // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
-                // the left-aligned upper bound of its longest codes is then exactly 2^15
-                const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
-                const bool full_ = ballot((hvw_ & 0xffffu) == 0x8000u && (d.lane & 15u) != 0u) != 0ull;
-                if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
-            }
-        }
-        s.mbw[MBW_ASM] = ok;
-        s.pad[8] = why; s.pad[9] = d.lds_top;
-    }
     if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
     while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
       u32 max_allowed;
@@ -1971,12 +1948,13 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             if (a.debug_stop == 8u) { // bring-up: the C++ loops alone, whole meta-block per call
                 st = fast ? hot_commands(HC_WHOLE) : generic_commands(HC_WHOLE);
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loops alone, one command per call
-                st = fast ? hot_commands(HC_START) : generic_commands(HC_START);
+                st = generic_commands(HC_START);
                 while (st == HC_CONTINUE) st = fast ? hot_commands(HC_RESUME_R1) : generic_commands(HC_RESUME_R1);
             } else {
                 // Assembly fast loop with a C++ loop as its safety net: the assembly runs until something unusual
                 // comes up, C++ takes exactly one command (or finishes the meta-block), and so on.
-                st = fast ? hot_commands(HC_START) : generic_commands(HC_START);
+                // first insert&copy symbol + the eligibility test, with exact end-of-input rules
+                st = generic_commands(HC_START);
                 const bool use_asm = rfl(s.mbw[MBW_ASM]) != 0u;
                 if (prof_on && lane == 0u) s.pad[use_asm ? 2 : fast ? 1 : 0]++;
                 if (st == HC_CONTINUE && !use_asm)
@@ -1988,7 +1966,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                         s.pad[3] += s.mbw[39];
                     }
                     const u32 md = HC_RESUME_R0 + (r > 2u ? 1u : r);
-                    st = fast ? hot_commands(md) : generic_commands(md);
+                    st = generic_commands(md);
                 }
             }
             if (st) break;
