@@ -59,7 +59,6 @@ struct __attribute__((aligned(16))) Lds {
 __shared__ Lds g_lds;
 
 #define FI __device__ __attribute__((always_inline)) inline
-#define TICK() (pf.on ? (u64)__builtin_readcyclecounter() : 0ull)
 
 // ---- wave-level primitives ---------------------------------------------------------------------------
 FI u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -123,10 +122,6 @@ struct Dec {
     const u32 *t_lut; // Lut0 | Lut1 | Lut2 as dwords
 };
 
-struct Prof { // bring-up profiling (BRX_DEBUG_STATS=1): cycle totals per section of the command loop
-    u64 tk[8];
-    bool on;
-};
 
 // ---- table memory: LDS first, HBM spill beyond ---------------------------------------------------------
 // An object lives entirely in LDS (word address < BRX_TM_WORDS) or entirely in the HBM spill arena.  The
@@ -254,7 +249,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_MLEN 35    // its MLEN
 #define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
-// hot_commands modes / return value, and the Lds::mbw slots that carry a parked command
+// generic_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
 #define HC_START 1u      // first insert&copy symbol only, then park at R1
 #define HC_RESUME_R0 2u  // resume: insert&copy symbol due; one command, park
@@ -904,109 +899,6 @@ struct MB { // per-meta-block scalars the command loop needs
     u32 mlen, npostfix, ndirect, cmode_w, cml, cmd, hl, hi, hd, ntl, ntd;
 };
 
-// Register-resident decode tables (FAST path): every table the command loop touches lives in VGPRs, one
-// entry per lane, and is read with v_readlane -- no LDS round trip on the serial symbol chain.
-//   *H : prefix-code headers, 4 trees per VGPR (lane = 16*(tree&3) + L)
-//   LS : literal symbols, u8 x4 per lane (256 per tree)
-//   DS : distance symbols, u8 x4 per lane, 4 trees per VGPR (lane = 16*(tree&3) + idx/4; alphabet <= 64)
-//   IS : insert&copy symbols of the CURRENT block type, u16 x2 per lane, 6 VGPRs (704 symbols); reloaded
-//        from table memory on the (rare) insert&copy block switch
-//   CMROW: literal context-map row of the current block type (64 B); CMDV: whole distance context map
-struct Fast { // named scalars, NOT arrays: any array here ends up in scratch memory (the compiler turns
-              // "i ? a[1] : a[0]" into a load from a computed stack address)
-    u32 LH0, LH1, LS0, LS1, LS2, LS3, LS4, LS5, LS6, LS7, DH0, DH1, DS0, DS1, IH, IS0, IS1, IS2, IS3, IS4, IS5, CMROW, CMDV;
-};
-
-FI u32 sel2(u32 a0, u32 a1, u32 i) { return (i & 1u) ? a1 : a0; }
-FI u32 sel8(u32 a0, u32 a1, u32 a2, u32 a3, u32 a4, u32 a5, u32 a6, u32 a7, u32 i) {
-    u32 x0 = (i & 1u) ? a1 : a0, x1 = (i & 1u) ? a3 : a2, x2 = (i & 1u) ? a5 : a4, x3 = (i & 1u) ? a7 : a6;
-    u32 y0 = (i & 2u) ? x1 : x0, y1 = (i & 2u) ? x3 : x2;
-    return (i & 4u) ? y1 : y0;
-}
-FI u32 pick2(const u32 (&a)[2], u32 i) { return i ? a[1] : a[0]; }
-FI u32 pick8(const u32 (&a)[8], u32 i) {
-    u32 x0 = (i & 1u) ? a[1] : a[0], x1 = (i & 1u) ? a[3] : a[2], x2 = (i & 1u) ? a[5] : a[4], x3 = (i & 1u) ? a[7] : a[6];
-    u32 y0 = (i & 2u) ? x1 : x0, y1 = (i & 2u) ? x3 : x2;
-    return (i & 4u) ? y1 : y0;
-}
-
-// Load one tree's header + symbols from table memory (LDS, or the HBM spill arena when the LDS part was
-// full -- the trees are only needed until they sit in registers) into the register tables.
-template <bool INL> FI void fast_load_hdr_as(const Dec &d, const Lds &s, u32 h, u32 t, u32 &hv4) {
-    u32 w = tm_ld32<INL>(d, s, h + (d.lane & 15u));
-    u32 mask = 0u - (u32)((d.lane >> 4) == (t & 3u)); // bitwise select: guaranteed branch-free
-    hv4 = (w & mask) | (hv4 & ~mask);
-}
-FI void fast_load_hdr(const Dec &d, const Lds &s, u32 h, u32 t, u32 &hv4) {
-    if (h < BRX_TM_WORDS) fast_load_hdr_as<true>(d, s, h, t, hv4); else fast_load_hdr_as<false>(d, s, h, t, hv4);
-}
-template <bool INL> FI u32 fast_load_sym8_as(const Dec &d, const Lds &s, u32 h) { // symbols as bytes, 4 per lane
-    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
-    u32 i = d.lane * 2u; // word index into the u16 symbol list: words i, i+1 hold symbols 4*lane .. 4*lane+3
-    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u; // clamp + select: no per-lane branch (see in_load_chunk)
-    u32 w0 = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
-    u32 w1 = tm_ld32<INL>(d, s, h + 16u + (i + 1u < last ? i + 1u : last));
-    w0 = (2u * i < nnz) ? w0 : 0u;
-    w1 = (2u * i + 2u < nnz) ? w1 : 0u;
-    return (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 << 8) & 0xff000000u);
-}
-FI u32 fast_load_sym8(const Dec &d, const Lds &s, u32 h) {
-    return h < BRX_TM_WORDS ? fast_load_sym8_as<true>(d, s, h) : fast_load_sym8_as<false>(d, s, h);
-}
-// same, but every 16-lane quarter holds symbols 0..63 (lane&15 indexes the group of four)
-template <bool INL> FI u32 fast_load_sym8_q_as(const Dec &d, const Lds &s, u32 h) {
-    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
-    u32 i = (d.lane & 15u) * 2u;
-    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u;
-    u32 w0 = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
-    u32 w1 = tm_ld32<INL>(d, s, h + 16u + (i + 1u < last ? i + 1u : last));
-    w0 = (2u * i < nnz) ? w0 : 0u;
-    w1 = (2u * i + 2u < nnz) ? w1 : 0u;
-    return (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 << 8) & 0xff000000u);
-}
-FI u32 fast_load_sym8_q(const Dec &d, const Lds &s, u32 h) {
-    return h < BRX_TM_WORDS ? fast_load_sym8_q_as<true>(d, s, h) : fast_load_sym8_q_as<false>(d, s, h);
-}
-template <bool INL> FI u32 fast_load_sym16_as(const Dec &d, const Lds &s, u32 h, u32 k) { // u16 x2 per lane
-    u32 nnz = rfl(tm_ld32<INL>(d, s, h)) >> 16;
-    u32 i = k * 64u + d.lane;
-    const u32 last = nnz ? (nnz - 1u) >> 1 : 0u;
-    u32 w = tm_ld32<INL>(d, s, h + 16u + (i < last ? i : last));
-    return (2u * i < nnz) ? w : 0u;
-}
-FI u32 fast_load_sym16(const Dec &d, const Lds &s, u32 h, u32 k) {
-    return h < BRX_TM_WORDS ? fast_load_sym16_as<true>(d, s, h, k) : fast_load_sym16_as<false>(d, s, h, k);
-}
-
-// Core of the ballot decode against a 4-trees-per-VGPR header vector.  Returns LK_*; on LK_OK either
-// `single` (kind 1: symbol in idx, zero bits, Q5) or idx = position in the sorted symbol list, L bits taken.
-FI u32 fast_lookup(Dec &d, u32 hv4, u32 slot, u32 &idx, bool &single) {
-    u32 h0 = rdl(hv4, slot * 16u);
-    u32 kind = h0 & 3u;
-    single = false;
-    if (kind != 2u) {
-        if (kind == 0u) return LK_NONE;
-        idx = h0 >> 16;
-        single = true;
-        return LK_OK;
-    }
-    u64 rem = in_remaining(d);
-    u32 peek = in_peek_raw(d) & 0x7fffu;
-    if (rem < 15u) peek &= (1u << (u32)rem) - 1u;
-    u32 v = __brev(peek) >> 17;
-    u32 m = (u32)(ballot(v < (hv4 & 0xffffu)) >> (slot * 16u)) & 0xfffeu;
-    if (m == 0u) {
-        u32 maxlen = (h0 >> 8) & 0xffu;
-        return rem >= (u64)(maxlen + 1u) ? LK_NONE : LK_EOF;
-    }
-    u32 L = (u32)__builtin_ctz(m);
-    if ((u64)L > rem) return LK_EOF;
-    u32 base = rdl(hv4, slot * 16u + L) >> 16;
-    idx = ((v >> (15u - L)) + base) & 0xffffu;
-    in_consume(d, L);
-    return LK_OK;
-}
-
 // Meta-block header (reference states NBltypesL .. PrefixCodesDistances, src/lib.rs:1745-2002), out of line.
 // Input: decoder state in Lds::st.  Output: status; on ST_OK the header results sit in Lds::mbw and the
 // advanced input cursor / table-memory tops in Lds::st.
@@ -1130,13 +1022,6 @@ __device__ __noinline__ u32 cold_header() {
         w[12] = L.nbl; w[13] = L.btype; w[14] = L.btype_prev; w[15] = L.blen; w[16] = L.h_types; w[17] = L.h_counts;
         w[18] = I.nbl; w[19] = I.btype; w[20] = I.btype_prev; w[21] = I.blen; w[22] = I.h_types; w[23] = I.h_counts;
         w[24] = D.nbl; w[25] = D.btype; w[26] = D.btype_prev; w[27] = D.blen; w[28] = D.h_types; w[29] = D.h_counts;
-        // Register-resident tables when the meta-block is small enough (the common case).  The trees themselves
-        // may sit in the HBM spill arena (they are copied into registers once); what the loop keeps reading
-        // from LDS are the context maps and context modes, allocated first.
-        const u32 mlen_ = s.st[ST_MLEN];
-        w[30] = (ntl <= 8u && ntd <= 8u && I.nbl <= 4u && dalpha <= 64u && D.nbl <= 64u &&
-                 cml + 64u * L.nbl <= TM_BYTES && cmd + 4u * D.nbl <= TM_BYTES &&
-                 (u64)d.pos + mlen_ <= (u64)d.cap && d.bitend < (1ull << 31)) ? 1u : 0u;
     }
     dec_store(d, s);
     return ST_OK;
@@ -1149,423 +1034,6 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
     L.nbl = rfl(w[12]); L.btype = rfl(w[13]); L.btype_prev = rfl(w[14]); L.blen = rfl(w[15]); L.h_types = rfl(w[16]); L.h_counts = rfl(w[17]);
     I.nbl = rfl(w[18]); I.btype = rfl(w[19]); I.btype_prev = rfl(w[20]); I.blen = rfl(w[21]); I.h_types = rfl(w[22]); I.h_counts = rfl(w[23]);
     D.nbl = rfl(w[24]); D.btype = rfl(w[25]); D.btype_prev = rfl(w[26]); D.blen = rfl(w[27]); D.h_types = rfl(w[28]); D.h_counts = rfl(w[29]);
-}
-
-// ---- the hot command loop ------------------------------------------------------------------------------------
-// Next input dword for the hot loop: `wl` is the lane of chunkA that holds it.  Common path = one v_readlane;
-// every 64 dwords the second staged chunk moves up and a new one is requested (one coalesced 256-B load).
-FI u32 in_next_word(Dec &d, u32 &wl) {
-    u32 w = rdl(d.chunkA, wl & 63u);
-    wl++;
-    if (wl == 64u) {
-        d.chunkA = d.chunkB;
-        d.cbase += 64u;
-        d.chunkB = in_load_chunk(d, d.cbase + 64u);
-        wl = 0;
-    }
-    return w;
-}
-FI u32 lutb(u32 vec, u32 b) { return (rdl(vec, b >> 2) >> ((b & 3u) * 8u)) & 0xffu; }
-
-// Literal context id = A[p1] | B[p2] for every context mode (reference src/lib.rs:1317-1341, tables spec 7.1):
-// mode 0 (LSB6): A = p & 63, B = 0; 1 (MSB6): A = p >> 2, B = 0; 2 (UTF8): A = Lut0, B = Lut1;
-// 3 (signed): A = Lut2 << 3, B = Lut2.  A and B live 4 bytes per lane in two VGPRs.
-FI void ctx_vectors(const Dec &d, u32 cmode, u32 &VA, u32 &VB) {
-    u32 a0 = ((d.lane * 4u) & 0x3fu) * 0x01010101u + 0x03020100u;
-    u32 a1 = d.lane * 0x01010101u;
-    u32 a3 = (d.v_lut2 & 0x1f1f1f1fu) << 3;
-    VA = cmode == 0u ? a0 : cmode == 1u ? a1 : cmode == 2u ? d.v_lut0 : a3;
-    VB = cmode == 2u ? d.v_lut1 : cmode == 3u ? d.v_lut2 : 0u;
-}
-
-// The register-table command loop: THE hot function (reference states DataMetaBlockBegin .. CopyLiterals,
-// src/lib.rs:2003-2141).  Lean on purpose: 32-bit state, one pending copy in flight, end-of-input detected lazily.
-//   * `left` = input bits remaining, signed.  Fields are taken without an end check; running past the end makes
-//     `left` negative and every exit (error or not) tests that FIRST and reports UnexpectedEOF -- exactly what the
-//     reference reports at the read that crossed the end, because that read precedes any later finding.
-//   * a copy of <= 64 non-overlapping bytes is issued (LDS ring read, or buffer_load of the stream's own HBM
-//     output for back-references older than the ring) and stays PENDING while the next command is decoded; it
-//     lands in the ring when its bytes are needed (literal context, an overlapping source, the next far copy).
-// Preconditions established by cold_header (mbw[30]): <= 8 literal / distance trees, <= 4 insert&copy block
-// types, NPOSTFIX = NDIRECT = 0, pos + MLEN <= capacity, input < 2^28 bytes.
-__device__ __noinline__ u32 hot_commands(u32 mode_in) {
-    Lds &s = g_lds;
-    Dec d;
-    dec_load(d, s);
-    MB m;
-    Cat L, I, D;
-    mb_load(s, m, L, I, D);
-    m.mlen = rfl(s.st[ST_MLEN]);
-    const u32 mode = rfl(mode_in);
-
-    // ---- register tables
-    Fast f;
-    u32 lit_single = 0, dist_single = 0, iac_single = 0; // bit t: tree t has ONE symbol (zero-bit code, Q5)
-    f.LH0 = f.LH1 = f.DH0 = f.DH1 = f.DS0 = f.DS1 = f.IH = 0;
-#define H_LOAD_LIT(T, LHX, LSX)                                                        \
-    do {                                                                               \
-        LSX = 0;                                                                       \
-        if ((T) < m.ntl) {                                                             \
-            u32 h_ = tm_u32(d, s, m.hl + (T));                                         \
-            fast_load_hdr(d, s, h_, (T), LHX);                                         \
-            LSX = fast_load_sym8(d, s, h_);                                            \
-            lit_single |= ((tm_u32(d, s, h_) & 3u) == 1u ? 1u : 0u) << (T);            \
-        }                                                                              \
-    } while (0)
-#define H_LOAD_DIST(T, DHX, DSX)                                                       \
-    do {                                                                               \
-        if ((T) < m.ntd) {                                                             \
-            u32 h_ = tm_u32(d, s, m.hd + (T));                                         \
-            fast_load_hdr(d, s, h_, (T), DHX);                                         \
-            u32 w_ = fast_load_sym8_q(d, s, h_);                                       \
-            u32 mask_ = 0u - (u32)((d.lane >> 4) == ((T)&3u));                         \
-            DSX = (w_ & mask_) | (DSX & ~mask_);                                       \
-            dist_single |= ((tm_u32(d, s, h_) & 3u) == 1u ? 1u : 0u) << (T);           \
-        }                                                                              \
-    } while (0)
-#define H_LOAD_IAC_HDR(T)                                                              \
-    do {                                                                               \
-        if ((T) < I.nbl) {                                                             \
-            u32 h_ = tm_u32(d, s, m.hi + (T));                                         \
-            fast_load_hdr(d, s, h_, (T), f.IH);                                        \
-            iac_single |= ((tm_u32(d, s, h_) & 3u) == 1u ? 1u : 0u) << (T);            \
-        }                                                                              \
-    } while (0)
-#define H_LOAD_IS(H)                                                                   \
-    do {                                                                               \
-        f.IS0 = fast_load_sym16(d, s, (H), 0); f.IS1 = fast_load_sym16(d, s, (H), 1);  \
-        f.IS2 = fast_load_sym16(d, s, (H), 2); f.IS3 = fast_load_sym16(d, s, (H), 3);  \
-        f.IS4 = fast_load_sym16(d, s, (H), 4); f.IS5 = fast_load_sym16(d, s, (H), 5);  \
-    } while (0)
-    H_LOAD_LIT(0u, f.LH0, f.LS0); H_LOAD_LIT(1u, f.LH0, f.LS1); H_LOAD_LIT(2u, f.LH0, f.LS2); H_LOAD_LIT(3u, f.LH0, f.LS3);
-    H_LOAD_LIT(4u, f.LH1, f.LS4); H_LOAD_LIT(5u, f.LH1, f.LS5); H_LOAD_LIT(6u, f.LH1, f.LS6); H_LOAD_LIT(7u, f.LH1, f.LS7);
-    H_LOAD_DIST(0u, f.DH0, f.DS0); H_LOAD_DIST(1u, f.DH0, f.DS0); H_LOAD_DIST(2u, f.DH0, f.DS0); H_LOAD_DIST(3u, f.DH0, f.DS0);
-    H_LOAD_DIST(4u, f.DH1, f.DS1); H_LOAD_DIST(5u, f.DH1, f.DS1); H_LOAD_DIST(6u, f.DH1, f.DS1); H_LOAD_DIST(7u, f.DH1, f.DS1);
-    H_LOAD_IAC_HDR(0u); H_LOAD_IAC_HDR(1u); H_LOAD_IAC_HDR(2u); H_LOAD_IAC_HDR(3u);
-    H_LOAD_IS(tm_u32(d, s, m.hi + I.btype));
-    f.CMROW = s.tm[(m.cml >> 2) + L.btype * 16u + (d.lane & 15u)];
-    f.CMDV = s.tm[(m.cmd >> 2) + (d.lane < D.nbl ? d.lane : D.nbl - 1u)];
-    u32 VA, VB;
-    ctx_vectors(d, tm_u8(d, s, m.cmode_w * 4u + L.btype), VA, VB);
-    u8 *const lds_bytes = (u8 *)&s; // the ring is the first member: ring byte i == lds_bytes[i]
-    const u32 trash_off = (u32)__builtin_offsetof(Lds, trash) + d.lane; // per-lane dump byte
-
-    // ---- scalar state
-    u32 boff = (u32)d.bitpos & 31u;            // bit offset inside the 64-bit window d.win (dwords d.ww, d.ww+1)
-    u32 wl = d.ww + 2u - d.cbase;              // lane of chunkA holding the next dword to enter the window
-    while (wl >= 64u) { // dec_load staged [cbase, cbase+128): make chunkA the chunk that holds that dword
-        d.chunkA = d.chunkB;
-        d.cbase += 64u;
-        d.chunkB = in_load_chunk(d, d.cbase + 64u);
-        wl -= 64u;
-    }
-    int left = (int)(d.bitend - d.bitpos);     // input bits remaining (may go negative: lazy EOF)
-    u32 mb_left = m.mlen;                      // bytes of this meta-block still to produce
-    u32 p1, p2;
-    ctx_bytes(d, s, p1, p2);
-    u32 pend_n = 0, pend_b = 0;                // pending copy: pend_n bytes (lanes 0..n-1 of pend_b) belong at
-                                               // ring positions [pos - pend_n, pos)
-    u32 insert_len = 0, copy_len = 0, implicit_zero = 0;
-    u32 rc = ST_OK;
-    // Re-entry (the assembly fast loop hands single commands back, see brx_hot.S): resume points
-    //   R0 = an insert&copy symbol is due, R1 = loop top (insert_len / copy_len / implicit_zero valid),
-    //   R2 = the distance of the current command is known (ring of last distances already updated).
-    u32 budget = (mode == HC_WHOLE || mode == HC_RESUME_R1_WHOLE) ? 0xffffffffu : mode == HC_START ? 0u : 1u; // commands before parking
-    // one-command calls keep going while the flush cursor is ragged (first KiB of a stream with an unaligned output
-    // pointer): the assembly loop only flushes whole aligned blocks
-    const bool oneshot = mode >= HC_RESUME_R0 && mode <= HC_RESUME_R2;
-    u32 phase2 = mode == HC_RESUME_R2 ? 1u : 0u;
-    u32 distance = 0, dist_bad = 0;
-    if (mode >= HC_RESUME_R0) {
-        mb_left = rfl(s.mbw[MBW_MBLEFT]);
-        insert_len = rfl(s.mbw[MBW_INS]); copy_len = rfl(s.mbw[MBW_CPY]); implicit_zero = rfl(s.mbw[MBW_IZ]);
-        distance = rfl(s.mbw[MBW_DIST]); dist_bad = rfl(s.mbw[MBW_DISTBAD]);
-    }
-
-#define H_PEEK() ((u32)(d.win >> boff))
-#define H_TAKE(n)                                                                      \
-    do {                                                                               \
-        boff += (n);                                                                   \
-        left -= (int)(n);                                                              \
-        if (boff >= 32u) {                                                             \
-            boff -= 32u;                                                               \
-            d.win = (d.win >> 32) | ((u64)in_next_word(d, wl) << 32);                  \
-        }                                                                              \
-    } while (0)
-    // Errors are STICKY instead of jumping out: the first one is recorded in rc, the loop counters are zeroed and
-    // the code runs on (harmlessly: every index is masked) to the single exit test of each loop.  Loops with
-    // several exits get "unified" by the AMDGPU backend into chains of flag registers and re-branches, which
-    // tripled the scalar instruction count of this function.
-#define H_FAIL(code)                                                                   \
-    do {                                                                               \
-        if (rc == 0u) rc = left < 0 ? (u32)ST_EOF : (u32)(code);                       \
-        mb_left = 0;                                                                   \
-    } while (0)
-    // Land the pending copy in the ring and refresh the literal context from it.
-#define H_LAND()                                                                       \
-    do {                                                                               \
-        if (pend_n) {                                                                  \
-            u32 dst_ = (d.pos - pend_n + d.a + d.lane) & RMASK;                        \
-            u32 off_ = d.lane < pend_n ? dst_ : trash_off;                             \
-            lds_bytes[off_] = (u8)pend_b;                                              \
-            p1 = rdl(pend_b, (pend_n - 1u) & 63u);                                     \
-            p2 = rdl(pend_b, (pend_n - 2u) & 63u);                                     \
-            pend_n = 0;                                                                \
-        }                                                                              \
-    } while (0)
-    // Hand the lean bit cursor to / from the generic (Dec-based) helpers used on the rare paths.
-#define H_SYNC_OUT() do { d.bitpos = d.bitend - (u64)(u32)left; d.ww = (u32)(d.bitpos >> 5); } while (0)
-#define H_SYNC_IN()                                                                    \
-    do {                                                                               \
-        left = (int)(d.bitend - d.bitpos);                                             \
-        boff = (u32)d.bitpos & 31u;                                                    \
-        /* the generic reader may have shifted the staged chunks: re-derive the lane cursor */ \
-        while (d.ww + 2u >= d.cbase + 64u) {                                           \
-            d.chunkA = d.chunkB;                                                       \
-            d.cbase += 64u;                                                            \
-            d.chunkB = in_load_chunk(d, d.cbase + 64u);                                \
-        }                                                                              \
-        wl = d.ww + 2u - d.cbase;                                                      \
-    } while (0)
-    // Rare: block switch of category C through the generic table-memory decoder (needs real bits: left >= 0).
-#define H_SWITCH(C)                                                                    \
-    do {                                                                               \
-        if (left < 0) {                                                                \
-            H_FAIL(ST_EOF);                                                            \
-        } else {                                                                       \
-            H_SYNC_OUT();                                                              \
-            bool sw_;                                                                  \
-            u32 e_ = cat_tick(d, s, C, sw_);                                           \
-            if (e_) { if (rc == 0u) rc = e_; mb_left = 0; }                            \
-            H_SYNC_IN();                                                               \
-            if (C.blen == 0xffffffffu) C.blen = 0x7fffffffu;                           \
-        }                                                                              \
-    } while (0)
-    // One prefix-code symbol through a 4-trees-per-VGPR header vector (see fast_lookup): idx_out = position in
-    // the tree's sorted symbol list.  Not found (incomplete code, Q15) -> the reference's None / EOF split.
-#define H_LOOKUP(hv, slot16, idx_out, none_code)                                       \
-    do {                                                                               \
-        u32 v_ = __brev(H_PEEK() & 0x7fffu) >> 17;                                     \
-        u32 m_ = (u32)(ballot(v_ < ((hv)&0xffffu)) >> (slot16)) & 0xfffeu;             \
-        if (m_ == 0u) {                                                                \
-            u32 maxlen_ = (rdl((hv), (slot16)) >> 8) & 0xffu;                          \
-            if (rc == 0u) rc = left >= (int)(maxlen_ + 1u) ? (u32)(none_code) : (u32)ST_EOF; \
-            mb_left = 0;                                                               \
-            m_ = 2u;                                                                   \
-        }                                                                              \
-        u32 L_ = (u32)__builtin_ctz(m_);                                               \
-        u32 base_ = rdl((hv), ((slot16) + L_) & 63u) >> 16;                            \
-        idx_out = ((v_ >> (15u - L_)) + base_) & 0xffffu;                              \
-        H_TAKE(L_);                                                                    \
-    } while (0)
-    // parse_insert_and_copy_length + decode_insert_and_copy_length (src/lib.rs:1179-1224)
-#define H_DECODE_IAC()                                                                 \
-    do {                                                                               \
-        if (I.blen == 0u) { /* block switch, rare */                                   \
-            H_SWITCH(I);                                                               \
-            u32 hh_ = tm_u32(d, s, m.hi + (I.btype & 3u));                             \
-            H_LOAD_IS(hh_);                                                            \
-        } else {                                                                       \
-            I.blen--;                                                                  \
-        }                                                                              \
-        u32 sym_;                                                                      \
-        const u32 isl_ = (I.btype & 3u) * 16u;                                         \
-        if ((iac_single >> (I.btype & 3u)) & 1u) {                                     \
-            sym_ = rdl(f.IH, isl_) >> 16;                                              \
-        } else {                                                                       \
-            u32 idx_;                                                                  \
-            H_LOOKUP(f.IH, isl_, idx_, ST_PARSE_IAC);                                  \
-            u32 w_;                                                                    \
-            switch ((idx_ >> 7) & 7u) {                                                \
-            case 0: w_ = rdl(f.IS0, (idx_ >> 1) & 63u); break;                        \
-            case 1: w_ = rdl(f.IS1, (idx_ >> 1) & 63u); break;                        \
-            case 2: w_ = rdl(f.IS2, (idx_ >> 1) & 63u); break;                        \
-            case 3: w_ = rdl(f.IS3, (idx_ >> 1) & 63u); break;                        \
-            case 4: w_ = rdl(f.IS4, (idx_ >> 1) & 63u); break;                       \
-            default: w_ = rdl(f.IS5, (idx_ >> 1) & 63u); break;                      \
-            }                                                                          \
-            sym_ = (w_ >> ((idx_ & 1u) * 16u)) & 0xffffu;                              \
-        }                                                                              \
-        if (sym_ > 703u) sym_ = 703u; /* only reachable after a sticky error */        \
-        implicit_zero = sym_ < 128u ? 1u : 0u; /* :2012-2015 */                        \
-        u32 cell_ = sym_ >> 6;                                                         \
-        u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;              \
-        u32 coff_ = (u32)((0x21202101010ull >> (4u * cell_)) & 15u) * 8u;              \
-        u32 pki_ = rdl(d.v_ic, ioff_ + ((sym_ >> 3) & 7u));                            \
-        u32 pkc_ = rdl(d.v_ic, 32u + coff_ + (sym_ & 7u));                             \
-        u32 ni_ = pki_ & 31u, nc_ = pkc_ & 31u;                                        \
-        insert_len = (pki_ >> 5) + (H_PEEK() & ((1u << ni_) - 1u));                    \
-        H_TAKE(ni_);                                                                   \
-        copy_len = (pkc_ >> 5) + (H_PEEK() & ((1u << nc_) - 1u));                      \
-        H_TAKE(nc_);                                                                   \
-    } while (0)
-
-    // A block category with one type never switches: give it an inexhaustible count (Q12).
-    // cat_tick semantics ("Some(0) -> switch, Some(n) -> n-1") with blen = symbols left BEFORE a switch is due.
-    if (L.blen == 0xffffffffu) L.blen = 0x7fffffffu;
-    if (I.blen == 0xffffffffu) I.blen = 0x7fffffffu;
-    if (D.blen == 0xffffffffu) D.blen = 0x7fffffffu;
-
-    if (mode <= HC_START || mode == HC_RESUME_R0) H_DECODE_IAC();
-    while (mb_left != 0u && budget != 0u) { // single exit: errors zero mb_left
-      u32 max_allowed;
-      if (phase2 == 0u) {
-        if (left < 0) { H_FAIL(ST_EOF); continue; }
-        if (insert_len > mb_left) { H_FAIL(ST_EXCEEDED_EXPECTED_BYTES); continue; } // :2036 (Q4)
-        // ---- parse_insert_literals :1286-1365
-        if (insert_len) {
-            H_LAND(); // the context of the first literal may be the tail of the pending copy
-            mb_left -= insert_len;
-            u32 bval = lutb(VB, p2);
-            for (u32 k = insert_len; k; k--) {
-                if (L.blen == 0u) { // literal block switch, rare
-                    H_SWITCH(L);
-                    f.CMROW = s.tm[(m.cml >> 2) + (L.btype & 255u) * 16u + (d.lane & 15u)];
-                    ctx_vectors(d, tm_u8(d, s, m.cmode_w * 4u + (L.btype & 255u)), VA, VB);
-                    bval = lutb(VB, p2);
-                } else {
-                    L.blen--;
-                }
-                const u32 cid = (lutb(VA, p1) | bval) & 63u;
-                const u32 ti = lutb(f.CMROW, cid) & 7u;
-                const u32 hv = sel2(f.LH0, f.LH1, ti >> 2);
-                const u32 sl = (ti & 3u) * 16u;
-                u32 lit;
-                if ((lit_single >> ti) & 1u) {
-                    lit = (rdl(hv, sl) >> 16) & 0xffu;
-                } else {
-                    u32 idx;
-                    H_LOOKUP(hv, sl, idx, ST_PARSE_LITERALS);
-                    lit = (rdl(sel8(f.LS0, f.LS1, f.LS2, f.LS3, f.LS4, f.LS5, f.LS6, f.LS7, ti), (idx >> 2) & 63u) >> ((idx & 3u) * 8u)) & 0xffu;
-                }
-                lds_bytes[d.lane == 0u ? ((d.pos + d.a) & RMASK) : trash_off] = (u8)lit;
-                d.pos++;
-                bval = lutb(VB, p1); // = B[p2] of the next literal
-                p2 = p1;
-                p1 = lit;
-                if (((d.pos + d.a) & 63u) == 0u) {
-                    maybe_flush(d, s);
-                    if (left < 0) H_FAIL(ST_EOF); // bound the work done on bits past the end
-                }
-                if (rc) k = 1u; // sticky error: leave through the loop's own exit
-            }
-            maybe_flush(d, s);
-        }
-        if (mb_left == 0u) continue; // :2069: the copy part of the last command is ignored (or an error is pending)
-
-        // ---- parse_distance_code :1367-1410 + decode_distance :1412-1481 (NPOSTFIX = NDIRECT = 0 here)
-        u32 dcode = 0;
-        if (!implicit_zero) {
-            if (D.blen == 0u) H_SWITCH(D); else D.blen--;
-            const u32 cidd = copy_len >= 5u ? 3u : (copy_len - 2u) & 3u;
-            const u32 ti = (rdl(f.CMDV, D.btype & 63u) >> (cidd * 8u)) & 7u;
-            const u32 hv = sel2(f.DH0, f.DH1, ti >> 2);
-            const u32 sl = (ti & 3u) * 16u;
-            if ((dist_single >> ti) & 1u) {
-                dcode = (rdl(hv, sl) >> 16) & 0xffu;
-            } else {
-                u32 idx;
-                H_LOOKUP(hv, sl, idx, ST_PARSE_DISTANCE_CODE);
-                dcode = (rdl(sel2(f.DS0, f.DS1, ti >> 2), sl + ((idx >> 2) & 15u)) >> ((idx & 3u) * 8u)) & 0xffu;
-            }
-        }
-        if (dcode <= 3u) {
-            distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
-        } else if (dcode <= 15u) {
-            int basev = (int)(dcode <= 9u ? d.dist0 : d.dist1); // distances < 2^25: int is enough
-            int delta = (int)(dcode <= 9u ? (dcode - 2u) >> 1 : (dcode - 8u) >> 1);
-            int r = (dcode & 1u) ? basev + delta : basev - delta;
-            if (r <= 0) { H_FAIL(ST_NON_POSITIVE_DISTANCE); r = 1; }
-            distance = (u32)r;
-        } else {
-            const u32 x = (dcode - 16u) & 63u;
-            const u32 nd = 1u + (x >> 1);
-            const u32 e = H_PEEK() & ((1u << nd) - 1u);
-            H_TAKE(nd);
-            distance = (((2u + (x & 1u)) << nd) - 4u) + e + 1u;
-        }
-        max_allowed = d.pos < d.window ? d.pos : d.window;
-        if (dcode > 0u && distance <= max_allowed) { // :1476-1478
-            d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
-        }
-      } else { // resumed at R2
-        max_allowed = d.pos < d.window ? d.pos : d.window;
-        if (dist_bad) { H_FAIL(ST_NON_POSITIVE_DISTANCE); distance = 1u; }
-      }
-        phase2 = 0u;
-        if (mb_left == 0u) continue; // an error was recorded while decoding the distance
-        // ---- copy_literals :1483-1542
-        if (distance <= max_allowed && copy_len <= 64u && distance >= copy_len) {
-            // common case: <= 64 non-overlapping bytes, kept pending while the next command is decoded
-            if (copy_len > mb_left) { H_FAIL(ST_EXCEEDED_EXPECTED_BYTES); continue; } // :2105
-            const bool far = distance > BRX_RING_BYTES;
-            if (pend_n && (far || distance < pend_n + copy_len)) H_LAND(); // one load in flight; sources must be final
-            const u32 lc = d.lane < copy_len ? d.lane : copy_len - 1u;     // switched-off lanes redo the last byte
-            u32 b;
-            if (!far) b = s.ring[(d.pos - distance + lc + d.a) & RMASK];
-            else if (distance - (copy_len - 1u) > BRX_RING_BYTES)
-                b = __builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, d.pos - distance + lc, 0, 0);
-            else b = copy_fetch(d, s, distance, distance - (copy_len - 1u), distance - lc);
-            H_LAND(); // an older pending copy that did not conflict lands now, in order
-            pend_b = b;
-            pend_n = copy_len;
-            d.pos += copy_len;
-            mb_left -= copy_len;
-            budget = (oneshot && (d.vfl & (BRX_FLUSH_BLOCK - 1u)) != 0u) ? budget : budget - 1u;
-            if (mb_left != 0u) H_DECODE_IAC(); // lookahead (:2128 otherwise): overlaps the fetch above
-            // the block being flushed ends >= BRX_FLUSH_LAG bytes behind the cursor: never the pending bytes
-            if (d.pos + d.a >= (d.vfl & ~(BRX_FLUSH_BLOCK - 1u)) + BRX_FLUSH_BLOCK + BRX_FLUSH_LAG) maybe_flush(d, s);
-            continue;
-        }
-        H_LAND();
-        if (distance <= max_allowed) { // long or overlapping window copy
-            if (copy_len > mb_left) { H_FAIL(ST_EXCEEDED_EXPECTED_BYTES); continue; }
-            mb_left -= copy_len;
-            window_copy(d, s, distance, copy_len, p1, p2);
-        } else { // static dictionary
-            if (copy_len < 4u || copy_len > 24u) { H_FAIL(ST_INVALID_DICT_LENGTH); continue; }
-            if (left < 0) { H_FAIL(ST_EOF); continue; }
-            u32 wl = 0, wb = 0;
-            u32 e_ = dict_word(d, copy_len, distance - max_allowed - 1u, wl, wb);
-            if (e_) { if (rc == 0u) rc = e_; mb_left = 0; continue; }
-            if (wl > mb_left) { H_FAIL(ST_EXCEEDED_EXPECTED_BYTES); continue; } // :2105 on the transformed length (Q4)
-            lds_bytes[d.lane < wl ? ((d.pos + d.lane + d.a) & RMASK) : trash_off] = (u8)wb;
-            d.pos += wl;
-            mb_left -= wl;
-            if (wl >= 2u) { p1 = rdl(wb, wl - 1u); p2 = rdl(wb, wl - 2u); }
-            else if (wl == 1u) { p2 = p1; p1 = rdl(wb, 0); }
-            maybe_flush(d, s);
-        }
-        budget = (oneshot && (d.vfl & (BRX_FLUSH_BLOCK - 1u)) != 0u) ? budget : budget - 1u;
-        if (mb_left != 0u) H_DECODE_IAC(); // :2128 otherwise
-    }
-    H_LAND();
-    maybe_flush(d, s);
-    const bool parked = mb_left != 0u; // budget ran out (no error: errors zero mb_left): park at R1
-    if (!parked && rc == 0u && left < 0) rc = ST_EOF;
-    if (rc == 0u) H_SYNC_OUT();
-    if (parked) {
-        s.mbw[MBW_MBLEFT] = mb_left; s.mbw[MBW_INS] = insert_len; s.mbw[MBW_CPY] = copy_len; s.mbw[MBW_IZ] = implicit_zero;
-        s.mbw[13] = L.btype; s.mbw[14] = L.btype_prev; s.mbw[15] = L.blen;
-        s.mbw[19] = I.btype; s.mbw[20] = I.btype_prev; s.mbw[21] = I.blen;
-        s.mbw[25] = D.btype; s.mbw[26] = D.btype_prev; s.mbw[27] = D.blen;
-        rc = HC_CONTINUE;
-    }
-#undef H_LOAD_LIT
-#undef H_LOAD_DIST
-#undef H_LOAD_IAC_HDR
-#undef H_LOAD_IS
-#undef H_PEEK
-#undef H_TAKE
-#undef H_FAIL
-#undef H_LAND
-#undef H_SYNC_OUT
-#undef H_SYNC_IN
-#undef H_SWITCH
-#undef H_LOOKUP
-#undef H_DECODE_IAC
-    dec_store(d, s);
-    return rc;
 }
 
 // The assembly command loop (brx_hot.S).  No operands: it reads and writes the parked state in LDS and returns the
@@ -1588,8 +1056,8 @@ __device__ __noinline__ u32 asm_commands() {
 // The table-memory command loop (reference states DataMetaBlockBegin .. CopyLiterals, src/lib.rs:2003-2141): every
 // meta-block shape -- any NPOSTFIX / NDIRECT, any number of trees and block types, tables in LDS or in the HBM spill
 // arena, exact end-of-input and capacity checks at every field.  Out of line.  It is also the safety net of the
-// assembly loop for meta-blocks beyond the register-table limits of hot_commands(): same modes, same resume points,
-// same parked state (see HC_* above).  Errors return at once (they are final); `mb_left` counts down like there.
+// assembly loop (modes and resume points: HC_* above; a parked command travels in Lds::mbw).  Errors return at once
+// (they are final).
 FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
     MB m;
     Cat L, I, D;
@@ -1944,29 +1412,27 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
             if (st) break;
-            const bool fast = rfl(s.mbw[30]) != 0u; // register-table limits of hot_commands() hold
-            if (a.debug_stop == 8u) { // bring-up: the C++ loops alone, whole meta-block per call
-                st = fast ? hot_commands(HC_WHOLE) : generic_commands(HC_WHOLE);
-            } else if (a.debug_stop == 7u) { // bring-up: the C++ loops alone, one command per call
+            if (a.debug_stop == 8u) { // bring-up: the C++ loop alone, whole meta-block per call
+                st = generic_commands(HC_WHOLE);
+            } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
                 st = generic_commands(HC_START);
-                while (st == HC_CONTINUE) st = fast ? hot_commands(HC_RESUME_R1) : generic_commands(HC_RESUME_R1);
+                while (st == HC_CONTINUE) st = generic_commands(HC_RESUME_R1);
             } else {
-                // Assembly fast loop with a C++ loop as its safety net: the assembly runs until something unusual
-                // comes up, C++ takes exactly one command (or finishes the meta-block), and so on.
-                // first insert&copy symbol + the eligibility test, with exact end-of-input rules
+                // The assembly loop (brx_hot.S) with the C++ loop as its safety net.  The C++ side reads the first
+                // insert&copy symbol (exact end-of-input rules) and decides whether the meta-block qualifies; then
+                // the assembly runs until something unusual comes up, C++ takes exactly one command (or finishes
+                // the meta-block), and so on.
                 st = generic_commands(HC_START);
                 const bool use_asm = rfl(s.mbw[MBW_ASM]) != 0u;
-                if (prof_on && lane == 0u) s.pad[use_asm ? 2 : fast ? 1 : 0]++;
-                if (st == HC_CONTINUE && !use_asm)
-                    st = fast ? hot_commands(HC_RESUME_R1_WHOLE) : generic_commands(HC_RESUME_R1_WHOLE);
+                if (prof_on && lane == 0u) s.pad[use_asm ? 2 : 0]++;
+                if (st == HC_CONTINUE && !use_asm) st = generic_commands(HC_RESUME_R1_WHOLE);
                 while (st == HC_CONTINUE) {
                     const u32 r = asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                         s.pad[3] += s.mbw[39];
                     }
-                    const u32 md = HC_RESUME_R0 + (r > 2u ? 1u : r);
-                    st = generic_commands(md);
+                    st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
                 }
             }
             if (st) break;
