@@ -16,6 +16,7 @@ for fn in re.split(r"UniformityInfo for function ", txt)[1:]:
     for b in blocks[1:]:
         phis=[l for l in b.split("\n") if " = phi " in l]
         if best is None or len(phis)>len(best[1]): best=(b.split("\n")[0],phis)
+    if best is None: print('%-45s (no blocks)' % name); continue
     div=[l for l in best[1] if l.strip().startswith("DIVERGENT")]
     tot=sum(1 for l in fn.split("\n") if " br i1 " in l); dv=sum(1 for l in fn.split("\n") if " br i1 " in l and "DIVERGENT" in l)
     print("%-45s biggest loop header BLOCK %s: %d phis, %d divergent; branches %d, divergent %d"%(name,best[0],len(best[1]),len(div),tot,dv))
