@@ -26,8 +26,8 @@ struct BrxDeviceTables {
     const uint8_t *dict;        // 122784 B, spec Appendix A
     const uint8_t *context_lut; // Lut0 | Lut1 | Lut2, 3 x 256 B
     const BrxTransform *xforms; // 121 entries
-    const uint32_t *iac;        // insert&copy symbol table for the assembly loop (brx_hot.S): 704 x {insert base |
-                                // extra bits << 16, copy base | extra bits << 16}, then 64 dwords DOFFSET | NDBITS << 24
+    const uint32_t *iac;        // insert&copy symbol table for the assembly loop (brx_hot.S): 704 x {insert base,
+                                // extra bits, copy base, extra bits}, then 64 dwords DOFFSET | NDBITS << 24
 };
 
 struct BrxKernelArgs {

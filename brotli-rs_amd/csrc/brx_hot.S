@@ -26,10 +26,7 @@
 #define LDS_MBW 9920
 #define RMASK 4095
 
-// ---- SGPRs
-#define WIN s[36:37]
-#define WINLO s36
-#define NAV s38
+// ---- SGPRs (s36-s38: scratch during entry)
 #define WL s39
 #define MAXA s40
 #define WLSTOP s41
@@ -106,25 +103,46 @@
 #define VT3 v21
 #define VT4 v22
 #define VPENB v23
+#define VR v24
+#define VU v25
+#define VBASE v26
+#define VI v27
+#define VIACL v28
+#define VIACB v29
+#define VE v30
+#define VLIM v31
+#define VWIN v[32:33]
+#define VWINLO v32
+#define VWINHI v33
+#define VNAV v34
+#define VRF v[36:37]
+#define VRFLO v36
+#define VRFHI v37
 
-// Bits are taken from the low end of WIN; NAV = number of valid bits in it (>= 32 after a REFILL_CHECK).
+// The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
+// ALU issues one instruction per SIMD every 4 cycles and is the bottleneck of this loop (profiles/r01g_pmc.csv), the
+// vector ALU is mostly idle.  Bits are taken from the low end of VWIN; VNAV = number of valid bits (>= 32 after a
+// REFILL_CHECK).  Only values that steer control flow or index lanes are moved to SGPRs (v_readfirstlane).
 .macro TAKE n
-    s_lshr_b64 WIN, WIN, \n
-    s_sub_u32 NAV, NAV, \n
+    v_lshrrev_b64 VWIN, \n, VWIN
+    v_subrev_u32 VNAV, \n, VNAV
 .endm
 .macro REFILL_CHECK id
-    s_cmp_lt_u32 NAV, 32
-    s_cbranch_scc1 .Lrf_stub_\id
+    v_cmp_gt_u32 vcc, 32, VNAV
+    s_cbranch_vccnz .Lrf_stub_\id
 .Lrf_back_\id:
 .endm
 // Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
 .macro REFILL_STUB id
 .Lrf_stub_\id:
     v_readlane_b32 T0, VCHA, WL
-    s_mov_b32 T1, 0
-    s_lshl_b64 T01, T01, NAV
-    s_or_b64 WIN, WIN, T01
-    s_add_u32 NAV, NAV, 32
+    v_mov_b32 VRFHI, 0
+    s_nop 1                                             // gfx940+: VALU-written SGPR read by a VALU: 2 wait states
+    v_mov_b32 VRFLO, T0
+    v_lshlrev_b64 VRF, VNAV, VRF
+    v_or_b32 VWINLO, VWINLO, VRFLO
+    v_or_b32 VWINHI, VWINHI, VRFHI
+    v_add_u32 VNAV, 32, VNAV
     s_add_u32 WL, WL, 1
     s_cmp_lg_u32 WL, WLSTOP
     s_cbranch_scc1 .Lrf_back_\id
@@ -138,22 +156,25 @@
     s_lshl_b32 T6, \b, 3
     s_lshr_b32 \dst, T7, T6
 .endm
-// Canonical prefix-code lookup.  hv = per-lane header words of the tree (lane L: limit[L] | base[L] << 16).
-// Out: CLEN = code length, T4 = index into the tree's sorted symbol list.  Clobbers T0-T3, VT3, vcc.
+// Canonical prefix-code lookup.  lim / base = per-lane limit[L] and base[L] of the tree (lane L, L = 1..15).
+// Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
 // Every code is complete (precondition), so some lane always matches.
-.macro LOOKUP hv
-    s_brev_b32 T0, WINLO
-    s_lshr_b32 T1, T0, 17
-    v_and_b32 VT3, 0xffff, \hv
-    v_cmp_lt_u32 vcc, T1, VT3
+.macro LOOKUP lim, base
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 17, VR
+    v_cmp_lt_u32 vcc, VU, \lim
     s_and_b32 T2, vcc_lo, 0xfffe
     s_ff1_i32_b32 CLEN, T2
-    v_readlane_b32 T3, \hv, CLEN
+    v_readlane_b32 T3, \base, CLEN
     s_sub_u32 T2, 32, CLEN
-    s_lshr_b32 T2, T0, T2
-    s_lshr_b32 T3, T3, 16
-    s_add_u32 T4, T2, T3
-    s_and_b32 T4, T4, 0xffff
+    v_lshrrev_b32 VI, T2, VR                            // (two instructions between the v_readlane and its VALU reader)
+    v_add_u32 VI, T3, VI
+    v_and_b32 VI, 0xffff, VI
+.endm
+// limit / base vectors of a tree whose header words (limit | base << 16) were just read into \hv
+.macro SPLIT_HV hv
+    v_and_b32 VLIM, 0xffff, \hv
+    v_lshrrev_b32 VBASE, 16, \hv
 .endm
 
 // Wait for the pending copy's bytes.  With -DBRX_ASM_PROF the cycles spent in this wait are summed into s97 and
@@ -240,7 +261,7 @@
     global_load_dword v28, VT0, s[88:89]                // Lut0
     global_load_dword v29, VT0, s[88:89] offset:256     // Lut1
     global_load_dword v30, VT0, s[88:89] offset:512     // Lut2
-    v_add_u32 VT1, 5632, VT0
+    v_add_u32 VT1, 11264, VT0
     global_load_dword VDICTINFO, VT1, IACTAB
     // meta-block words
     ds_read_b128 v[20:23], VZERO offset:LDS_MBW+0       // npostfix, ndirect, cmode_w, cml
@@ -358,8 +379,14 @@
     // bit window
     v_readlane_b32 s36, VCHA, 0
     v_readlane_b32 s37, VCHA, 1
-    s_lshr_b64 WIN, WIN, T3
-    s_sub_u32 NAV, 64, T3
+    s_lshr_b64 s[36:37], s[36:37], T3
+    s_sub_u32 s38, 64, T3
+    v_mov_b32 VWINLO, s36
+    v_mov_b32 VWINHI, s37
+    v_mov_b32 VNAV, s38
+    s_waitcnt lgkmcnt(0)                                // VHVIAC
+    v_and_b32 VIACL, 0xffff, VHVIAC
+    v_lshrrev_b32 VIACB, 16, VHVIAC
     s_mov_b32 WL, 2
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
@@ -403,32 +430,27 @@
 .Lcmd:
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
-    LOOKUP VHVIAC
-    s_lshl1_add_u32 T4, T4, HISYM
-    v_mov_b32 VT0, T4
+    LOOKUP VIACL, VIACB
+    v_lshl_add_u32 VT0, VI, 1, HISYM
     ds_read_u16 VT0, VT0
     TAKE CLEN
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 T0, VT0                         // insert&copy symbol
     s_cmp_lt_u32 T0, 128
     s_cselect_b32 IZ, 1, 0
-    s_lshl_b32 T0, T0, 3
-    s_load_dwordx2 s[92:93], IACTAB, T0
+    s_lshl_b32 T0, T0, 4
+    s_load_dwordx4 s[92:95], IACTAB, T0                 // insert base, extra bits, copy base, extra bits
     REFILL_CHECK 1
     s_waitcnt lgkmcnt(0)
-    s_lshr_b32 T2, s92, 16
-    s_and_b32 INS, s92, 0xffff
-    s_bfm_b32 T3, T2, 0
-    s_and_b32 T3, WINLO, T3
-    s_add_u32 INS, INS, T3
-    TAKE T2
+    v_bfe_u32 VE, VWINLO, 0, s93
+    v_add_u32 VE, s92, VE
+    TAKE s93                                            // (gfx940+: a VALU result needs 1 wait state before v_readfirstlane)
+    v_readfirstlane_b32 INS, VE
     REFILL_CHECK 2
-    s_lshr_b32 T2, s93, 16
-    s_and_b32 CPY, s93, 0xffff
-    s_bfm_b32 T3, T2, 0
-    s_and_b32 T3, WINLO, T3
-    s_add_u32 CPY, CPY, T3
-    TAKE T2
+    v_bfe_u32 VE, VWINLO, 0, s95
+    v_add_u32 VE, s94, VE
+    TAKE s95
+    v_readfirstlane_b32 CPY, VE
     REFILL_CHECK 3
 
 // ======================================================================================================== R1
@@ -453,9 +475,9 @@
     v_add_u32 VT0, T5, VLANE4
     ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP VT1
-    s_lshl1_add_u32 T4, T4, T5
-    v_mov_b32 VT0, T4
+    SPLIT_HV VT1
+    LOOKUP VLIM, VBASE
+    v_lshl_add_u32 VT0, VI, 1, T5
     ds_read_u16 VT2, VT0 offset:64
     TAKE CLEN
 .Llit_have:
@@ -494,9 +516,9 @@
     v_add_u32 VT0, T5, VLANE4
     ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP VT1
-    s_lshl1_add_u32 T4, T4, T5
-    v_mov_b32 VT0, T4
+    SPLIT_HV VT1
+    LOOKUP VLIM, VBASE
+    v_lshl_add_u32 VT0, VI, 1, T5
     ds_read_u16 VT2, VT0 offset:64
     TAKE CLEN
     REFILL_CHECK 5
@@ -518,13 +540,13 @@
     s_add_u32 T2, T2, 2
     s_lshl_b32 T2, T2, T1
     s_sub_u32 T2, T2, 4                                 // offset
-    s_bfm_b32 T4, T1, 0
-    s_and_b32 T4, WINLO, T4
+    v_bfe_u32 VE, VWINLO, 0, T1
+    TAKE T1
+    v_readfirstlane_b32 T4, VE
     s_add_u32 T2, T2, T4
     s_lshl_b32 T2, T2, NPOST
     s_add_u32 T2, T2, T3
     s_add_u32 DIST, T2, NDIRECT1
-    TAKE T1
     REFILL_CHECK 6
     s_branch .Ldist_push
 .Ldist_direct:
@@ -791,7 +813,8 @@
     // bit cursor: 32 * (CBASE + WL) - NAV
     s_add_u32 T0, CBASE, WL
     s_lshl_b32 T0, T0, 5
-    s_sub_u32 T0, T0, NAV
+    v_readfirstlane_b32 T1, VNAV
+    s_sub_u32 T0, T0, T1
     v_mov_b32 VT0, T0
     v_mov_b32 VT1, 0
     ds_write_b32 VZERO, VT0 offset:LDS_ST+12            // bitpos (st[3], st[4])

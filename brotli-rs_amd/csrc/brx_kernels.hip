@@ -1049,7 +1049,7 @@ __device__ __noinline__ u32 asm_commands() {
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
           "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
-          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37");
     return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
@@ -1431,6 +1431,10 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                         s.pad[3] += s.mbw[39];
+                        if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) { // first exit: the parked command
+                            for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
+                            s.pad[15] = s.st[10]; s.pad[7] = s.st[3];
+                        }
                     }
                     st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
                 }
