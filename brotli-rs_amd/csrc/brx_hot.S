@@ -25,6 +25,10 @@
 #define LDS_ST 9728
 #define LDS_MBW 9920
 #define RMASK 4095
+// the code-length scratch area (Lds::lens, 768 B) is free during the command loop: context tables live there
+#define LDS_ATAB 8960
+#define LDS_BTAB 9216
+#define LDS_CMH 9472
 
 // ---- SGPRs (s36-s38: scratch during entry)
 #define WL s39
@@ -53,7 +57,6 @@
 #define IBLEN s66
 #define DBLEN s67
 #define P1 s68
-#define BVAL s69
 #define PENDN s70
 #define HISYM s71
 #define CMDW s72
@@ -81,6 +84,8 @@
 #define NDIRECT s5
 #define POSTMASK s6
 #define NDIRECT1 s7
+#define NDIR16 s8
+#define NPOST1 s9
 // ---- VGPRs
 #define VZERO v0
 #define VLANE v1
@@ -90,7 +95,6 @@
 #define VCHB v5
 #define VVA v6
 #define VVB v7
-#define VCMROW v8
 #define VLHOFF v9
 #define VDHOFF v10
 #define VHVIAC v11
@@ -118,6 +122,16 @@
 #define VRF v[36:37]
 #define VRFLO v36
 #define VRFHI v37
+#define VA1 v38
+#define VB1 v39
+#define VB2 v40
+#define VC v41
+#define VH v42
+#define VX v43
+#define VN v44
+#define VHH v45
+#define VLC v46
+#define VDH4 v47
 
 // The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
 // ALU issues one instruction per SIMD every 4 cycles and is the bottleneck of this loop (profiles/r01g_pmc.csv), the
@@ -148,13 +162,6 @@
     s_cbranch_scc1 .Lrf_back_\id
     s_call_b64 LINKA, .Lspecial
     s_branch .Lrf_back_\id
-.endm
-// byte b of a 256-entry byte table held 4 per lane in VGPR vec -> dst (garbage above bit 7 is left in place)
-.macro LUTB dst, vec, b
-    s_lshr_b32 T6, \b, 2
-    v_readlane_b32 T7, \vec, T6
-    s_lshl_b32 T6, \b, 3
-    s_lshr_b32 \dst, T7, T6
 .endm
 // Canonical prefix-code lookup.  lim / base = per-lane limit[L] and base[L] of the tree (lane L, L = 1..15).
 // Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
@@ -334,8 +341,8 @@
     // literal context map row of the current block type (64 bytes, lanes 0..15), distance map word, context mode
     s_lshl_b32 T6, s95, 6
     s_add_u32 T1, T1, T6
-    v_add_u32 VT0, T1, VLANE4
-    ds_read_b32 VCMROW, VT0 offset:LDS_TM
+    v_add_u32 VT0, T1, VLANE
+    ds_read_u8 VT4, VT0 offset:LDS_TM                   // lane c: tree index of context id c
     s_lshl_b32 T6, DCODE, 2
     s_add_u32 T2, T2, T6
     v_mov_b32 VT0, T2
@@ -348,6 +355,18 @@
     v_readfirstlane_b32 T7, VT1                         // h of the insert&copy tree
     v_readfirstlane_b32 CMDW, VT2
     v_readfirstlane_b32 T0, VT3                         // context mode
+    // CMH[c] = descriptor of the literal tree of context id c; VDH4 lane k = descriptor of the distance tree of
+    // distance context k (both for the current block types; a block switch leaves the loop and re-enters here)
+    v_lshlrev_b32 VT4, 2, VT4
+    ds_bpermute_b32 VT4, VT4, VLHOFF
+    v_lshlrev_b32 VT3, 3, VLANE
+    v_lshrrev_b32 VT3, VT3, CMDW
+    v_and_b32 VT3, 0xff, VT3
+    v_lshlrev_b32 VT3, 2, VT3
+    ds_bpermute_b32 VDH4, VT3, VDHOFF
+    v_lshlrev_b32 VT3, 2, VLANE
+    s_waitcnt lgkmcnt(0)
+    ds_write_b32 VT3, VT4 offset:LDS_CMH
     s_lshl_b32 T7, T7, 2
     s_add_u32 T7, T7, LDS_TM
     s_add_u32 HISYM, T7, 64
@@ -376,6 +395,9 @@
     v_lshlrev_b32 VVA, 3, VVA
     v_mov_b32 VVB, v30
 .Lcm_not3:
+    v_lshlrev_b32 VT0, 2, VLANE
+    ds_write_b32 VT0, VVA offset:LDS_ATAB
+    ds_write_b32 VT0, VVB offset:LDS_BTAB
     // bit window
     v_readlane_b32 s36, VCHA, 0
     v_readlane_b32 s37, VCHA, 1
@@ -393,6 +415,8 @@
     s_min_u32 WLSTOP, T0, 64
     s_bfm_b32 POSTMASK, NPOST, 0
     s_add_u32 NDIRECT1, NDIRECT, 1
+    s_add_u32 NDIR16, NDIRECT, 16
+    s_add_u32 NPOST1, NPOST, 1
     s_mov_b32 PENDN, 0
     s_mov_b32 FLAGS, 0
     s_mov_b32 EXITC, 1
@@ -417,7 +441,11 @@
     s_cselect_b32 P1, P1, 0
     s_cmp_ge_u32 POS, 2
     s_cselect_b32 T5, T5, 0
-    LUTB BVAL, VVB, T5
+    v_mov_b32 VT0, P1
+    v_mov_b32 VT3, T5
+    ds_read_u8 VA1, VT0 offset:LDS_ATAB                 // A[p1]
+    ds_read_u8 VB1, VT0 offset:LDS_BTAB                 // B[p1] (becomes B[p2] after the next literal)
+    ds_read_u8 VB2, VT3 offset:LDS_BTAB                 // B[p2]
     // not enough input left for the fast loop, or ragged flush cursor: hand straight back
     s_cmp_lt_u32 WLSTOP, 3
     s_cbranch_scc1 .Lexit
@@ -464,31 +492,33 @@
 .Llit:
     s_sub_u32 LBLEN, LBLEN, 1
     s_cbranch_scc1 .Lx_lit_switch
-    // context id -> tree
-    LUTB T0, VVA, P1
-    s_or_b32 T0, T0, BVAL
-    s_and_b32 T0, T0, 63
-    LUTB T1, VCMROW, T0                                 // v_readlane uses bits 5:0 of the lane select only
-    v_readlane_b32 T5, VLHOFF, T1
-    s_cmp_lt_i32 T5, 0
-    s_cbranch_scc1 .Llit_single
-    v_add_u32 VT0, T5, VLANE4
+    // context id -> tree descriptor, all on the vector side: (A[p1] | B[p2]) & 63 indexes CMH
+    s_waitcnt lgkmcnt(0)
+    v_or_b32 VC, VA1, VB2
+    v_and_b32 VC, 63, VC
+    v_lshlrev_b32 VC, 2, VC
+    ds_read_b32 VH, VC offset:LDS_CMH
+    s_waitcnt lgkmcnt(0)
+    v_cmp_gt_i32 vcc, 0, VH
+    s_cbranch_vccnz .Llit_single
+    v_add_u32 VT0, VH, VLANE4
     ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
     SPLIT_HV VT1
     LOOKUP VLIM, VBASE
-    v_lshl_add_u32 VT0, VI, 1, T5
+    v_lshl_add_u32 VT0, VI, 1, VH
     ds_read_u16 VT2, VT0 offset:64
     TAKE CLEN
 .Llit_have:
-    s_add_u32 T0, POS, SKEW
-    s_and_b32 T0, T0, RMASK
-    v_mov_b32 VT0, T0
-    LUTB BVAL, VVB, P1                                  // B[p2] of the next literal
+    v_mov_b32 VT0, POS
+    v_add_u32 VT0, SKEW, VT0
+    v_and_b32 VT0, RMASK, VT0
+    v_mov_b32 VB2, VB1                                  // B[p2] of the next literal
     s_add_u32 POS, POS, 1
     s_waitcnt lgkmcnt(0)
     ds_write_b8 VT0, VT2
-    v_readfirstlane_b32 P1, VT2
+    ds_read_u8 VA1, VT2 offset:LDS_ATAB
+    ds_read_u8 VB1, VT2 offset:LDS_BTAB
     s_cmp_ge_u32 POS, FLUSHAT
     s_cbranch_scc1 .Lflush_stub_lit
 .Lflush_back_lit:
@@ -507,10 +537,8 @@
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
     s_sub_u32 T0, CPY, 2
-    s_min_u32 T0, T0, 3
-    s_lshl_b32 T0, T0, 3
-    s_lshr_b32 T0, CMDW, T0
-    v_readlane_b32 T5, VDHOFF, T0
+    s_min_u32 T0, T0, 3                                 // distance context
+    v_readlane_b32 T5, VDH4, T0
     s_cmp_lt_i32 T5, 0
     s_cbranch_scc1 .Ldist_single
     v_add_u32 VT0, T5, VLANE4
@@ -523,39 +551,38 @@
     TAKE CLEN
     REFILL_CHECK 5
     s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 DCODE, VT2
-.Ldist_have:
-    s_cmp_lt_u32 DCODE, 16
-    s_cbranch_scc1 .Ldist_ring
-    // distance codes >= 16 (decode_distance :1412-1481)
-    s_sub_u32 T0, DCODE, 16
-    s_sub_u32 T0, T0, NDIRECT
-    s_cbranch_scc1 .Ldist_direct                        // 16 <= code < 16 + NDIRECT
-    s_add_u32 T2, NPOST, 1
-    s_lshr_b32 T1, T0, T2
-    s_add_u32 T1, T1, 1                                 // extra bits
-    s_lshr_b32 T2, T0, NPOST                            // hcode
-    s_and_b32 T3, T0, POSTMASK                          // lcode
-    s_and_b32 T2, T2, 1
-    s_add_u32 T2, T2, 2
-    s_lshl_b32 T2, T2, T1
-    s_sub_u32 T2, T2, 4                                 // offset
-    v_bfe_u32 VE, VWINLO, 0, T1
-    TAKE T1
-    v_readfirstlane_b32 T4, VE
-    s_add_u32 T2, T2, T4
-    s_lshl_b32 T2, T2, NPOST
-    s_add_u32 T2, T2, T3
-    s_add_u32 DIST, T2, NDIRECT1
+.Ldist_have:                                            // VT2 = distance code (decode_distance :1412-1481)
+    v_cmp_gt_u32 vcc, 16, VT2
+    s_cbranch_vccnz .Ldist_ring
+    v_cmp_gt_u32 vcc, NDIR16, VT2
+    s_cbranch_vccnz .Ldist_direct                       // 16 <= code < 16 + NDIRECT
+    v_subrev_u32 VX, NDIR16, VT2
+    v_lshrrev_b32 VN, NPOST1, VX
+    v_add_u32 VN, 1, VN                                 // extra bits
+    v_lshrrev_b32 VHH, NPOST, VX                        // hcode
+    v_and_b32 VLC, POSTMASK, VX                         // lcode
+    v_and_b32 VHH, 1, VHH
+    v_add_u32 VHH, 2, VHH
+    v_lshlrev_b32 VHH, VN, VHH
+    v_bfe_u32 VE, VWINLO, 0, VN
+    v_add3_u32 VHH, VHH, VE, -4                         // offset + extra
+    v_lshlrev_b32 VHH, NPOST, VHH
+    v_add3_u32 VHH, VHH, VLC, NDIRECT1
+    v_lshrrev_b64 VWIN, VN, VWIN
+    v_sub_u32 VNAV, VNAV, VN
+    v_readfirstlane_b32 DIST, VHH
     REFILL_CHECK 6
     s_branch .Ldist_push
 .Ldist_direct:
+    v_readfirstlane_b32 DCODE, VT2
     s_sub_u32 DIST, DCODE, 15
     s_branch .Ldist_push
 .Ldist_single:
     s_and_b32 DCODE, T5, 0xffff
+    v_mov_b32 VT2, DCODE
     s_branch .Ldist_have
 .Ldist_ring:
+    v_readfirstlane_b32 DCODE, VT2
     s_cmp_eq_u32 DCODE, 0
     s_cbranch_scc1 .Ldist_zero
     s_cmp_ge_u32 DCODE, 4
@@ -663,15 +690,14 @@
     s_branch .Lcopy_issued
 
 .Llit_single:                                           // one-symbol tree: no bits
-    s_and_b32 T4, T5, 0xff
-    v_mov_b32 VT2, T4
+    v_and_b32 VT2, 0xff, VH
     s_branch .Llit_have
 
 // ======================================================================================================== helpers
 // Land the pending copy in the ring: its bytes sit in lanes 0..PENDN-1 of VPEND (FLAGS bit 2 clear) or VPENB (set).
 // Two copies can be in flight: a far copy is requested into the free register BEFORE the older one is waited for
 // (.Lland_[ab]_w1 wait with vmcnt(1): everything but the request just issued).  .Lland also refreshes the literal
-// context (P1, BVAL) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
+// context (VA1 = A[p1], VB1 = B[p1], VB2 = B[p2]) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
 .macro LAND_STORE reg
     s_sub_u32 T6, POS, PENDN
     s_add_u32 T6, T6, SKEW
@@ -689,7 +715,11 @@
     v_readlane_b32 P1, \reg, T6
     s_sub_u32 T6, PENDN, 2
     v_readlane_b32 T5, \reg, T6
-    LUTB BVAL, VVB, T5
+    v_mov_b32 VT4, P1                                   // (2 instructions after the v_readlane that wrote P1)
+    ds_read_u8 VA1, VT4 offset:LDS_ATAB
+    ds_read_u8 VB1, VT4 offset:LDS_BTAB
+    v_mov_b32 VT4, T5
+    ds_read_u8 VB2, VT4 offset:LDS_BTAB
 .endm
 .Lland:
     s_cmp_eq_u32 PENDN, 0
