@@ -86,6 +86,7 @@
 #define NDIRECT1 s7
 #define NDIR16 s8
 #define NPOST1 s9
+#define DTREE s10
 // ---- VGPRs
 #define VZERO v0
 #define VLANE v1
@@ -132,6 +133,7 @@
 #define VHH v45
 #define VLC v46
 #define VDH4 v47
+#define VDHV v48
 
 // The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
 // ALU issues one instruction per SIMD every 4 cycles and is the bottleneck of this loop (profiles/r01g_pmc.csv), the
@@ -485,6 +487,13 @@
 .Lr1:
     s_cmp_gt_u32 INS, MBLEFT
     s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
+    // the distance tree depends on the copy length only: request its header words now, use them after the literals
+    s_sub_u32 T0, CPY, 2
+    s_min_u32 T0, T0, 3                                 // distance context
+    v_readlane_b32 DTREE, VDH4, T0
+    s_max_i32 T0, DTREE, 0                              // (a one-symbol tree has no header: read anything)
+    v_add_u32 VT0, T0, VLANE4
+    ds_read_b32 VDHV, VT0
     s_cmp_eq_u32 INS, 0
     s_cbranch_scc1 .Lafter_lits
     s_call_b64 LINKB, .Lland
@@ -536,17 +545,12 @@
     // ---- distance symbol (reference parse_distance_code :1367-1410)
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
-    s_sub_u32 T0, CPY, 2
-    s_min_u32 T0, T0, 3                                 // distance context
-    v_readlane_b32 T5, VDH4, T0
-    s_cmp_lt_i32 T5, 0
+    s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc1 .Ldist_single
-    v_add_u32 VT0, T5, VLANE4
-    ds_read_b32 VT1, VT0
     s_waitcnt lgkmcnt(0)
-    SPLIT_HV VT1
+    SPLIT_HV VDHV
     LOOKUP VLIM, VBASE
-    v_lshl_add_u32 VT0, VI, 1, T5
+    v_lshl_add_u32 VT0, VI, 1, DTREE
     ds_read_u16 VT2, VT0 offset:64
     TAKE CLEN
     REFILL_CHECK 5
@@ -578,7 +582,7 @@
     s_sub_u32 DIST, DCODE, 15
     s_branch .Ldist_push
 .Ldist_single:
-    s_and_b32 DCODE, T5, 0xffff
+    s_and_b32 DCODE, DTREE, 0xffff
     v_mov_b32 VT2, DCODE
     s_branch .Ldist_have
 .Ldist_ring:
