@@ -14,6 +14,7 @@
  */
 #include "brotli_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -912,6 +913,9 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
             d->dist[0] = (uint32_t)distance;
         }
 
+        if (getenv("BRO_TRACE")) /* analysis aid: one line per command on stderr */
+            fprintf(stderr, "CMD %zu %zu %zu %llu\n", d->pos, insert_len, (size_t)copy_len,
+                    distance <= max_allowed ? (unsigned long long)distance : 0ull);
         /* copy_literals :1483-1542 and the CopyLiterals state :2102-2141 */
         if (distance <= max_allowed) {
             if (mlen < mb_count + copy_len) { rc = BRO_EXCEEDED_EXPECTED_BYTES; goto out; } /* :2105 */
