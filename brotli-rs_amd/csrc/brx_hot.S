@@ -123,16 +123,18 @@
 #define VRF v[36:37]
 #define VRFLO v36
 #define VRFHI v37
+// (v40-v47 are callee-saved in the AMDGPU calling convention: using them would make the wrapper spill them to scratch on
+// every call)
 #define VA1 v38
 #define VB1 v39
-#define VB2 v40
-#define VC v41
-#define VH v42
-#define VX v43
-#define VN v44
-#define VHH v45
-#define VLC v46
-#define VDH4 v47
+#define VB2 v49
+#define VC v50
+#define VH v51
+#define VX v52
+#define VN v53
+#define VHH v54
+#define VLC v55
+#define VDH4 v64
 #define VDHV v48
 
 // The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
