@@ -8,7 +8,8 @@
 A "step" = one pass of the hot path (brx_decode_batch through the C ABI) over one batch of synthetic input
 already resident in HBM.  Workload at every N: BASELINE.json configs[1], "4096 x data/alice29.txt.compressed"
 PER GPU (weak scaling: independent streams shard across ranks with no data-path collective; the RCCL
-scatter/gather of SURVEY 8e is timed separately, never inside `value`).  Prints ONE JSON line on rank 0.
+scatter/gather of SURVEY 8e lives in brotli-rs_amd/shard.py and is never inside `value`).  Prints ONE JSON line on
+rank 0.
 """
 import argparse
 import json

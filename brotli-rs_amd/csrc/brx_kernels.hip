@@ -15,9 +15,17 @@
 //     read back from the stream's own HBM output          (reference: copy_literals, src/lib.rs:1483-1542)
 //   * static dictionary + 121 transforms                 (reference: src/dictionary, src/transformation)
 //
+// The kernel is a dispatcher over out-of-line segments that hand the decoder state through LDS (Lds::st, Lds::mbw):
+//   seg_frame         stream / meta-block framing, uncompressed and metadata blocks
+//   cold_header       everything between MLEN and the first command: block types, context maps, prefix codes
+//   generic_commands  the command loop in C++: every meta-block shape, exact end-of-input / error / capacity rules;
+//                     re-entrant at three resume points (HC_*), which makes it the safety net of ...
+//   asm_commands      ... the hand-written gfx950 command loop (brx_hot.S), where the time is spent
+//   seg_finish        final flush
+//
 // Everything observable follows the reference, quirks Q1..Q15 of SURVEY.md section 2.3 included.
-// There is no MFMA here: the path is integer/byte work bounded by HBM bandwidth and by the serial
-// prefix-code chain of each stream.
+// There is no MFMA here: the path is integer/byte work bounded by HBM bandwidth (copy-dominated streams) and by the
+// serial prefix-code chain of each stream (instruction issue rate / dependent latency), see DESIGN.md section 6.
 #include <hip/hip_runtime.h>
 
 #include "brx_device.h"
@@ -47,10 +55,11 @@ enum { LK_OK = 0, LK_NONE = 1, LK_EOF = 2 };
 struct __attribute__((aligned(16))) Lds {
     u8 ring[BRX_RING_BYTES];
     u32 tm[BRX_TM_WORDS];
-    u8 lens[BRX_LENS_BYTES - 512u]; // code lengths of one alphabet (<= 704), rounded up for 4-byte clears
+    u8 lens[BRX_LENS_BYTES - 512u]; // code lengths of one alphabet (<= 704), rounded up for 4-byte clears; during the
+                                     // command loop brx_hot.S keeps its literal-context tables here
     u32 st[48];                      // decoder state parked here across calls into the cold (out-of-line) parts
     u32 mbw[48];                     // meta-block header results handed from cold_header to the command loop
-    u32 pad[16];                     // profiling accumulators
+    u32 pad[16];                     // bring-up counters (BRX_DEBUG_STATS)
     u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
 };
 
