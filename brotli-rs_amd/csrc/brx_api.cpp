@@ -8,7 +8,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <numeric>
 #include <new>
 #include <string>
 #include <vector>
@@ -193,8 +195,10 @@ static int grow(uint8_t **p, size_t *cap, size_t need) {
 }
 
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
-                  uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status) {
+                  uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
+                  const uint32_t *d_order = nullptr) {
     BrxKernelArgs a;
+    a.order = d_order;
     a.in = d_in;
     a.in_off = d_in_off;
     a.out = d_out;
@@ -272,7 +276,7 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
     if ((rc = grow(&c->st_in, &c->st_in_cap, in_bytes + 16))) return rc;
     if ((rc = grow(&c->st_out, &c->st_out_cap, out_bytes + 16))) return rc;
     const size_t meta_words = 3 * (size_t)(n + 1);
-    const size_t meta_bytes = meta_words * 8 + (size_t)n * 4;
+    const size_t meta_bytes = meta_words * 8 + (size_t)n * 4 + (size_t)n * 4;
     if ((rc = grow((uint8_t **)&c->st_meta, &c->st_meta_cap, meta_bytes))) return rc;
     std::vector<uint64_t> hmeta(2 * (size_t)(n + 1));
     for (uint32_t i = 0; i <= n; i++) {
@@ -281,10 +285,20 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
     }
     uint64_t *d_in_off = c->st_meta, *d_out_off = c->st_meta + (n + 1), *d_out_len = c->st_meta + 2 * (size_t)(n + 1);
     int32_t *d_status = (int32_t *)(c->st_meta + meta_words);
+    // Work-queue order: longest compressed stream first.  The streams of a batch are ragged; a
+    // stream is a serial job on one wavefront, so the batch finishes when its longest job does -- start those first.
+    uint32_t *d_order = (uint32_t *)(d_status + n);
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return in_off[x + 1] - in_off[x] > in_off[y + 1] - in_off[y];
+    });
+    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     if (in_bytes) HIP_TRY(hipMemcpyAsync(c->st_in, in + in_lo, in_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-    rc = launch(c, st, timing, c->st_in, d_in_off, n, c->st_out, d_out_off, d_out_len, d_status);
+    rc = launch(c, st, timing, c->st_in, d_in_off, n, c->st_out, d_out_off, d_out_len, d_status,
+                getenv("BRX_NO_ORDER") ? nullptr : d_order);
     if (rc) return rc;
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
     HIP_TRY(hipMemcpyAsync(out_len, d_out_len, (size_t)n * 8, hipMemcpyDeviceToHost, st));

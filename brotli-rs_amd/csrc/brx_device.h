@@ -38,6 +38,7 @@ struct BrxKernelArgs {
     uint64_t *out_len;
     int32_t *status;
     uint32_t n;
+    const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
     uint32_t *work_counter; // zeroed before every launch
     uint32_t *scratch;      // gridDim.x * BRX_SCRATCH_WORDS

@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
         // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
         u32 sid = rdl(atomicAdd(a.work_counter, lane == 0u ? 1u : 0u), 0);
         if (sid >= a.n) break;
+        if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
         {

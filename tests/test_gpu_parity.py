@@ -258,3 +258,20 @@ def test_random_encoder_fuzz(ctx):
     for i, (d, o, st) in enumerate(zip(datas, outs, status)):
         assert st == 0, (i, int(st))
         assert o == d, i
+
+
+def test_ragged_batch_long_streams_last(ctx):
+    """A ragged batch whose long streams come LAST in the caller's order (4096 tiny streams, then 32 x 1 MiB): the host
+    path queues the longest streams first; results must not depend on the queue order."""
+    d = os.path.join(GOLDEN, "config5")
+    man = json.load(open(os.path.join(d, "manifest.json")))["streams"]
+    big = [open(os.path.join(d, e["name"] + ".compressed"), "rb").read() for e in man]
+    small = _read("monkey.compressed")
+    exp_small = _read("monkey")
+    streams = [small] * 4096 + [big[i % len(big)] for i in range(32)]
+    caps = [len(exp_small)] * 4096 + [1 << 20] * 32
+    outs, status, out_len = ctx.decode_batch(streams, caps)
+    assert not status.any()
+    assert all(o == exp_small for o in outs[:4096])
+    for i in range(32):
+        assert hashlib.sha256(outs[4096 + i]).hexdigest() == man[i % len(man)]["sha256"]
