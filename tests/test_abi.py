@@ -65,3 +65,13 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "brotli_oracle" not in text and "oracle_py" not in text, os.path.join(dirpath, f)
                 assert "libbrotli" not in text, os.path.join(dirpath, f)
+
+
+def test_assembly_loop_passes_the_wait_state_lint():
+    """brx_hot.S assembles for gfx950 on its own and tools/asm_hazard_lint.py finds no gfx940+ data hazard in it (the
+    assembler inserts no wait states into hand-written code)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 finding(s)" in r.stdout
