@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static int g_trace;
+
 #include "_gen/tables_gen.h" /* BRO_DICT, BRO_CONTEXT_LUT, BRO_TRANSFORMS (tools/bin2h.py) */
 
 /* ------------------------------------------------------------------------- */
@@ -913,7 +915,7 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
             d->dist[0] = (uint32_t)distance;
         }
 
-        if (getenv("BRO_TRACE")) /* analysis aid: one line per command on stderr */
+        if (g_trace) /* analysis aid (BRO_TRACE=1): one line per command on stderr */
             fprintf(stderr, "CMD %zu %zu %zu %llu\n", d->pos, insert_len, (size_t)copy_len,
                     distance <= max_allowed ? (unsigned long long)distance : 0ull);
         /* copy_literals :1483-1542 and the CopyLiterals state :2102-2141 */
@@ -977,6 +979,7 @@ out:
 int bro_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len, unsigned flags,
                bro_stats *stats) {
     bro_init();
+    g_trace = getenv("BRO_TRACE") != NULL; /* read once per stream: keeps the command loop free of libc calls */
     Dec d;
     memset(&d, 0, sizeof d);
     d.br.p = in;
