@@ -74,6 +74,36 @@ def cpu_baseline(comp, expect, seconds=12.0):
                       % (reps, len(comp), len(expect), dt)}, st.as_dict()
 
 
+def libbrotlidec_rate(comp, expect, seconds=3.0):
+    """Single-thread rate of the system libbrotlidec (1.0.9 in this image) on the same stream -- not the reference, not
+    the baseline of record, just a second CPU yardstick next to the oracle.  None when the library is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import ctypes
+        import brotli_enc
+        if not brotli_enc.available():
+            return None
+        dec = ctypes.CDLL("libbrotlidec.so.1")
+        dec.BrotliDecoderDecompress.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
+        out = ctypes.create_string_buffer(len(expect) + 64)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(8):
+                n = ctypes.c_size_t(len(out))
+                if dec.BrotliDecoderDecompress(len(comp), comp, ctypes.byref(n), out) != 1:
+                    return None
+            reps += 8
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+        if out.raw[:n.value] != expect:
+            return None
+        return {"value": round(reps * len(expect) / dt / 1e6, 2), "unit": "MB/s", "cores": 1,
+                "sample": "%d decodes in %.1f s, libbrotlidec.so.1 one-shot API" % (reps, dt)}
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +244,9 @@ def main():
         if cb:
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_1core"] = round(value / world / cb["value"], 1)
+            other = libbrotlidec_rate(comp, expect)
+            if other:
+                res["cpu_libbrotlidec"] = other  # informational: Google's optimized C decoder, if the image has it
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
