@@ -80,6 +80,7 @@
 #define CLEN s96
 #define LINKB s[98:99]
 #define LINKC s[100:101]
+#define LINKD s[24:25]
 #define NPOST s4
 #define NDIRECT s5
 #define POSTMASK s6
@@ -87,6 +88,8 @@
 #define NDIR16 s8
 #define NPOST1 s9
 #define DTREE s10
+#define XFP s[26:27]
+#define PENDEND s28
 // ---- VGPRs
 #define VZERO v0
 #define VLANE v1
@@ -188,23 +191,6 @@
     v_lshrrev_b32 VBASE, 16, \hv
 .endm
 
-// Wait for the pending copy's bytes.  With -DBRX_ASM_PROF the cycles spent in this wait are summed into s97 and
-// handed out through mbw[39] (bring-up measurement of how much of a stream's time is far-copy latency).
-.macro PROF_WAIT
-#ifdef BRX_ASM_PROF
-    s_waitcnt lgkmcnt(0)
-    s_memtime s[92:93]
-    s_waitcnt lgkmcnt(0)
-    s_waitcnt vmcnt(0)
-    s_memtime s[94:95]
-    s_waitcnt lgkmcnt(0)
-    s_sub_u32 s94, s94, s92
-    s_add_u32 s97, s97, s94
-#else
-    s_waitcnt vmcnt(0) lgkmcnt(0)
-#endif
-.endm
-
 // ======================================================================================================== entry
     s_waitcnt vmcnt(0) lgkmcnt(0)
     v_mov_b32 VZERO, 0
@@ -235,9 +221,11 @@
     ds_read_b64 v[20:21], VZERO offset:LDS_ST+64        // dist2, dist3
     ds_read_b32 v22, VZERO offset:LDS_ST+92             // t_dict (st[23], st[24]: only 4-byte aligned)
     ds_read_b32 v23, VZERO offset:LDS_ST+96
+    ds_read_b32 v26, VZERO offset:LDS_ST+100            // t_xforms (st[25], st[26])
+    ds_read_b32 v27, VZERO offset:LDS_ST+104
     ds_read_b32 v24, VZERO offset:LDS_ST+108            // t_lut (st[27], st[28])
     ds_read_b32 v25, VZERO offset:LDS_ST+112
-    ds_read_b64 v[26:27], VZERO offset:LDS_ST+144       // insert&copy / dictionary info table
+    ds_read_b64 v[28:29], VZERO offset:LDS_ST+144       // insert&copy / dictionary info table
     s_and_b32 s49, s49, 0xffff
     s_mov_b32 s50, -1
     s_mov_b32 s51, 0x00020000
@@ -264,8 +252,10 @@
     v_readfirstlane_b32 s77, v23
     v_readfirstlane_b32 T4, v24
     v_readfirstlane_b32 T5, v25
-    v_readfirstlane_b32 s74, v26
-    v_readfirstlane_b32 s75, v27
+    v_readfirstlane_b32 s26, v26
+    v_readfirstlane_b32 s27, v27
+    v_readfirstlane_b32 s74, v28
+    v_readfirstlane_b32 s75, v29
     // context LUTs (3 x 64 dwords) and the dictionary info vector (dwords 1408.. of the insert&copy table)
     v_lshlrev_b32 VT0, 2, VLANE
     s_nop 4                                             // v_readfirstlane -> VMEM address SGPR: 5 wait states
@@ -424,7 +414,6 @@
     s_mov_b32 PENDN, 0
     s_mov_b32 FLAGS, 0
     s_mov_b32 EXITC, 1
-    s_mov_b32 s97, 0
     s_and_b32 T0, VFL, 0xfffffc00
     s_add_u32 T0, T0, 2048
     s_sub_u32 FLUSHAT, T0, SKEW
@@ -487,8 +476,6 @@
 
 // ======================================================================================================== R1
 .Lr1:
-    s_cmp_gt_u32 INS, MBLEFT
-    s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
     // the distance tree depends on the copy length only: request its header words now, use them after the literals
     s_sub_u32 T0, CPY, 2
     s_min_u32 T0, T0, 3                                 // distance context
@@ -497,7 +484,9 @@
     v_add_u32 VT0, T0, VLANE4
     ds_read_b32 VDHV, VT0
     s_cmp_eq_u32 INS, 0
-    s_cbranch_scc1 .Lafter_lits
+    s_cbranch_scc1 .Lno_lits                            // two commands in three have no literals
+    s_cmp_gt_u32 INS, MBLEFT
+    s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
     s_call_b64 LINKB, .Lland
     s_sub_u32 MBLEFT, MBLEFT, INS
 .Llit:
@@ -541,6 +530,7 @@
 .Lafter_lits:
     s_cmp_eq_u32 MBLEFT, 0
     s_cbranch_scc1 .Lexit                               // :2069 the copy part of the last command is ignored
+.Lno_lits:
     s_min_u32 MAXA, POS, WINDOW
     s_cmp_lg_u32 IZ, 0
     s_cbranch_scc1 .Ldist_zero
@@ -660,7 +650,9 @@
 .Lcopy_issued:
     s_mov_b32 PENDN, CPY
     s_add_u32 POS, POS, CPY
+    s_mov_b32 PENDEND, POS                              // the pending bytes end here
     s_sub_u32 MBLEFT, MBLEFT, CPY
+.Lcopy_tail:
     s_cmp_ge_u32 POS, FLUSHAT
     s_cbranch_scc1 .Lflush_stub_cmd
 .Lflush_back_cmd:
@@ -675,18 +667,20 @@
     s_cbranch_scc1 .Lx_r2
     s_cmp_gt_u32 CPY, 24
     s_cbranch_scc1 .Lx_r2
-    s_cmp_gt_u32 CPY, MBLEFT
-    s_cbranch_scc1 .Lx_r2
     v_readlane_b32 T0, VDICTINFO, CPY                   // DOFFSET | NDBITS << 24
     s_sub_u32 T1, DIST, MAXA
     s_sub_u32 T1, T1, 1                                 // word id
     s_lshr_b32 T2, T0, 24
     s_lshr_b32 T3, T1, T2                               // transform id
-    s_cmp_lg_u32 T3, 0
-    s_cbranch_scc1 .Lx_r2
+    s_bfm_b32 T4, T2, 0
+    s_and_b32 T1, T1, T4                                // word index
     s_and_b32 T0, T0, 0xffffff
     s_mul_i32 T1, T1, CPY
-    s_add_u32 T0, T0, T1
+    s_add_u32 T0, T0, T1                                // byte offset of the word in the dictionary
+    s_cmp_lg_u32 T3, 0
+    s_cbranch_scc1 .Ldict_xform
+    s_cmp_gt_u32 CPY, MBLEFT
+    s_cbranch_scc1 .Lx_r2
     s_call_b64 LINKB, .Lland_noctx
     s_bitset0_b32 FLAGS, 2
     s_sub_u32 T1, CPY, 1
@@ -694,7 +688,6 @@
     v_add_u32 VT0, T0, VT0
     global_load_ubyte VPEND, VT0, DICTP
     s_branch .Lcopy_issued
-
 .Llit_single:                                           // one-symbol tree: no bits
     v_and_b32 VT2, 0xff, VH
     s_branch .Llit_have
@@ -705,7 +698,7 @@
 // (.Lland_[ab]_w1 wait with vmcnt(1): everything but the request just issued).  .Lland also refreshes the literal
 // context (VA1 = A[p1], VB1 = B[p1], VB2 = B[p2]) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
 .macro LAND_STORE reg
-    s_sub_u32 T6, POS, PENDN
+    s_sub_u32 T6, PENDEND, PENDN
     s_add_u32 T6, T6, SKEW
     v_add_u32 VT4, T6, VLANE
     v_and_b32 VT4, RMASK, VT4
@@ -728,9 +721,11 @@
     ds_read_u8 VB2, VT4 offset:LDS_BTAB
 .endm
 .Lland:
+    s_bitcmp1_b32 FLAGS, 1
+    s_cbranch_scc1 .Lland_ringctx
     s_cmp_eq_u32 PENDN, 0
     s_cbranch_scc1 .Lland_ret
-    PROF_WAIT
+    s_waitcnt vmcnt(0) lgkmcnt(0)
     s_bitcmp1_b32 FLAGS, 2
     s_cbranch_scc1 .Lland_ctx_b
     LAND_CTX VPEND
@@ -741,7 +736,7 @@
 .Lland_noctx:
     s_cmp_eq_u32 PENDN, 0
     s_cbranch_scc1 .Lland_ret
-    PROF_WAIT
+    s_waitcnt vmcnt(0) lgkmcnt(0)
     s_bitcmp1_b32 FLAGS, 2
     s_cbranch_scc1 .Lland_store_b
     LAND_STORE VPEND
@@ -758,6 +753,29 @@
     s_waitcnt vmcnt(1) lgkmcnt(0)
     LAND_STORE VPENB
 .Lland_ret:
+    s_setpc_b64 LINKB
+// After a transformed dictionary word the last two bytes of the stream may belong to its suffix: land what is pending,
+// then read them back from the ring.  (Only called from .Lr1: with fewer than 2 bytes of output, leave at R1.)
+.Lland_ringctx:
+    s_bitset0_b32 FLAGS, 1
+    s_cmp_lt_u32 POS, 2
+    s_cbranch_scc1 .Lexit
+    s_mov_b64 LINKD, LINKB
+    s_call_b64 LINKB, .Lland_noctx
+    s_mov_b64 LINKB, LINKD
+    s_add_u32 T6, POS, SKEW
+    s_sub_u32 T7, T6, 1
+    s_and_b32 T7, T7, RMASK
+    v_mov_b32 VT0, T7
+    ds_read_u8 VT0, VT0
+    s_sub_u32 T7, T6, 2
+    s_and_b32 T7, T7, RMASK
+    v_mov_b32 VT1, T7
+    ds_read_u8 VT1, VT1
+    s_waitcnt lgkmcnt(0)
+    ds_read_u8 VA1, VT0 offset:LDS_ATAB
+    ds_read_u8 VB1, VT0 offset:LDS_BTAB
+    ds_read_u8 VB2, VT1 offset:LDS_BTAB
     s_setpc_b64 LINKB
 
 // Flush 1 KiB blocks of the ring to HBM (64 lanes x 16 B, both sides 16-byte aligned).
@@ -819,6 +837,78 @@
     REFILL_STUB 4
     REFILL_STUB 5
     REFILL_STUB 6
+
+// ---- a transformed word (reference src/transformation/mod.rs, spec Appendix B): prefix + op(word) + suffix with
+// op = identity / OmitFirstN / OmitLastN.  Prefix and suffix (<= 8 bytes each, from the transform record) go to the
+// ring at once; the middle part is an ordinary pending load.  The two uppercase operations go to the C++ side.
+.Ldict_xform:
+    s_cmp_gt_u32 T3, 120
+    s_cbranch_scc1 .Lx_r2
+    s_mul_i32 T4, T3, 20                                // sizeof(BrxTransform)
+    s_load_dwordx4 s[92:95], XFP, T4                    // prefix[8], suffix[8]
+    s_add_u32 T4, T4, 16
+    s_load_dword s97, XFP, T4                           // plen | slen << 8 | op << 16
+    s_call_b64 LINKB, .Lland_noctx
+    s_bitset0_b32 FLAGS, 2
+    s_waitcnt lgkmcnt(0)
+    s_bfe_u32 T1, s97, 0x80010                          // op
+    s_and_b32 T2, s97, 0xff                             // prefix length
+    s_bfe_u32 T3, s97, 0x80008                          // suffix length
+    s_sub_u32 T4, T1, 1
+    s_cmp_lt_u32 T4, 2
+    s_cbranch_scc1 .Lx_r2                               // UppercaseFirst / UppercaseAll
+    s_mov_b32 T5, 0                                     // first word byte used
+    s_mov_b32 T7, CPY                                   // word bytes used
+    s_cmp_lt_u32 T1, 3
+    s_cbranch_scc1 .Lxf_have
+    s_cmp_ge_u32 T1, 12
+    s_cbranch_scc1 .Lxf_last
+    s_sub_u32 T4, T1, 2                                 // OmitFirstN: word[min(N, len-1)..] (Q1)
+    s_sub_u32 T6, CPY, 1
+    s_min_u32 T5, T4, T6
+    s_sub_u32 T7, CPY, T5
+    s_branch .Lxf_have
+.Lxf_last:
+    s_sub_u32 T4, T1, 11                                // OmitLastN: word[..max(N, len) - N]
+    s_max_u32 T7, CPY, T4
+    s_sub_u32 T7, T7, T4
+.Lxf_have:
+    s_add_u32 CLEN, T2, T7
+    s_add_u32 CLEN, CLEN, T3                            // transformed length (<= 40)
+    s_cmp_gt_u32 CLEN, MBLEFT
+    s_cbranch_scc1 .Lx_r2                               // :2105 on the transformed length (Q4): raised by the C++ side
+    v_lshlrev_b32 VT1, 3, VLANE
+    v_lshrrev_b64 v[20:21], VT1, s[92:93]               // lane i: prefix byte i
+    s_add_u32 T4, POS, SKEW
+    v_add_u32 VT0, T4, VLANE
+    v_and_b32 VT0, RMASK, VT0
+    s_bfm_b64 exec, T2, 0
+    ds_write_b8 VT0, v20
+    s_mov_b64 exec, -1
+    s_add_u32 T4, T4, T2
+    s_add_u32 T4, T4, T7
+    v_lshrrev_b64 v[20:21], VT1, s[94:95]               // lane i: suffix byte i
+    v_add_u32 VT0, T4, VLANE
+    v_and_b32 VT0, RMASK, VT0
+    s_bfm_b64 exec, T3, 0
+    ds_write_b8 VT0, v20
+    s_mov_b64 exec, -1
+    s_mov_b32 PENDN, 0
+    s_cmp_eq_u32 T7, 0
+    s_cbranch_scc1 .Lxf_nomid
+    s_add_u32 T0, T0, T5
+    s_sub_u32 T4, T7, 1
+    v_min_u32 VT0, T4, VLANE
+    v_add_u32 VT0, T0, VT0
+    global_load_ubyte VPEND, VT0, DICTP
+    s_mov_b32 PENDN, T7
+.Lxf_nomid:
+    s_add_u32 PENDEND, POS, T2
+    s_add_u32 PENDEND, PENDEND, T7                      // the pending (middle) bytes end before the suffix
+    s_add_u32 POS, POS, CLEN
+    s_sub_u32 MBLEFT, MBLEFT, CLEN
+    s_bitset1_b32 FLAGS, 1                              // literal context: from the ring (see .Lland)
+    s_branch .Lcopy_tail
 
 // ======================================================================================================== exits
 .Lx_r0_switch:                                          // insert&copy block count exhausted (or poisoned)
@@ -884,6 +974,4 @@
     v_mov_b32 v22, EXITC
     ds_write_b64 VZERO, v[20:21] offset:LDS_MBW+144     // distance, distance-is-bad
     ds_write_b32 VZERO, v22 offset:LDS_MBW+152          // exit point
-    v_mov_b32 v23, s97
-    ds_write_b32 VZERO, v23 offset:LDS_MBW+156          // (BRX_ASM_PROF) cycles waited for copy data
     s_waitcnt lgkmcnt(0)

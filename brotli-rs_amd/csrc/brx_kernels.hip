@@ -1052,7 +1052,7 @@ __device__ __noinline__ u32 asm_commands() {
 #include "_gen/brx_hot_asm.h"
         :
         :
-        : "memory", "vcc", "scc", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+        : "memory", "vcc", "scc", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
           "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
           "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
@@ -1440,7 +1440,6 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                     const u32 r = asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
-                        s.pad[3] += s.mbw[39];
                         if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) { // first exit: the parked command
                             for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
                             s.pad[15] = s.st[10]; s.pad[7] = s.st[3];

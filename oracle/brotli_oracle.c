@@ -941,6 +941,7 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
             unsigned nbits = NDBITS[copy_len];
             uint64_t index = word_id & ((1u << nbits) - 1);
             uint64_t transform_id = word_id >> nbits;
+            if (g_trace) fprintf(stderr, "TID %llu\n", (unsigned long long)transform_id);
             if (transform_id > 120) { rc = BRO_INVALID_TRANSFORM_ID; goto out; }
             uint8_t word[40];
             int wl = bro_transform((unsigned)transform_id, BRO_DICT + DOFFSET[copy_len] + index * copy_len,

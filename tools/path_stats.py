@@ -3,6 +3,7 @@
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["BRX_DEBUG_STATS"] = "1"; os.environ["BRX_DEBUG_STATS_ALL"] = "1"
 from brotli_rs_amd import brx
 def run(name, streams, caps):
@@ -11,10 +12,13 @@ def run(name, streams, caps):
     outs, status, out_len = ctx.decode_batch(streams, caps)
     os.dup2(saved, 2); os.close(w)
     txt = os.read(r, 1 << 24).decode(errors="replace")
-    g = f = a = 0
-    for m in re.finditer(r"words: (\d+) (\d+) (\d+)", txt):
-        g += int(m.group(1)); f += int(m.group(2)); a += int(m.group(3))
-    print("%-12s streams %4d  meta-blocks: generic %5d  fast-C++ %5d  asm %5d" % (name, len(streams), g, f, a))
+    g = a = x0 = x1 = x2 = 0
+    for m in re.finditer(r"words: (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+)", txt):
+        g += int(m.group(1)); a += int(m.group(3)); x0 += int(m.group(5)); x1 += int(m.group(6)); x2 += int(m.group(7))
+    import oracle_py
+    cmds = sum(oracle_py.decode(s_, want_stats=True)[2]["commands"] for s_ in streams)
+    print("%-10s streams %4d  meta-blocks: C++ only %4d, assembly %5d;  commands %8d, exits to C++ at R0 %6d  R1 %6d  R2 %6d  (%.2f %% of commands)"
+          % (name, len(streams), g, a, cmds, x0, x1, x2, 100.0 * (x0 + x1 + x2) / max(cmds, 1)))
     ctx.close()
 G = os.path.join(ROOT, "tests/golden")
 man = json.load(open(os.path.join(G, "enc/manifest.json")))["streams"]
