@@ -1093,21 +1093,23 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
         u32 ok = (m.hl + total <= BRX_TM_WORDS && (u32)(uintptr_t)&g_lds == 0u && m.ntl <= 64u && m.ntd <= 64u &&
                   m.cml + 64u * L.nbl <= TM_BYTES && m.cmd + 4u * D.nbl <= TM_BYTES && m.cmode_w * 4u + L.nbl <= TM_BYTES &&
                   (u64)d.pos + m.mlen <= (u64)d.cap && d.bitend < (1ull << 31)) ? 1u : 0u;
+        u32 why = ok ? 0u : ((m.ntl > 64u || m.ntd > 64u) ? 16u : (m.hl + total > BRX_TM_WORDS) ? 1u : 32u); // (bring-up statistics)
         for (u32 i = 0; i < total; i++) {
             const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
-            if (h_ >= BRX_TM_WORDS - 16u) ok = 0u;
+            if (h_ >= BRX_TM_WORDS - 16u) { ok = 0u; why |= 2u; }
             else {
                 const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
-                if (kind_ != 2u && (iac_ || kind_ != 1u)) ok = 0u;
+                if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u; }
                 // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
                 // the left-aligned upper bound of its longest codes is then exactly 2^15
                 const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
                 const bool full_ = ballot((hvw_ & 0xffffu) == 0x8000u && (d.lane & 15u) != 0u) != 0ull;
-                if (kind_ == 2u && !full_) ok = 0u;
+                if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }
         s.mbw[MBW_ASM] = ok;
+        if (!ok) s.pad[8] |= why;
     }
 
     // parse_insert_and_copy_length :1179-1208 + decode_insert_and_copy_length :1210-1224
@@ -1440,10 +1442,6 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                     const u32 r = asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
-                        if (s.pad[4] + s.pad[5] + s.pad[6] == 1u) { // first exit: the parked command
-                            for (u32 q = 0; q < 7u; q++) s.pad[8 + q] = s.mbw[32 + q];
-                            s.pad[15] = s.st[10]; s.pad[7] = s.st[3];
-                        }
                     }
                     st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
                 }

@@ -13,12 +13,20 @@ def run(name, streams, caps):
     os.dup2(saved, 2); os.close(w)
     txt = os.read(r, 1 << 24).decode(errors="replace")
     g = a = x0 = x1 = x2 = 0
-    for m in re.finditer(r"words: (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+)", txt):
+    import collections
+    why = collections.Counter()
+    for m in re.finditer(r"words: (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+) (\d+)", txt):
         g += int(m.group(1)); a += int(m.group(3)); x0 += int(m.group(5)); x1 += int(m.group(6)); x2 += int(m.group(7))
+        w = int(m.group(9))
+        for bit, nm in ((1, "handle table beyond LDS"), (2, "a tree beyond LDS"), (4, "empty / one-symbol insert&copy tree"), (8, "incomplete code"), (16, "> 64 trees"), (32, "capacity / maps beyond LDS")):
+            if w & bit:
+                why[nm] += 1
     import oracle_py
     cmds = sum(oracle_py.decode(s_, want_stats=True)[2]["commands"] for s_ in streams)
     print("%-10s streams %4d  meta-blocks: C++ only %4d, assembly %5d;  commands %8d, exits to C++ at R0 %6d  R1 %6d  R2 %6d  (%.2f %% of commands)"
           % (name, len(streams), g, a, cmds, x0, x1, x2, 100.0 * (x0 + x1 + x2) / max(cmds, 1)))
+    if why:
+        print("           streams with a C++-only meta-block, by reason:", dict(why))
     ctx.close()
 G = os.path.join(ROOT, "tests/golden")
 man = json.load(open(os.path.join(G, "enc/manifest.json")))["streams"]
