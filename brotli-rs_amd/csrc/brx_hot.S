@@ -101,7 +101,6 @@
 #define VVB v7
 #define VLHOFF v9
 #define VDHOFF v10
-#define VHVIAC v11
 #define VPEND v12
 #define VDICTINFO v13
 #define VQ v[14:17]
@@ -115,8 +114,8 @@
 #define VU v25
 #define VBASE v26
 #define VI v27
-#define VIACL v28
-#define VIACB v29
+#define VIACL v66
+#define VIACB v67
 #define VE v30
 #define VLIM v31
 #define VWIN v[32:33]
@@ -139,6 +138,7 @@
 #define VLC v55
 #define VDH4 v64
 #define VDHV v48
+#define VDHB v65
 
 // The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
 // ALU issues one instruction per SIMD every 4 cycles and is the bottleneck of this loop (profiles/r01g_pmc.csv), the
@@ -170,25 +170,19 @@
     s_call_b64 LINKA, .Lspecial
     s_branch .Lrf_back_\id
 .endm
-// Canonical prefix-code lookup.  lim / base = per-lane limit[L] and base[L] of the tree (lane L, L = 1..15).
+// Canonical prefix-code lookup (table layout: brx_kernels.hip, "Table layout in table memory").
+// lim = per-lane limit[L] << 16 (lane 0: 0), base = per-lane base[L] of the tree (lane L, L = 1..15).
 // Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
-// Every code is complete (precondition), so some lane always matches.
+// Every code is complete (precondition), so some lane always matches; the lowest matching lane is the length.
 .macro LOOKUP lim, base
     v_bfrev_b32 VR, VWINLO
-    v_lshrrev_b32 VU, 17, VR
+    v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
-    s_and_b32 T2, vcc_lo, 0xfffe
-    s_ff1_i32_b32 CLEN, T2
+    s_ff1_i32_b32 CLEN, vcc_lo
     v_readlane_b32 T3, \base, CLEN
     s_sub_u32 T2, 32, CLEN
     v_lshrrev_b32 VI, T2, VR                            // (two instructions between the v_readlane and its VALU reader)
     v_add_u32 VI, T3, VI
-    v_and_b32 VI, 0xffff, VI
-.endm
-// limit / base vectors of a tree whose header words (limit | base << 16) were just read into \hv
-.macro SPLIT_HV hv
-    v_and_b32 VLIM, 0xffff, \hv
-    v_lshrrev_b32 VBASE, 16, \hv
 .endm
 
 // ======================================================================================================== entry
@@ -312,8 +306,8 @@
     s_waitcnt lgkmcnt(0)
     v_lshlrev_b32 VLHOFF, 2, VLHOFF
     v_lshlrev_b32 VDHOFF, 2, VDHOFF
-    ds_read_b32 VT0, VLHOFF offset:LDS_TM               // header word 0: kind | max_len << 8 | symbol << 16
-    ds_read_b32 VT1, VDHOFF offset:LDS_TM
+    ds_read_b32 VT0, VLHOFF offset:LDS_TM+64            // header word 16: kind | max_len << 8 | symbol << 16
+    ds_read_b32 VT1, VDHOFF offset:LDS_TM+64
     v_add_u32 VLHOFF, LDS_TM, VLHOFF
     v_add_u32 VDHOFF, LDS_TM, VDHOFF
     s_waitcnt lgkmcnt(0)
@@ -363,9 +357,10 @@
     ds_write_b32 VT3, VT4 offset:LDS_CMH
     s_lshl_b32 T7, T7, 2
     s_add_u32 T7, T7, LDS_TM
-    s_add_u32 HISYM, T7, 64
+    s_add_u32 HISYM, T7, 128
     v_add_u32 VT0, T7, VLANE4
-    ds_read_b32 VHVIAC, VT0
+    ds_read_b32 VIACL, VT0                              // limits and bases of the insert&copy tree stay resident
+    ds_read_b32 VIACB, VT0 offset:64
     // context vectors (see ctx_vectors() in brx_kernels.hip): id = (A[p1] | B[p2]) & 63
     s_waitcnt vmcnt(0)
     v_lshlrev_b32 VT0, 2, VLANE
@@ -400,9 +395,6 @@
     v_mov_b32 VWINLO, s36
     v_mov_b32 VWINHI, s37
     v_mov_b32 VNAV, s38
-    s_waitcnt lgkmcnt(0)                                // VHVIAC
-    v_and_b32 VIACL, 0xffff, VHVIAC
-    v_lshrrev_b32 VIACB, 16, VHVIAC
     s_mov_b32 WL, 2
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
@@ -483,6 +475,7 @@
     s_max_i32 T0, DTREE, 0                              // (a one-symbol tree has no header: read anything)
     v_add_u32 VT0, T0, VLANE4
     ds_read_b32 VDHV, VT0
+    ds_read_b32 VDHB, VT0 offset:64
     s_cmp_eq_u32 INS, 0
     s_cbranch_scc1 .Lno_lits                            // two commands in three have no literals
     s_cmp_gt_u32 INS, MBLEFT
@@ -502,12 +495,12 @@
     v_cmp_gt_i32 vcc, 0, VH
     s_cbranch_vccnz .Llit_single
     v_add_u32 VT0, VH, VLANE4
-    ds_read_b32 VT1, VT0
+    ds_read_b32 VLIM, VT0
+    ds_read_b32 VBASE, VT0 offset:64
     s_waitcnt lgkmcnt(0)
-    SPLIT_HV VT1
     LOOKUP VLIM, VBASE
     v_lshl_add_u32 VT0, VI, 1, VH
-    ds_read_u16 VT2, VT0 offset:64
+    ds_read_u16 VT2, VT0 offset:128
     TAKE CLEN
 .Llit_have:
     v_mov_b32 VT0, POS
@@ -540,10 +533,9 @@
     s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc1 .Ldist_single
     s_waitcnt lgkmcnt(0)
-    SPLIT_HV VDHV
-    LOOKUP VLIM, VBASE
+    LOOKUP VDHV, VDHB
     v_lshl_add_u32 VT0, VI, 1, DTREE
-    ds_read_u16 VT2, VT0 offset:64
+    ds_read_u16 VT2, VT0 offset:128
     TAKE CLEN
     REFILL_CHECK 5
     s_waitcnt lgkmcnt(0)

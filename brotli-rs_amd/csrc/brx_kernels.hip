@@ -315,16 +315,19 @@ FI void dec_load(Dec &d, const Lds &s) {
 }
 
 // ---- prefix codes ----------------------------------------------------------------------------------------
-// Table layout in table memory (word address h): 16 header words, then the symbols as u16 in
-// (length, symbol) order.  header[0] = kind | max_len << 8 | single_symbol << 16  (kind 0 empty, 1 single,
-// 2 general); header[L] (1..15) = limit[L] | base[L] << 16 with
-//   limit[L] = (first_code[L] + count[L]) << (15-L)   -- exclusive upper bound of length-L codes, left aligned
-//   base[L]  = offset[L] - first_code[L]  (mod 2^16)
+// Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols as u16 in
+// (length, symbol) order.
+//   header[L], L = 1..15 : limit[L] << 16, limit[L] = (first_code[L] + count[L]) << (15-L) -- the exclusive upper bound
+//                          of the length-L codes as a left-aligned 31-bit value; header[0] = 0 (never matches)
+//   header[16]           : kind | max_len << 8 | x << 16  (kind 0 empty, 1 one symbol x, 2 general with x symbols)
+//   header[16 + L]       : base[L] = offset[L] - first_code[L] (two's complement): code value + base = symbol index
+// One v_cmp of (bit-reversed window >> 1) against header[lane & 15] gives the code length (lowest matching lane).
 // Lookup = reference Tree::lookup_symbol (src/huffman/tree/mod.rs:63-93): zero bits for a single-symbol
 // code (Q5); an unassigned codeword of an incomplete code reads max_len+1 bits and yields None (Q15).
+#define BRX_HDR_WORDS 32u
 template <bool INL> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) {
-    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 15u)); // per-lane header word
-    u32 h0 = rdl(hv, 0);
+    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 31u)); // lanes 0..15: limits, lanes 16..31: info word and bases
+    u32 h0 = rdl(hv, 16);
     u32 kind = h0 & 3u;
     if (kind == 0u) return LK_NONE;
     if (kind == 1u) {
@@ -335,16 +338,16 @@ template <bool INL> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) 
     u32 peek = in_peek_raw(d) & 0x7fffu;
     if (rem < 15u) peek &= (1u << (u32)rem) - 1u;
     u32 v = __brev(peek) >> 17; // first stream bit = MSB of a 15-bit left-aligned code
-    u64 m = ballot(v < (hv & 0xffffu)) & 0xfffeull; // lanes 1..15 carry limit[1..15]
+    u64 m = ballot((v << 16) < hv) & 0xfffeull; // lanes 1..15 carry limit[1..15] << 16
     if (m == 0ull) {
         u32 maxlen = (h0 >> 8) & 0xffu;
         return rem >= (u64)(maxlen + 1u) ? LK_NONE : LK_EOF;
     }
     u32 L = (u32)__builtin_ctzll(m);
     if ((u64)L > rem) return LK_EOF;
-    u32 base = rdl(hv, L) >> 16;
+    u32 base = rdl(hv, 16u + L);
     u32 idx = ((v >> (15u - L)) + base) & 0xffffu;
-    sym = rfl(tm_ld16<INL>(d, s, (h + 16u) * 2u + idx));
+    sym = rfl(tm_ld16<INL>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
     in_consume(d, L);
     return LK_OK;
 }
@@ -373,11 +376,11 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
     for (u32 l = 1; l <= 15u; l++) {
         u32 c = rdl(cnt, l);
         u32 limit = (code + c) << (15u - l);
-        u32 base = (off - code) & 0xffffu;
         if (lane == l) {
-            hv = limit | (base << 16);
+            hv = limit << 16;
             offv = off;
         }
+        if (lane == 16u + l) hv = off - code; // base[l]
         if (c) {
             maxlen = l;
             present |= 1u << l;
@@ -386,11 +389,11 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
         code = (code + c) << 1;
     }
     u32 nnz = off;
-    u32 h = tm_alloc(d, 16u + ((nnz + 1u) >> 1));
-    if (lane == 0u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[0]: kind | max_len | number of symbols
+    u32 h = tm_alloc(d, BRX_HDR_WORDS + ((nnz + 1u) >> 1));
+    if (lane == 16u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[16]: kind | max_len | number of symbols
     const bool inl = h < BRX_TM_WORDS;
-    if (inl) { if (lane < 16u) tm_st32<true>(d, s, h + lane, hv); }
-    else { if (lane < 16u) tm_st32<false>(d, s, h + lane, hv); }
+    if (inl) { if (lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + lane, hv); }
+    else { if (lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + lane, hv); }
     const u64 lt = (1ull << lane) - 1ull;
     for (u32 c = 0; c < n; c += 64u) {
         u32 i = c + lane;
@@ -408,17 +411,17 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
             if (my == l) slot = run + (u32)__builtin_popcountll(m & lt);
             if (lane == l) offv += (u32)__builtin_popcountll(m);
         }
-        if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + 16u) * 2u + slot, i); }
-        else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + 16u) * 2u + slot, i); }
+        if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
+        else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
     }
     return h;
 }
 
 FI u32 build_single(Dec &d, Lds &s, u32 sym) {
-    u32 h = tm_alloc(d, 16u);
-    u32 w = d.lane == 0u ? (1u | (sym << 16)) : 0u;
-    if (h < BRX_TM_WORDS) { if (d.lane < 16u) tm_st32<true>(d, s, h + d.lane, w); }
-    else { if (d.lane < 16u) tm_st32<false>(d, s, h + d.lane, w); }
+    u32 h = tm_alloc(d, BRX_HDR_WORDS);
+    u32 w = d.lane == 16u ? (1u | (sym << 16)) : 0u;
+    if (h < BRX_TM_WORDS) { if (d.lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + d.lane, w); }
+    else { if (d.lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + d.lane, w); }
     return h;
 }
 
@@ -1058,7 +1061,7 @@ __device__ __noinline__ u32 asm_commands() {
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
           "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
-          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64");
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67");
     return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
@@ -1096,15 +1099,15 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
         u32 why = ok ? 0u : ((m.ntl > 64u || m.ntd > 64u) ? 16u : (m.hl + total > BRX_TM_WORDS) ? 1u : 32u); // (bring-up statistics)
         for (u32 i = 0; i < total; i++) {
             const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
-            if (h_ >= BRX_TM_WORDS - 16u) { ok = 0u; why |= 2u; }
+            if (h_ >= BRX_TM_WORDS - BRX_HDR_WORDS) { ok = 0u; why |= 2u; }
             else {
-                const u32 kind_ = rfl(s.tm[h_]) & 3u; // literal / distance trees may be one-symbol codes
+                const u32 kind_ = rfl(s.tm[h_ + 16u]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
                 if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u; }
                 // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
-                // the left-aligned upper bound of its longest codes is then exactly 2^15
+                // the left-aligned upper bound of its longest codes is then exactly 2^15 (<< 16 in the table)
                 const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
-                const bool full_ = ballot((hvw_ & 0xffffu) == 0x8000u && (d.lane & 15u) != 0u) != 0ull;
+                const bool full_ = ballot(hvw_ == 0x80000000u) != 0ull;
                 if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }
