@@ -206,6 +206,7 @@
     v_readfirstlane_b32 T2, v25                         // bitend
     v_readfirstlane_b32 s48, v27
     v_readfirstlane_b32 s49, v28
+    v_readfirstlane_b32 s50, v29                        // num_records = the stream's capacity: a wild offset is dropped, not a fault
     v_readfirstlane_b32 POS, v30
     v_readfirstlane_b32 SKEW, v31
     v_readfirstlane_b32 VFL, v32
@@ -221,7 +222,6 @@
     ds_read_b32 v25, VZERO offset:LDS_ST+112
     ds_read_b64 v[28:29], VZERO offset:LDS_ST+144       // insert&copy / dictionary info table
     s_and_b32 s49, s49, 0xffff
-    s_mov_b32 s50, -1
     s_mov_b32 s51, 0x00020000
     s_sub_u32 WENDM1, T0, 1
     s_lshr_b32 WSAFE, T2, 5

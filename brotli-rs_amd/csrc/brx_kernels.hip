@@ -296,7 +296,8 @@ FI void dec_load(Dec &d, const Lds &s) {
     d.in_words = (const u32 *)(uintptr_t)get64(s, 0); d.w_end = rfl(s.st[2]);
     d.bitend = get64(s, 5);
     d.out = (u8 *)(uintptr_t)get64(s, 7); d.cap = rfl(s.st[9]);
-    d.out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0xffffffff, 0x00020000); d.pos = rfl(s.st[10]); d.a = rfl(s.st[11]);
+    d.out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.cap, 0x00020000); // range-checked against the capacity
+    d.pos = rfl(s.st[10]); d.a = rfl(s.st[11]);
     d.vfl = rfl(s.st[12]); d.window = rfl(s.st[13]);
     d.dist0 = rfl(s.st[14]); d.dist1 = rfl(s.st[15]); d.dist2 = rfl(s.st[16]); d.dist3 = rfl(s.st[17]);
     d.lds_top = rfl(s.st[18]); d.scr_top = rfl(s.st[19]); d.scratch = (u32 *)(uintptr_t)get64(s, 20);
