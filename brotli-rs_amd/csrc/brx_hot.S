@@ -384,6 +384,11 @@
     v_lshlrev_b32 VVA, 3, VVA
     v_mov_b32 VVB, v30
 .Lcm_not3:
+    // the tables hold (x & 63) << 2: A[p1] | B[p2] is then the byte offset of the context's entry in CMH
+    v_and_b32 VVA, 0x3f3f3f3f, VVA
+    v_and_b32 VVB, 0x3f3f3f3f, VVB
+    v_lshlrev_b32 VVA, 2, VVA
+    v_lshlrev_b32 VVB, 2, VVB
     v_lshlrev_b32 VT0, 2, VLANE
     ds_write_b32 VT0, VVA offset:LDS_ATAB
     ds_write_b32 VT0, VVB offset:LDS_BTAB
@@ -485,11 +490,9 @@
 .Llit:
     s_sub_u32 LBLEN, LBLEN, 1
     s_cbranch_scc1 .Lx_lit_switch
-    // context id -> tree descriptor, all on the vector side: (A[p1] | B[p2]) & 63 indexes CMH
+    // context id -> tree descriptor, all on the vector side: A[p1] | B[p2] (pre-scaled) indexes CMH
     s_waitcnt lgkmcnt(0)
     v_or_b32 VC, VA1, VB2
-    v_and_b32 VC, 63, VC
-    v_lshlrev_b32 VC, 2, VC
     ds_read_b32 VH, VC offset:LDS_CMH
     s_waitcnt lgkmcnt(0)
     v_cmp_gt_i32 vcc, 0, VH
