@@ -1,22 +1,23 @@
 // brx_hot.S -- the command loop of one compressed meta-block, hand-written for gfx950 (CDNA4).
 //
 // Reference states DataMetaBlockBegin .. CopyLiterals (src/lib.rs:2003-2141): insert&copy symbol, extra bits,
-// context-modelled literals, distance symbol / last-distance ring, window copy.  One wavefront = one stream; all
-// decoder state is wave-uniform and lives in SGPRs, the 64 lanes are used as (a) a 256-byte staging buffer of the
-// compressed input (v_readlane feeds the 64-bit bit window), (b) comparators of the canonical prefix-code lookup
-// (lane L holds the left-aligned exclusive upper bound of the length-L codes: one v_cmp + s_ff1 = code length),
+// context-modelled literals, distance symbol / last-distance ring, window copy, dictionary word.  One wavefront = one
+// stream; all decoder state is wave-uniform (SGPRs for what steers control flow, "uniform VGPRs" -- the same value in
+// every lane -- for the bit window and the arithmetic, see TAKE below); the 64 lanes are used as (a) a 256-byte staging
+// buffer of the compressed input (v_readlane feeds the 64-bit bit window), (b) comparators of the canonical prefix-code
+// lookup (lane L holds the left-aligned exclusive upper bound of the length-L codes: one v_cmp + s_ff1 = code length),
 // (c) byte movers of a copy (one byte per lane, LDS ring or buffer_load of the stream's own HBM output).
 //
 // This file is preprocessed (register names) and pasted into ONE asm statement of brx_kernels.hip
 // (asm_commands()).  It talks to the C++ segments only through the parked state in LDS (Lds::st, Lds::mbw):
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
-// Everything unusual leaves through one of those points and is handled by hot_commands() in C++, which runs one
-// command and hands back: block switches, dictionary words with a transform, copies longer than 64 bytes or
+// Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
+// command and hands back: block switches, the two uppercase dictionary transforms, copies longer than 64 bytes or
 // overlapping their source, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
 // (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
 //
-// Preconditions (the HC_START call of hot_commands() / generic_commands() sets mbw[MBW_ASM]): every literal and
+// Preconditions (the HC_START call of generic_commands() sets mbw[MBW_ASM]): every literal and
 // distance tree is a complete general code or a one-symbol code, every insert&copy tree a complete general code, all
 // of them and the context maps resident in LDS table memory, <= 64 literal and <= 64 distance trees, input < 2^28
 // bytes, pos + MLEN <= capacity.  (A ragged flush cursor at entry hands straight back to the C++ side.)
@@ -656,7 +657,7 @@
     s_mov_b32 INS, 0
     s_branch .Lexit
 
-// ---- static dictionary word, identity transform only (src/lib.rs:1506-1540, transformation id 0)
+// ---- static dictionary word (src/lib.rs:1506-1540); identity transform here, the others in .Ldict_xform
 .Ldict:
     s_cmp_lt_u32 CPY, 4
     s_cbranch_scc1 .Lx_r2
@@ -688,7 +689,8 @@
     s_branch .Llit_have
 
 // ======================================================================================================== helpers
-// Land the pending copy in the ring: its bytes sit in lanes 0..PENDN-1 of VPEND (FLAGS bit 2 clear) or VPENB (set).
+// Land the pending copy in the ring: its PENDN bytes sit in lanes 0..PENDN-1 of VPEND (FLAGS bit 2 clear) or VPENB (set)
+// and belong just before stream position PENDEND.
 // Two copies can be in flight: a far copy is requested into the free register BEFORE the older one is waited for
 // (.Lland_[ab]_w1 wait with vmcnt(1): everything but the request just issued).  .Lland also refreshes the literal
 // context (VA1 = A[p1], VB1 = B[p1], VB2 = B[p2]) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
