@@ -140,6 +140,8 @@
 #define VDH4 v64
 #define VDHV v48
 #define VDHB v65
+#define VCLA v68
+#define VCLB v69
 
 // The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
 // ALU issues one instruction per SIMD every 4 cycles and is the bottleneck of this loop (profiles/r01g_pmc.csv), the
@@ -624,6 +626,7 @@
     s_call_b64 LINKB, .Lland_noctx                      // the source may be the pending bytes
     s_bitset0_b32 FLAGS, 2
     s_add_u32 T1, T1, SKEW
+    v_mov_b32 VCLA, VT0
     v_add_u32 VT0, T1, VT0
     v_and_b32 VT0, RMASK, VT0
     ds_read_u8 VPEND, VT0
@@ -632,14 +635,17 @@
     s_sub_u32 T2, DIST, T0
     s_cmp_le_u32 T2, 4096
     s_cbranch_scc1 .Lx_r2                               // straddles the ring edge: rare
-    v_add_u32 VT0, T1, VT0
     s_bitcmp1_b32 FLAGS, 2
     s_cbranch_scc1 .Lcopy_far_b
+    v_mov_b32 VCLB, VT0
+    v_add_u32 VT0, T1, VT0
     buffer_load_ubyte VPENB, VT0, RSRC, 0 offen         // request first, THEN wait for and land the older copy
     s_call_b64 LINKB, .Lland_a_w1
     s_bitset1_b32 FLAGS, 2
     s_branch .Lcopy_issued
 .Lcopy_far_b:
+    v_mov_b32 VCLA, VT0
+    v_add_u32 VT0, T1, VT0
     buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
     s_call_b64 LINKB, .Lland_b_w1
     s_bitset0_b32 FLAGS, 2
@@ -680,8 +686,8 @@
     s_call_b64 LINKB, .Lland_noctx
     s_bitset0_b32 FLAGS, 2
     s_sub_u32 T1, CPY, 1
-    v_min_u32 VT0, T1, VLANE
-    v_add_u32 VT0, T0, VT0
+    v_min_u32 VCLA, T1, VLANE
+    v_add_u32 VT0, T0, VCLA
     global_load_ubyte VPEND, VT0, DICTP
     s_branch .Lcopy_issued
 .Llit_single:                                           // one-symbol tree: no bits
@@ -694,15 +700,14 @@
 // Two copies can be in flight: a far copy is requested into the free register BEFORE the older one is waited for
 // (.Lland_[ab]_w1 wait with vmcnt(1): everything but the request just issued).  .Lland also refreshes the literal
 // context (VA1 = A[p1], VB1 = B[p1], VB2 = B[p2]) from the last two bytes; the _noctx forms leave it stale (a copy follows, or an exit).
-.macro LAND_STORE reg
+// (\cl = min(lane, PENDN - 1), kept from the request: lanes past the end rewrite the last byte in place, so the store
+// needs no lane mask)
+.macro LAND_STORE reg, cl
     s_sub_u32 T6, PENDEND, PENDN
     s_add_u32 T6, T6, SKEW
-    v_add_u32 VT4, T6, VLANE
+    v_add_u32 VT4, T6, \cl
     v_and_b32 VT4, RMASK, VT4
-    s_sub_u32 T7, 64, PENDN
-    s_lshr_b64 exec, -1, T7
     ds_write_b8 VT4, \reg
-    s_mov_b64 exec, -1
     s_mov_b32 PENDN, 0
     s_setpc_b64 LINKB
 .endm
@@ -726,29 +731,29 @@
     s_bitcmp1_b32 FLAGS, 2
     s_cbranch_scc1 .Lland_ctx_b
     LAND_CTX VPEND
-    LAND_STORE VPEND
+    LAND_STORE VPEND, VCLA
 .Lland_ctx_b:
     LAND_CTX VPENB
-    LAND_STORE VPENB
+    LAND_STORE VPENB, VCLB
 .Lland_noctx:
     s_cmp_eq_u32 PENDN, 0
     s_cbranch_scc1 .Lland_ret
     s_waitcnt vmcnt(0) lgkmcnt(0)
     s_bitcmp1_b32 FLAGS, 2
     s_cbranch_scc1 .Lland_store_b
-    LAND_STORE VPEND
+    LAND_STORE VPEND, VCLA
 .Lland_store_b:
-    LAND_STORE VPENB
+    LAND_STORE VPENB, VCLB
 .Lland_a_w1:
     s_cmp_eq_u32 PENDN, 0
     s_cbranch_scc1 .Lland_ret
     s_waitcnt vmcnt(1) lgkmcnt(0)
-    LAND_STORE VPEND
+    LAND_STORE VPEND, VCLA
 .Lland_b_w1:
     s_cmp_eq_u32 PENDN, 0
     s_cbranch_scc1 .Lland_ret
     s_waitcnt vmcnt(1) lgkmcnt(0)
-    LAND_STORE VPENB
+    LAND_STORE VPENB, VCLB
 .Lland_ret:
     s_setpc_b64 LINKB
 // After a transformed dictionary word the last two bytes of the stream may belong to its suffix: land what is pending,
@@ -895,8 +900,8 @@
     s_cbranch_scc1 .Lxf_nomid
     s_add_u32 T0, T0, T5
     s_sub_u32 T4, T7, 1
-    v_min_u32 VT0, T4, VLANE
-    v_add_u32 VT0, T0, VT0
+    v_min_u32 VCLA, T4, VLANE
+    v_add_u32 VT0, T0, VCLA
     global_load_ubyte VPEND, VT0, DICTP
     s_mov_b32 PENDN, T7
 .Lxf_nomid:
