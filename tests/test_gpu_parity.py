@@ -275,3 +275,19 @@ def test_ragged_batch_long_streams_last(ctx):
     assert all(o == exp_small for o in outs[:4096])
     for i in range(32):
         assert hashlib.sha256(outs[4096 + i]).hexdigest() == man[i % len(man)]["sha256"]
+
+
+def test_crafted_context_mode_streams(ctx):
+    """All four literal context modes (LSB6 / MSB6 only exist in these hand-assembled streams) against the independent
+    Python model in tests/craft.py; the long variants run in the assembly loop, the short ones in the C++ loop."""
+    import craft
+    streams, expects = [], []
+    for mode in range(4):
+        for seed in range(12):
+            for n in (6, 300, 1500):
+                s, e = craft.context_mode_stream(mode, seed, n)
+                streams.append(s)
+                expects.append(e)
+    outs, status, out_len = ctx.decode_batch(streams, [len(e) + (i % 17) for i, e in enumerate(expects)])
+    for i, (o, e, st) in enumerate(zip(outs, expects, status)):
+        assert st == 0 and o == e, (i, int(st))

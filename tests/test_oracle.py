@@ -151,3 +151,16 @@ def test_status_strings_match_reference_descriptions():
     assert oracle.status_str(23) == "Run length excceeded declared length of context map"
     assert oracle.status_str(24) == "Encountered unexpected EOF"
     assert oracle.status_str(3) == "More uncompressed bytes than expected in meta-block"
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["LSB6", "MSB6", "UTF8", "SIGNED"])
+def test_crafted_context_mode_streams(mode):
+    """Literal context modes against an independent Python model of the context rules (tests/craft.py); LSB6 / MSB6 are
+    never produced by the encoders at hand, so these hand-assembled streams are their only vectors."""
+    import craft
+    for seed in range(12):
+        for n in (6, 300):
+            stream, expect = craft.context_mode_stream(mode, seed, n)
+            for flags in (0, oracle.FLAG_TREE_WALK):
+                st, out = oracle.decode(stream, flags=flags)[:2]
+                assert st == 0 and out == expect, (mode, seed, n, flags)
