@@ -727,11 +727,47 @@ FI void bulk_copy_1k(Dec &d, Lds &s, u32 de) {
 // write cursor is 16-byte aligned and the effective distance is >= 1024: an overlapping (periodic) copy may use
 // any multiple of its period as distance as soon as that much periodic history exists, so a period-1 or
 // period-43 fill becomes a plain far-enough copy after its first ~1 KiB.
+// A long overlapping copy is a periodic fill.  Once the ring holds one period P (a multiple of the distance AND of 16,
+// <= 1 KiB) ending at a 16-byte aligned cursor, every further 1 KiB block is 64 aligned 16-byte units of that period:
+// lane l reads its unit from the ring and stores it STRAIGHT to HBM -- no ring write, no flush read: one LDS read and
+// one 16 B/lane buffer store per KiB and wave (configs 3/4 of BASELINE.json run at the HBM write rate this way).
+// Afterwards the ring is re-seeded with the last 4 KiB of the output, read back from HBM.
+FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
+    flush_range(d, s, d.vfl, d.pos + d.a);                 // everything up to the cursor is in HBM now
+    const u32 base = d.pos - P + d.a;                      // skewed ring coordinate of the period's first byte
+    u32 o = (16u * d.lane) % P;                            // this lane's unit inside the period, for the first block
+    const u32 step = 1024u % P;
+    for (u32 k = 0; k < nblocks; k++) {
+        const u32x4 q = *(const u32x4 *)&s.ring[(base + o) & RMASK];
+        __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, d.pos + 16u * d.lane, 0, 0);
+        d.pos += 1024u;
+        o += step;
+        o = o >= P ? o - P : o;
+    }
+    d.vfl = d.pos + d.a;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the stores are done before their bytes are read back
+    for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) {
+        const u32 off = d.pos - BRX_RING_BYTES + 1024u * j + 16u * d.lane;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, off, 0, 0);
+        *(u32x4 *)&s.ring[(off + d.a) & RMASK] = q;
+    }
+}
+
 FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
     u32 done = 0, de = dist;
     bool bulk_used = false;
+    // period of an overlapping copy as a multiple of 16: dist * 16 / gcd(dist, 16)
+    const u32 g16 = dist & (0u - dist) & 15u ? (dist & (0u - dist) & 15u) : 16u;
+    const u32 P16 = dist * (16u / g16);
     while (done < len) {
         const u32 rem = len - done;
+        if (dist < len && rem >= 8192u && P16 <= 1024u && done + dist >= P16 && ((d.pos + d.a) & 15u) == 0u) {
+            const u32 nb = rem >> 10;
+            periodic_fill(d, s, P16, nb);
+            done += nb << 10;
+            bulk_used = true;
+            continue;
+        }
         if (rem >= 2048u && de < 1024u) { // grow the distance to a multiple of the period >= 1024
             const u32 target = dist * ((1023u + dist) / dist);
             if (done + dist >= target) de = target;
