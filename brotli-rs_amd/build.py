@@ -22,9 +22,19 @@ def _stale():
 
 
 def build_library(force=False, verbose=False):
-    """Compile csrc/ into brotli-rs_amd/libbrx.so.  Returns the library path."""
+    """Compile csrc/ into brotli-rs_amd/libbrx.so.  Returns the library path.  Safe to call from several processes at
+    once (one rank per GPU): the build is serialised by a lock file and the library is replaced atomically."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    with open(os.path.join(PKG, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():  # another process built it while this one waited
+            return LIB_PATH
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
     if not os.path.exists(HIPCC):
         if os.path.exists(LIB_PATH):
             return LIB_PATH  # GPU box without a need to rebuild: use the prebuilt library that travelled
@@ -39,11 +49,12 @@ def build_library(force=False, verbose=False):
         f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+    tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+    cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
