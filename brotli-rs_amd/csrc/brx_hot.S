@@ -13,8 +13,7 @@
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
-// command and hands back: block switches, the two uppercase dictionary transforms, copies longer than 64 bytes or
-// overlapping their source, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
+// command and hands back: block switches, the two uppercase dictionary transforms, copies longer than 64 bytes, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
 // (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
 //
 // Preconditions (the HC_START call of generic_commands() sets mbw[MBW_ASM]): every literal and
@@ -614,10 +613,10 @@
 
 // ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542)
 .Lcopy:
-    s_min_u32 T0, DIST, 64                              // CPY <= min(64, distance, bytes left) or the C++ side does it
+    s_min_u32 T0, DIST, 64                              // the common case: CPY <= min(64, distance, bytes left)
     s_min_u32 T0, T0, MBLEFT
     s_cmp_gt_u32 CPY, T0
-    s_cbranch_scc1 .Lx_r2
+    s_cbranch_scc1 .Lcopy_overlap
     s_sub_u32 T0, CPY, 1
     v_min_u32 VT0, T0, VLANE                            // switched-off lanes redo the last byte
     s_sub_u32 T1, POS, DIST
@@ -911,6 +910,31 @@
     s_sub_u32 MBLEFT, MBLEFT, CLEN
     s_bitset1_b32 FLAGS, 1                              // literal context: from the ring (see .Lland)
     s_branch .Lcopy_tail
+
+// ---- a copy of <= 64 bytes that overlaps its source (distance < length): out[i] = src[i mod distance] (:1500-1503).
+// The source bytes are final (anything pending is landed first), so this is a near copy with a periodic lane index;
+// lane mod distance by binary long division (lane < 64).  Longer copies go to the C++ side.
+.Lcopy_overlap:
+    s_min_u32 T0, MBLEFT, 64
+    s_cmp_gt_u32 CPY, T0
+    s_cbranch_scc1 .Lx_r2
+    s_call_b64 LINKB, .Lland_noctx
+    s_bitset0_b32 FLAGS, 2
+    s_sub_u32 T0, CPY, 1
+    v_min_u32 VCLA, T0, VLANE
+    v_mov_b32 VT0, VCLA
+    .irp k, 5, 4, 3, 2, 1, 0
+    s_lshl_b32 T2, DIST, \k
+    v_subrev_u32 VT1, T2, VT0
+    v_cmp_le_u32 vcc, T2, VT0
+    v_cndmask_b32 VT0, VT0, VT1, vcc
+    .endr
+    s_sub_u32 T1, POS, DIST
+    s_add_u32 T1, T1, SKEW
+    v_add_u32 VT0, T1, VT0
+    v_and_b32 VT0, RMASK, VT0
+    ds_read_u8 VPEND, VT0
+    s_branch .Lcopy_issued
 
 // ======================================================================================================== exits
 .Lx_r0_switch:                                          // insert&copy block count exhausted (or poisoned)
