@@ -247,6 +247,14 @@ def main():
             other = libbrotlidec_rate(comp, expect)
             if other:
                 res["cpu_libbrotlidec"] = other  # informational: Google's optimized C decoder, if the image has it
+            try:  # informational: the oracle on every host core at once (CPU baseline item b)
+                import subprocess
+                fixture_path = os.path.join(C5 if fixtures[0].startswith("c5_") else GOLD, fixtures[0] + ".compressed")
+                o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), fixture_path, "4"],
+                                   capture_output=True, text=True, timeout=120)
+                res["cpu_all_cores"] = json.loads(o.stdout.strip().splitlines()[-1])
+            except Exception:
+                pass
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
