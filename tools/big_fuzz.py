@@ -24,7 +24,7 @@ bad = 0
 for r in range(rounds):
     datas, streams = [], []
     for it in range(1500):
-        kind = rng.randrange(6)
+        kind = rng.randrange(7)
         if kind == 0:
             base = rng.choice(pool)
             n = rng.randrange(1, min(len(base), 120000) if it % 50 == 0 else 30000)
@@ -40,10 +40,15 @@ for r in range(rounds):
             data = b"".join(base[o:o + 150] for o in (rng.randrange(len(base) - 150) for _ in range(rng.randrange(1, 80))))
         elif kind == 4:
             data = bytes(rng.choice(b"ab\n ") for _ in range(rng.randrange(1, 12000)))
-        else:
+        elif kind == 5:
             base = rng.choice(pool)
             o = rng.randrange(len(base) - 5000)
             data = base[o:o + rng.randrange(1, 5000)].upper() + base[o:o + rng.randrange(1, 3000)].title()
+        else:  # long fills and long far copies: periodic_fill / bulk copy paths
+            unit = bytes(rng.getrandbits(8) for _ in range(rng.choice([1, 2, 3, 5, 16, 43, 64, 100, 257, 1000, 5000])))
+            n = rng.randrange(1, 300000 if it % 10 == 0 else 40000)
+            head = bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 200)))
+            data = head + (unit * (1 + n // len(unit)))[:n] + head[::-1] + (unit[::-1] * 40)[:rng.randrange(0, 20000)]
         npf = rng.choice([None, 0, 1, 2, 3])
         nd = None if npf is None else rng.randrange(0, 16) << npf
         comp = brotli_enc.compress(data, quality=rng.randrange(0, 12), lgwin=rng.randrange(10, 25), mode=rng.randrange(3),
