@@ -13,7 +13,7 @@
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
-// command and hands back: block switches, the two uppercase dictionary transforms, copies longer than 64 bytes, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
+// command and hands back: block switches, copies longer than 64 bytes, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
 // (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
 //
 // Preconditions (the HC_START call of generic_commands() sets mbw[MBW_ASM]): every literal and
@@ -841,7 +841,7 @@
 
 // ---- a transformed word (reference src/transformation/mod.rs, spec Appendix B): prefix + op(word) + suffix with
 // op = identity / OmitFirstN / OmitLastN.  Prefix and suffix (<= 8 bytes each, from the transform record) go to the
-// ring at once; the middle part is an ordinary pending load.  The two uppercase operations go to the C++ side.
+// ring at once; the middle part is an ordinary pending load (the uppercase forms fetch it first, see .Lxf_upper).
 .Ldict_xform:
     s_cmp_gt_u32 T3, 120
     s_cbranch_scc1 .Lx_r2
@@ -855,11 +855,12 @@
     s_bfe_u32 T1, s97, 0x80010                          // op
     s_and_b32 T2, s97, 0xff                             // prefix length
     s_bfe_u32 T3, s97, 0x80008                          // suffix length
-    s_sub_u32 T4, T1, 1
-    s_cmp_lt_u32 T4, 2
-    s_cbranch_scc1 .Lx_r2                               // UppercaseFirst / UppercaseAll
     s_mov_b32 T5, 0                                     // first word byte used
     s_mov_b32 T7, CPY                                   // word bytes used
+    s_bitset0_b32 FLAGS, 5                              // (bit 5: the word is already in VPEND)
+    s_sub_u32 T4, T1, 1
+    s_cmp_lt_u32 T4, 2
+    s_cbranch_scc1 .Lxf_upper                           // UppercaseFirst / UppercaseAll
     s_cmp_lt_u32 T1, 3
     s_cbranch_scc1 .Lxf_have
     s_cmp_ge_u32 T1, 12
@@ -897,12 +898,14 @@
     s_mov_b32 PENDN, 0
     s_cmp_eq_u32 T7, 0
     s_cbranch_scc1 .Lxf_nomid
+    s_mov_b32 PENDN, T7
+    s_bitcmp1_b32 FLAGS, 5
+    s_cbranch_scc1 .Lxf_nomid                           // uppercase forms: loaded and modified above
     s_add_u32 T0, T0, T5
     s_sub_u32 T4, T7, 1
     v_min_u32 VCLA, T4, VLANE
     v_add_u32 VT0, T0, VCLA
     global_load_ubyte VPEND, VT0, DICTP
-    s_mov_b32 PENDN, T7
 .Lxf_nomid:
     s_add_u32 PENDEND, POS, T2
     s_add_u32 PENDEND, PENDEND, T7                      // the pending (middle) bytes end before the suffix
@@ -910,6 +913,53 @@
     s_sub_u32 MBLEFT, MBLEFT, CLEN
     s_bitset1_b32 FLAGS, 1                              // literal context: from the ring (see .Lland)
     s_branch .Lcopy_tail
+// UppercaseFirst / UppercaseAll (src/transformation/mod.rs:3-82): the word is fetched and waited for, one byte per lane
+// (lanes past the end repeat the last byte, see LAND_STORE), and bytes are flipped as the reference does: a-z ^ 32, the
+// second byte of a 2-byte UTF-8 sequence ^ 32, the third of a 3-byte one ^ 5.  A word starting with 0x00 under
+// UppercaseFirst makes the reference panic (Q3): that one goes to the C++ side, which reports status 26.
+.Lxf_upper:
+    s_sub_u32 T4, CPY, 1
+    v_min_u32 VCLA, T4, VLANE
+    v_add_u32 VT0, T0, VCLA
+    global_load_ubyte VPEND, VT0, DICTP
+    s_bitset1_b32 FLAGS, 5
+    v_mov_b32 VT1, 0                                    // xor mask per lane
+    s_mov_b32 T6, 0                                     // i
+    s_waitcnt vmcnt(0)
+.Lxf_up_loop:
+    v_readlane_b32 T4, VPEND, T6                        // b = word[i]
+    s_cmp_lt_u32 T4, 192
+    s_cbranch_scc0 .Lxf_up_multi
+    s_cmp_eq_u32 T1, 1                                  // UppercaseFirst on 0x00: reference panics
+    s_cselect_b32 T0, 1, 0
+    s_cmp_eq_u32 T4, 0
+    s_cselect_b32 T0, T0, 0
+    s_cmp_lg_u32 T0, 0
+    s_cbranch_scc1 .Lx_r2
+    s_sub_u32 T0, T4, 97
+    s_cmp_le_u32 T0, 25
+    s_cselect_b32 T0, 32, 0                             // a-z
+    s_mov_b32 T4, T6                                    // flipped lane
+    s_add_u32 T6, T6, 1
+    s_branch .Lxf_up_mark
+.Lxf_up_multi:
+    s_cmp_lt_u32 T4, 224
+    s_cselect_b32 T0, 32, 5
+    s_cselect_b32 T4, 1, 2
+    s_add_u32 T4, T6, T4                                // lane i + 1 (2-byte sequence) or i + 2 (3-byte)
+    s_add_u32 T6, T4, 1
+.Lxf_up_mark:
+    v_mov_b32 VT0, T0
+    v_cmp_eq_u32 vcc, T4, VCLA
+    v_cndmask_b32 VT0, 0, VT0, vcc
+    v_or_b32 VT1, VT1, VT0
+    s_cmp_eq_u32 T1, 1
+    s_cbranch_scc1 .Lxf_up_done                         // UppercaseFirst: one step
+    s_cmp_lt_u32 T6, CPY
+    s_cbranch_scc1 .Lxf_up_loop
+.Lxf_up_done:
+    v_xor_b32 VPEND, VPEND, VT1
+    s_branch .Lxf_have
 
 // ---- a copy of <= 64 bytes that overlaps its source (distance < length): out[i] = src[i mod distance] (:1500-1503).
 // The source bytes are final (anything pending is landed first), so this is a near copy with a periodic lane index;
