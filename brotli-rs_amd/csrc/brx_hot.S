@@ -13,7 +13,7 @@
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
-// command and hands back: block switches, copies longer than 64 bytes, any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
+// command and hands back: block switches, copies longer than 512 bytes (or long and closer than 64 bytes), any error (the C++ side re-decodes and raises it), the last 256 bits of the stream
 // (so no end-of-input test is needed here: every bit consumed below is a real bit), a ragged first flush block.
 //
 // Preconditions (the HC_START call of generic_commands() sets mbw[MBW_ASM]): every literal and
@@ -967,7 +967,7 @@
 .Lcopy_overlap:
     s_min_u32 T0, MBLEFT, 64
     s_cmp_gt_u32 CPY, T0
-    s_cbranch_scc1 .Lx_r2
+    s_cbranch_scc1 .Lcopy_long
     s_call_b64 LINKB, .Lland_noctx
     s_bitset0_b32 FLAGS, 2
     s_sub_u32 T0, CPY, 1
@@ -985,6 +985,53 @@
     v_and_b32 VT0, RMASK, VT0
     ds_read_u8 VPEND, VT0
     s_branch .Lcopy_issued
+
+// ---- a copy of 65..512 bytes at a distance >= 64: 64-byte chunks, each read (ring or the stream's own HBM output), waited
+// for and written before the next one; nothing stays pending.  Anything longer, closer or straddling the ring edge
+// goes to the C++ side (1 KiB steps, periodic fills).
+.Lcopy_long:
+    s_min_u32 T0, MBLEFT, 512
+    s_cmp_gt_u32 CPY, T0
+    s_cbranch_scc1 .Lx_r2
+    s_cmp_lt_u32 DIST, 64
+    s_cbranch_scc1 .Lx_r2
+    s_sub_u32 T0, DIST, 4097
+    s_cmp_lt_u32 T0, 63
+    s_cbranch_scc1 .Lx_r2                               // 4096 < distance < 4160: a chunk would straddle the ring edge
+    s_call_b64 LINKB, .Lland_noctx
+    s_mov_b32 T5, CPY                                   // bytes left
+.Lcl_chunk:
+    s_min_u32 T0, T5, 64
+    s_sub_u32 T1, T0, 1
+    v_min_u32 VT1, T1, VLANE                            // clamped lane
+    s_sub_u32 T1, POS, DIST
+    s_cmp_gt_u32 DIST, 4096
+    s_cbranch_scc1 .Lcl_far
+    s_add_u32 T1, T1, SKEW
+    v_add_u32 VT0, T1, VT1
+    v_and_b32 VT0, RMASK, VT0
+    ds_read_u8 VT2, VT0
+    s_branch .Lcl_have
+.Lcl_far:
+    v_add_u32 VT0, T1, VT1
+    buffer_load_ubyte VT2, VT0, RSRC, 0 offen
+.Lcl_have:
+    s_add_u32 T1, POS, SKEW
+    v_add_u32 VT0, T1, VT1
+    v_and_b32 VT0, RMASK, VT0
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    ds_write_b8 VT0, VT2
+    s_add_u32 POS, POS, T0
+    s_sub_u32 MBLEFT, MBLEFT, T0
+    s_sub_u32 T5, T5, T0
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc0 .Lcl_noflush
+    s_call_b64 LINKC, .Lflush
+.Lcl_noflush:
+    s_cmp_lg_u32 T5, 0
+    s_cbranch_scc1 .Lcl_chunk
+    s_bitset1_b32 FLAGS, 1                              // literal context: from the ring (see .Lland)
+    s_branch .Lflush_back_cmd
 
 // ======================================================================================================== exits
 .Lx_r0_switch:                                          // insert&copy block count exhausted (or poisoned)
