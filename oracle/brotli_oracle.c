@@ -161,6 +161,11 @@ static int pcode_build(PCode *c, const uint8_t *lengths, const uint16_t *symbols
             }
         }
     }
+    if (g_trace) { /* analysis aid: alphabet size, symbols present, codes per length */
+        fprintf(stderr, "TREE %u %u %u :", n, (unsigned)c->nsym, max_len);
+        for (unsigned l = 1; l <= max_len; l++) fprintf(stderr, " %u", (unsigned)c->count[l]);
+        fprintf(stderr, "\n");
+    }
     return 0;
 }
 

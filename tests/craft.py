@@ -103,3 +103,400 @@ def context_mode_stream(mode, seed, n_cmds=6):
                 out.append(out[-4])
     assert len(out) == mlen
     return b.bytes(), bytes(out)
+
+
+# ======================================================================================================================
+# General hand-assembler (round 2): complex prefix codes, dictionary references with chosen transform ids, quirk streams.
+# Expected behaviour comes from the oracle (tests compare the HIP path with it); what this file guarantees is that the
+# streams reach the code paths they are named after (the tests assert that through the oracle's census / status).
+# ======================================================================================================================
+NDBITS = [0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5]
+INS_BASE = [0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26, 34, 50, 66, 98, 130, 194, 322, 578, 1090, 2114, 6210, 22594]
+INS_EXTRA = [0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24]
+CPY_BASE = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 18, 22, 30, 38, 54, 70, 102, 134, 198, 326, 582, 1094, 2118]
+CPY_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24]
+# insert&copy symbol = 64 * cell + 8 * (insert code & 7) + (copy code & 7); cell by (insert code >> 3, copy code >> 3)
+CELL = {(0, 0): 2, (0, 1): 3, (1, 0): 4, (1, 1): 5, (0, 2): 6, (2, 0): 7, (1, 2): 8, (2, 1): 9, (2, 2): 10}
+
+
+def rev(v, n):
+    r = 0
+    for i in range(n):
+        r |= ((v >> i) & 1) << (n - 1 - i)
+    return r
+
+
+def canonical(lengths):
+    """{symbol: (code, length)} of the canonical prefix code (RFC 1951 rule; symbols ascending within a length)."""
+    maxlen = max(lengths) if lengths else 0
+    bl = [0] * (maxlen + 2)
+    for l in lengths:
+        if l:
+            bl[l] += 1
+    code, nxt = 0, [0] * (maxlen + 2)
+    for bits in range(1, maxlen + 1):
+        code = (code + bl[bits - 1]) << 1
+        nxt[bits] = code
+    out = {}
+    for s, l in enumerate(lengths):
+        if l:
+            out[s] = (nxt[l], l)
+            nxt[l] += 1
+    return out
+
+
+def put_sym(b, codes, sym):
+    """One symbol of a prefix code: first stream bit = MSB of the canonical code."""
+    if len(codes) == 1:
+        return  # one-symbol code: zero bits (SURVEY Q5)
+    code, l = codes[sym]
+    b.put(rev(code, l), l)
+
+
+def _cl_code_lengths(k):
+    """lengths of a complete prefix code over k >= 2 symbols, all <= 5"""
+    m = max(1, (k - 1).bit_length())
+    short = (1 << m) - k
+    return [m - 1] * short + [m] * (k - short)
+
+
+_CL_ORDER = [1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+_CL_FIXED = {0: (0b00, 2), 3: (0b10, 2), 4: (0b01, 2), 2: (0b011, 3), 1: (0b0111, 4), 5: (0b1111, 4)}  # LSB-first fields
+
+
+def complex_code(b, lengths, zero_run_17=False):
+    """Complex prefix code (HSKIP = 0) for the per-symbol `lengths` (0 = absent).  Lengths after the point where the
+    Kraft sum completes must be 0 and are not transmitted.  With zero_run_17 runs of >= 3 zeros use code 17.
+    Returns the canonical {symbol: (code, len)} map."""
+    # tokens of the code-length alphabet
+    toks, total, i, n = [], 0, 0, len(lengths)
+    while i < n and total < 32768:
+        l = lengths[i]
+        if l == 0 and zero_run_17:
+            j = i
+            while j < n and lengths[j] == 0:
+                j += 1
+            if j - i >= 3:  # chained repeat-zero codes, most significant base-8 digit first (src/lib.rs:836-872)
+                reps, digits = j - i - 3, []
+                while True:
+                    digits.append(reps & 7)
+                    reps >>= 3
+                    if reps == 0:
+                        break
+                    reps -= 1
+                for dg in reversed(digits):
+                    toks.append((17, dg))
+                i = j
+                continue
+        toks.append((l, None))
+        if l:
+            total += 32768 >> l
+        i += 1
+    assert all(l == 0 for l in lengths[i:]), "symbols after the code is complete"
+    used = sorted({t[0] for t in toks})
+    cl_len = [0] * 18
+    if len(used) == 1:
+        cl_len[used[0]] = 1  # one code-length symbol: zero bits each (the 18 entries never sum to 32)
+    else:
+        for s, l in zip(used, _cl_code_lengths(len(used))):
+            cl_len[s] = l
+    b.put(0, 2)  # HSKIP = 0 (kind 0 = complex, nothing skipped)
+    acc = 0
+    for s in _CL_ORDER:
+        v, nb = _CL_FIXED[cl_len[s]]
+        b.put(v, nb)
+        if cl_len[s]:
+            acc += 32 >> cl_len[s]
+            if acc == 32:
+                break
+    cl_codes = canonical(cl_len)
+    for s, extra in toks:
+        put_sym(b, cl_codes, s)
+        if s == 17:
+            b.put(extra, 3)
+    return canonical(list(lengths))
+
+
+def uniform_lengths(alphabet, used=None):
+    """A complete code over `used` (default: all) symbols of the alphabet with lengths differing by at most one."""
+    used = list(range(alphabet)) if used is None else sorted(used)
+    k = len(used)
+    m = (k - 1).bit_length()
+    short = (1 << m) - k
+    lens = [0] * alphabet
+    for idx, s in enumerate(used):
+        lens[s] = m - 1 if idx < short else m
+    # canonical order wants the short codes first by symbol value: they are (used is sorted, short ones first)
+    return lens
+
+
+def iac_symbol(insert_len, copy_len):
+    """(symbol, insert extra (value, bits), copy extra (value, bits)) with an EXPLICIT distance (cells 2..10)."""
+    ic = max(c for c in range(24) if INS_BASE[c] <= insert_len)
+    cc = max(c for c in range(24) if CPY_BASE[c] <= copy_len)
+    sym = 64 * CELL[(ic >> 3, cc >> 3)] + 8 * (ic & 7) + (cc & 7)
+    return sym, (insert_len - INS_BASE[ic], INS_EXTRA[ic]), (copy_len - CPY_BASE[cc], CPY_EXTRA[cc])
+
+
+def distance_code(distance, npostfix=0, ndirect=0):
+    """(code, extra value, extra bits) of an explicit distance (no ring codes), RFC 7932 section 4."""
+    if distance <= ndirect:
+        return 15 + distance, 0, 0
+    d = distance - ndirect - 1
+    lcode = d & ((1 << npostfix) - 1)
+    v = (d >> npostfix) + 4  # = offset + extra + 4 = (2 + h) << ndistbits | extra
+    ndistbits = v.bit_length() - 2
+    h = (v >> ndistbits) & 1
+    extra = v & ((1 << ndistbits) - 1)
+    hcode = 2 * (ndistbits - 1) + h
+    code = 16 + ndirect + (hcode << npostfix) + lcode
+    return code, extra, ndistbits
+
+
+class MetaBlock:
+    """One compressed meta-block with one block type per category, one literal tree (all 256 bytes, 8 bits each),
+    a near-uniform insert&copy code over the symbols the commands use and a uniform distance code over the 64 symbols
+    of NPOSTFIX = NDIRECT = 0.  Commands: (literal bytes, copy_len, distance) -- distance None = no copy (last command)."""
+
+    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0):
+        self.commands, self.mlen, self.npostfix, self.ndirect = commands, mlen, npostfix, ndirect
+
+    def emit(self, b, is_last, out_len_hint):
+        mlen = self.mlen if self.mlen is not None else out_len_hint
+        b.put(1 if is_last else 0, 1)
+        if is_last:
+            b.put(0, 1)  # ISLASTEMPTY
+        nib = 4 if mlen <= 1 << 16 else 5 if mlen <= 1 << 20 else 6
+        b.put(nib - 4, 2)
+        b.put(mlen - 1, 4 * nib)
+        if not is_last:
+            b.put(0, 1)  # ISUNCOMPRESSED
+        b.put(0, 1); b.put(0, 1); b.put(0, 1)  # NBLTYPES L / I / D = 1
+        b.put(self.npostfix, 2)
+        b.put(self.ndirect >> self.npostfix, 4)
+        b.put(0, 2)   # context mode LSB6 (irrelevant: one tree)
+        b.put(0, 1)   # NTREESL = 1
+        b.put(0, 1)   # NTREESD = 1
+        lit = complex_code(b, [8] * 256)
+        syms = sorted({iac_symbol(len(l), c if c else 2)[0] for l, c, d in self.commands})
+        if len(syms) == 1:
+            syms.append(syms[0] + 1 if syms[0] + 1 < 704 else syms[0] - 1)  # (a 1-symbol insert&copy code never enters the asm loop)
+        iac = complex_code(b, uniform_lengths(704, syms), zero_run_17=True)
+        dalpha = 16 + self.ndirect + (48 << self.npostfix)
+        dist = complex_code(b, uniform_lengths(dalpha), zero_run_17=False)
+        for lits, cl, d in self.commands:
+            sym, ie, ce = iac_symbol(len(lits), cl if cl else 2)
+            put_sym(b, iac, sym)
+            b.put(*ie)
+            b.put(*ce)
+            for x in lits:
+                put_sym(b, lit, x)
+            if d is not None:
+                code, ev, eb = distance_code(d, self.npostfix, self.ndirect)
+                put_sym(b, dist, code)
+                b.put(ev, eb)
+
+
+def raw_block(b, data):
+    """Uncompressed meta-block (ISLAST = 0)."""
+    assert 0 < len(data) <= 1 << 16
+    b.put(0, 1)
+    b.put(0, 2)
+    b.put(len(data) - 1, 16)
+    b.put(1, 1)  # ISUNCOMPRESSED
+    b.put(0, (-b.n) % 8)
+    for x in data:
+        b.put(x, 8)
+
+
+def stream_header(b, wbits=16):
+    if wbits == 16:
+        b.put(0, 1)
+    elif wbits == 17:
+        b.put(1, 7)      # 1 000 000
+    elif wbits >= 18:
+        b.put(1 | ((wbits - 17) << 1), 4)
+    else:
+        b.put(1 | ((wbits - 8) << 4), 7)  # 1 000 mmm
+
+
+DOFFSET = [0] * 25
+for _n in range(4, 25):
+    DOFFSET[_n] = DOFFSET[_n - 1] + ((_n - 1) << NDBITS[_n - 1] if _n > 4 else 0)
+
+
+def dictionary_stream(word_len, refs, seed, long_form, transform, dictionary, wbits=22, mlen_delta=0, tail=None,
+                      lits_per_ref=None):
+    """Dictionary references of one word length.  refs = [(transform id, word index)].  Every reference is preceded by
+    1..2 literals and followed by the next command's literals, so the literal context after a transformed word is
+    exercised.  long_form: a 3 KiB uncompressed meta-block first (aligns the flush cursor: the commands then run in the
+    assembly loop) and 48 literal-only padding commands at the end (the assembly loop hands the last 256 bits of a
+    stream to the C++ loop).  `transform(tid, word) -> bytes | None` and `dictionary` (the 122 784-byte table) are passed
+    in by the test (the oracle's); the encoder needs the transformed lengths to track the output position, because a
+    reference is addressed as distance = position + 1 + word id.  mlen_delta != 0 declares a wrong MLEN (Q4 tests).
+    Returns (stream, expected output or None when a reference makes the reference decoder panic (Q3))."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    out = bytearray()
+    if long_form:
+        data = bytes(rng.randrange(256) for _ in range(3072))
+        raw_block(b, data)
+        out += data
+    start = len(out)
+    nb = NDBITS[word_len]
+    cmds, panics = [], False
+    for tid, idx in refs:
+        nl = lits_per_ref if lits_per_ref is not None else 1 + rng.randrange(2)
+        lits = bytes(rng.choice(b"ab \xc3\xe4Z\x00") for _ in range(nl))
+        out += lits
+        idx &= (1 << nb) - 1
+        word = dictionary[DOFFSET[word_len] + idx * word_len:DOFFSET[word_len] + (idx + 1) * word_len]
+        cmds.append((lits, word_len, len(out) + 1 + ((tid << nb) | idx)))
+        t = transform(tid, word) if tid <= 120 else b""
+        if t is None:
+            panics = True
+            t = b""
+        out += t
+    ntail = (48 if long_form else 1) if tail is None else tail
+    for k in range(ntail):
+        lits = bytes(rng.randrange(97, 123) for _ in range(6))
+        out += lits
+        if k == ntail - 1:
+            cmds.append((lits, 0, None))  # the meta-block ends after these literals: no copy part
+        else:
+            cmds.append((lits, 2, 7))     # an ordinary 2-byte copy from distance 7
+            out += out[-7:-5]
+    if ntail == 0:  # the last command is a reference whose word ends exactly at MLEN
+        pass
+    MetaBlock(cmds, mlen=len(out) - start + mlen_delta).emit(b, True, 0)
+    return b.bytes(), (None if panics else bytes(out))
+
+
+# ---- quirk streams (SURVEY 2.3): each returns a stream; the test compares the HIP path with the oracle and also pins the
+# status the reading of the reference source predicts (given in the docstrings) --------------------------------------
+def _mb_header(b, mlen, is_last=True):
+    b.put(1 if is_last else 0, 1)
+    if is_last:
+        b.put(0, 1)
+    b.put(0, 2)
+    b.put(mlen - 1, 16)
+    if not is_last:
+        b.put(0, 1)
+
+
+def _nbltypes(b, n):
+    """parse_n_bltypes (src/lib.rs:501-525): 1 -> '0'; 2 -> '1 000'; else 1, 3-bit k, k extra bits: (1 << k) + 1 + e"""
+    if n == 1:
+        b.put(0, 1)
+    elif n == 2:
+        b.put(1, 1); b.put(0, 3)
+    else:
+        k = (n - 1).bit_length() - 1
+        b.put(1, 1); b.put(k, 3); b.put(n - 1 - (1 << k), k)
+
+
+def incomplete_code_stream(kind, pad_ones=64):
+    """Q15: an under-subscribed complex prefix code is accepted when it is built; reading one of its unassigned codewords
+    fails later with the error of the place that reads it.  kind -> expected status:
+      'literal' 21 ParseErrorInsertLiterals, 'iac' 20 ParseErrorInsertAndCopyLength, 'distance' 19 ParseErrorDistanceCode,
+      'context_map' 17 ParseErrorContextMap, 'block_type' 5 InvalidBlockSwitchCommandCode,
+      'block_count' 24 UnexpectedEOF (parse_block_count maps Ok(None) to UnexpectedEOF, src/lib.rs:977).
+    pad_ones: one-bits after the bad codeword (enough of them: the failure is "no such codeword", not end of input)."""
+    b = Bits()
+    stream_header(b, 16)
+    _mb_header(b, 16)
+    two_l = kind in ("block_type", "block_count")
+    if two_l:
+        _nbltypes(b, 2)
+        if kind == "block_type":
+            types = complex_code(b, [1, 2, 0, 0])          # '11' unassigned
+        else:
+            types = None
+            simple_code(b, [0, 1], 2)                       # alphabet NBLTYPES + 2 = 4 -> 2 bits per symbol
+        if kind == "block_count":
+            counts = complex_code(b, [1, 2] + [0] * 24)     # '11' unassigned
+            put_sym(b, counts, 0)                           # first block count: symbol 0 = 1 + 2 extra bits
+        else:
+            simple_code(b, [0], 5)                          # alphabet 26 -> 5 bits; one symbol: zero bits per lookup
+        b.put(0, 2)                                         # extra bits of count symbol 0: block length 1
+    else:
+        _nbltypes(b, 1)
+    _nbltypes(b, 1)
+    _nbltypes(b, 1)
+    b.put(0, 2); b.put(0, 4)                                # NPOSTFIX, NDIRECT
+    for _ in range(2 if two_l else 1):
+        b.put(0, 2)                                         # context modes
+    if kind == "context_map":
+        _nbltypes(b, 2)                                     # NTREESL = 2
+        b.put(0, 1)                                         # RLEMAX = 0
+        complex_code(b, [2, 2])                             # '1x' unassigned
+        b.put(3, 2)                                         # first map entry: unassigned codeword
+        b.put((1 << pad_ones) - 1, pad_ones)
+        return b.bytes()
+    _nbltypes(b, 1)                                         # NTREESL
+    _nbltypes(b, 1)                                         # NTREESD
+    lit = complex_code(b, [8] * 255 + [0] if kind == "literal" else [8] * 256)
+    sym, ie, ce = iac_symbol(2, 4)
+    if kind == "iac":
+        iac = complex_code(b, [0] * sym + [1, 2] + [0] * (704 - sym - 2), zero_run_17=True)
+    else:
+        iac = complex_code(b, uniform_lengths(704, [sym, sym + 1]), zero_run_17=True)
+    if kind == "distance":
+        dist = complex_code(b, [1, 2] + [0] * 62, zero_run_17=True)
+    else:
+        dist = complex_code(b, uniform_lengths(64))
+    if kind == "iac":
+        b.put(3, 2)
+    else:
+        put_sym(b, iac, sym)
+        b.put(*ie); b.put(*ce)
+        if kind == "literal":
+            b.put(0xFF, 8)                                  # codeword 11111111 = the absent 256th symbol
+        else:
+            put_sym(b, lit, 65)                             # first literal; its block count (1) is used up
+            if kind == "block_type":
+                b.put(3, 2)                                 # block switch before the second literal: bad type code
+            elif kind == "block_count":
+                put_sym(b, {0: (0, 1), 1: (1, 1)}, 1)       # type code 1 = next block type (simple code: 1 bit)
+                b.put(3, 2)                                 # then the block count: unassigned codeword
+            elif kind == "distance":
+                put_sym(b, lit, 66)
+                b.put(3, 2)
+    b.put((1 << pad_ones) - 1, pad_ones)
+    return b.bytes()
+
+
+def metadata_skip_stream(skip_bytes_field, payload=b"after the metadata"):
+    """Q2 / Q10: a metadata meta-block with MSKIPBYTES = len(skip_bytes_field) whose MSKIPLEN the reference assembles as
+    byte << i (not << 8 i), then `payload` as an uncompressed meta-block and an empty last meta-block.  The metadata
+    body is sized for the REFERENCE's reading, so the stream decodes to `payload` iff the decoder shares the quirk; a
+    last length byte of 0 with MSKIPBYTES > 1 is UnexpectedEOF (24) in the reference (Q10)."""
+    b = Bits()
+    stream_header(b, 16)
+    b.put(0, 1)              # ISLAST = 0
+    b.put(3, 2)              # MNIBBLES code 3: metadata block
+    b.put(0, 1)              # reserved
+    b.put(len(skip_bytes_field), 2)
+    skip = 0
+    for i, x in enumerate(skip_bytes_field):
+        b.put(x, 8)
+        skip |= x << i       # the reference's arithmetic (src/lib.rs:460-466)
+    skip += 1 if skip_bytes_field else 0
+    b.put(0, (-b.n) % 8)
+    for k in range(skip):
+        b.put((k * 37 + 11) & 0xFF, 8)
+    raw_block(b, payload)
+    b.put(1, 1); b.put(1, 1)  # ISLAST, ISLASTEMPTY
+    return b.bytes()
+
+
+def trailer_nibble_stream(nibbles):
+    """Q10: MNIBBLES = 5 or 6 with a zero top nibble -> NonZeroTrailerNibble (16), src/lib.rs:476-479."""
+    b = Bits()
+    stream_header(b, 16)
+    b.put(1, 1); b.put(0, 1)
+    b.put(nibbles - 4, 2)
+    b.put(0x1234, 4 * nibbles)  # top nibble(s) zero
+    b.put(0, 64)
+    return b.bytes()

@@ -291,3 +291,68 @@ def test_crafted_context_mode_streams(ctx):
     outs, status, out_len = ctx.decode_batch(streams, [len(e) + (i % 17) for i, e in enumerate(expects)])
     for i, (o, e, st) in enumerate(zip(outs, expects, status)):
         assert st == 0 and o == e, (i, int(st))
+
+
+def test_crafted_transform_and_quirk_streams(ctx):
+    """Hand-assembled streams (tests/craft.py): every transform id 0..120 on every word length 4..24 -- OmitFirstN on
+    words shorter than N (Q1), words emptied by OmitLastN, UppercaseFirst on 0x00-led words (Q3 -> status 26), words
+    that end exactly at / one byte past MLEN (Q4), transform id 121 -- each once in a short stream (C++ loop) and once in
+    a long one (assembly loop); MSKIPBYTES 2 and 3 (Q2), zero top nibble / zero last skip byte (Q10), unassigned
+    codewords of incomplete codes at all six reading sites (Q15).  Status and bytes must equal the oracle's; the
+    statuses the streams were built for are pinned by tests/test_craft.py."""
+    import crafted_sets
+    sets = crafted_sets.all_sets()
+    streams = [s for _, s, _, _ in sets]
+    cap = 1 << 16
+    want = [oracle.decode(s, 0, cap=cap) for s in streams]
+    tids = set()
+    for (name, s, st, exp), w in zip(sets, want):
+        assert st is None or w[0] == st, name
+    outs, status, out_len = ctx.decode_batch(streams, cap)
+    bad = [(sets[i][0], w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
+           if w[0] != st or (st == 0 and o != w[1])]
+    assert not bad, bad[:8]
+    # unaligned output slots and exact capacities (the assembly loop needs pos + MLEN <= capacity proven)
+    ok = [(s, w[1]) for s, w in zip(streams, want) if w[0] == 0]
+    outs, status, out_len = ctx.decode_batch([s for s, _ in ok], [len(e) + (i % 5) for i, (_, e) in enumerate(ok)])
+    assert not status.any()
+    assert all(o == e for o, (_, e) in zip(outs, ok))
+
+
+def test_bitflip_fuzz_of_the_long_streams(ctx):
+    """Differential fuzz on the streams that live in the assembly loop and the spill arena: bit flips and truncations of
+    alice29, metablock_reset, compressed_repeated and a 1 MiB config-5 stream; status (and bytes when 0) vs the oracle."""
+    rng = random.Random(20260929)
+    bases = [_read("alice29.txt.compressed"), _read("metablock_reset.compressed"), _read("compressed_repeated.compressed"),
+             open(os.path.join(GOLDEN, "config5", "c5_0.compressed"), "rb").read(), _read("lcet10.txt.compressed")]
+    streams = []
+    for base in bases:
+        for k in range(48):
+            m = bytearray(base)
+            for _ in range(rng.randrange(1, 4)):
+                # half of the flips land in the first 2 KiB (headers, first commands), the rest anywhere
+                hi = min(len(m), 2048) if rng.random() < 0.5 else len(m)
+                pos = rng.randrange(hi * 8)
+                m[pos >> 3] ^= 1 << (pos & 7)
+            if rng.random() < 0.25:
+                m = m[:rng.randrange(len(m) // 2, len(m) + 1)]
+            streams.append(bytes(m))
+    cap = (1 << 20) + 4096
+    want = [oracle.decode(s, 0, cap=cap) for s in streams]
+    outs, status, out_len = ctx.decode_batch(streams, cap)
+    bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
+           if w[0] != st or (st == 0 and o != w[1])]
+    assert not bad, bad[:8]
+    assert sum(1 for w in want if w[0] == 0) > 0 and sum(1 for w in want if w[0] != 0) > 20
+
+
+@pytest.mark.parametrize("stop", ["7", "8"])
+def test_cpp_only_command_loops(stop):
+    """BRX_DEBUG_STOP=8: the C++ command loop alone, whole meta-blocks; =7: re-entered after every single command (the
+    resume points the assembly loop uses).  Same parity subset as the mixed path, in a fresh process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BRX_DEBUG_STOP=stop)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
