@@ -68,12 +68,17 @@ def load_library():
     L.brx_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     L.brx_stream_free.restype = None
     L.brx_stream_free.argtypes = [ctypes.c_void_p]
+    L.brx_host_alloc.restype = ctypes.c_void_p
+    L.brx_host_alloc.argtypes = [ctypes.c_size_t]
+    L.brx_host_free.restype = None
+    L.brx_host_free.argtypes = [ctypes.c_void_p]
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
-                    "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free"]
+                    "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
+                    "brx_host_alloc", "brx_host_free"]
 
 
 def status_str(code: int) -> str:

@@ -1,17 +1,23 @@
 // brx_api.cpp -- host side of the C ABI declared in include/brx.h.
 //
-// Owns the per-GPU context (device copies of the constant tables, the per-wave spill arena, a stream)
-// and implements brx_decode_batch + the Read-shaped stream facade on top of the gfx950 kernel in
-// brx_kernels.hip.  There is deliberately NO CPU decode path in this library: without a HIP device
-// brx_ctx_create fails with BRX_ERR_NO_DEVICE.
+// Owns the per-GPU context (device copies of the constant tables, the spill-slab pool, HIP streams and
+// events, pinned/device staging) and implements brx_decode_batch + the Read-shaped stream facade on top of
+// the gfx950 kernel in brx_kernels.hip.  There is deliberately NO CPU decode path in this library: without
+// a HIP device brx_ctx_create fails with BRX_ERR_NO_DEVICE.
+//
+// Concurrency contract (also stated in brx.h): every entry point may be called from any thread; calls on
+// one context are serialised on the host by a mutex, launches on one context never share a work counter
+// (ring of counters) or a spill slab (slabs are claimed by the waves themselves from a pool), so two
+// BRX_MEM_DEVICE calls on two caller HIP streams may overlap on the device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <algorithm>
 #include <cstring>
-#include <numeric>
+#include <mutex>
 #include <new>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -27,32 +33,69 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess) {
         snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
     else
         snprintf(buf, sizeof buf, "%s", what);
-    g_err = buf;
+    try {
+        g_err = buf;
+    } catch (...) {
+    }
     return code;
 }
 
-#define HIP_TRY(call)                                           \
-    do {                                                        \
-        hipError_t e_ = (call);                                 \
+#define HIP_TRY(call)                                              \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
         if (e_ != hipSuccess) return fail(BRX_ERR_HIP, #call, e_); \
     } while (0)
 
+// Every extern "C" body runs inside this: no C++ exception may cross the C ABI.
+#define BRX_GUARD_BEGIN try {
+#define BRX_GUARD_END(ret_oom, ret_other)                                       \
+    }                                                                           \
+    catch (const std::bad_alloc &) {                                            \
+        fail(BRX_ERR_OUT_OF_MEMORY, "host allocation failed");                  \
+        return ret_oom;                                                         \
+    }                                                                           \
+    catch (...) {                                                               \
+        fail(BRX_ERR_HIP, "unexpected C++ exception inside libbrx");            \
+        return ret_other;                                                       \
+    }
+
+#define BRX_COUNTER_RING 64u   // launches in flight on one context before a work counter is reused
+#define BRX_MAX_CHUNKS 8u      // host-pointer pipeline: H2D / decode / D2H chunks in flight
+#define BRX_STREAM_LIMIT 0xffffff00ull // per-stream output limit of the 32-bit position arithmetic
+
+struct brx_stream;
+
 struct brx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    std::mutex mu;
+    hipStream_t stream = nullptr;                 // decode stream of the host-pointer path / default device-path stream
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr; // copy streams of the chunked host pipeline
     uint8_t *d_dict = nullptr;
     uint8_t *d_lut = nullptr;
     BrxTransform *d_xforms = nullptr;
     uint32_t *d_iac = nullptr;
-    uint32_t *d_counter = nullptr;
-    uint32_t *d_scratch = nullptr;
-    unsigned max_grid = 0; // resident waves we size the spill arena for
+    uint32_t *d_counters = nullptr; // BRX_COUNTER_RING x 64 B
+    uint64_t launch_seq = 0;
+    // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
+    BrxSlabPool *d_pool = nullptr; // device copy of `pool`
+    BrxSlabPool pool = {nullptr, nullptr, 0};
+    unsigned max_grid = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
+    hipEvent_t ev_in[BRX_MAX_CHUNKS] = {}, ev_k[BRX_MAX_CHUNKS] = {};
     bool have_timing = false;
-    // host-mode staging buffers (grown on demand)
+    bool any_launch = false;
+    // options read once from the environment (bring-up switches)
+    uint32_t debug_stop = 0;
+    bool debug_stats = false, debug_stats_all = false, no_order = false;
+    uint32_t dump_interval = 0, dump_max = 0; // BRX_DEBUG_DUMP=interval:max:path (with BRX_DEBUG_STOP=9)
+    std::string dump_path;
+    // host-mode device staging (grown on demand)
     uint8_t *st_in = nullptr, *st_out = nullptr;
-    uint64_t *st_meta = nullptr; // in_off | out_off | out_len, then status
+    uint64_t *st_meta = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_meta_cap = 0;
+    // Read facade: streams created but not yet decoded (decoded together by the first read of any of them)
+    std::vector<brx_stream *> pending;
 };
 
 extern "C" const char *brx_last_error(void) { return g_err.c_str(); }
@@ -92,28 +135,69 @@ extern "C" const char *brx_status_str(int32_t s) {
     return (s >= 0 && s <= 27) ? STR[s] : "unknown status";
 }
 
-extern "C" int brx_ctx_create(brx_ctx **out, int device) {
-    if (!out) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_create: out is NULL");
-    *out = nullptr;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0)
-        return fail(BRX_ERR_NO_DEVICE, "no HIP device: libbrx has no CPU fallback", e);
-    if (device < 0 || device >= ndev) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_create: bad device index");
-    HIP_TRY(hipSetDevice(device));
-    brx_ctx *c = new (std::nothrow) brx_ctx();
-    if (!c) return fail(BRX_ERR_OUT_OF_MEMORY, "brx_ctx_create: host allocation failed");
+static void ctx_release(brx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->s_h2d) (void)hipStreamSynchronize(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamSynchronize(c->s_d2h);
+    if (c->ev_last && c->any_launch) (void)hipEventSynchronize(c->ev_last);
+    (void)hipFree(c->d_dict);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_xforms);
+    (void)hipFree(c->d_iac);
+    (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_pool);
+    (void)hipFree(c->pool.bitmap);
+    (void)hipFree(c->pool.slabs);
+    (void)hipFree(c->st_in);
+    (void)hipFree(c->st_out);
+    (void)hipFree(c->st_meta);
+    for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_in)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_k)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    delete c;
+}
+
+static int ctx_init(brx_ctx *c, int device) {
     c->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     // 16 single-wave workgroups per CU: 4 per SIMD, bounded by the ~10 KiB of LDS each one declares.
     c->max_grid = (unsigned)prop.multiProcessorCount * 16u;
+    {
+        const char *e = getenv("BRX_DEBUG_STOP");
+        c->debug_stop = e ? (uint32_t)atoi(e) : 0u;
+        c->debug_stats = getenv("BRX_DEBUG_STATS") != nullptr;
+        c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
+        c->no_order = getenv("BRX_NO_ORDER") != nullptr;
+        if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
+            unsigned iv = 0, mx = 0;
+            char path[400];
+            if (sscanf(e, "%u:%u:%399s", &iv, &mx, path) == 3 && iv && mx) {
+                c->dump_interval = iv;
+                c->dump_max = mx;
+                c->dump_path = path;
+            }
+        }
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
-    HIP_TRY(hipMalloc(&c->d_counter, 256));
-    HIP_TRY(hipMalloc(&c->d_scratch, (size_t)c->max_grid * BRX_SCRATCH_WORDS * 4u));
+    HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 64u));
+    HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 64u));
+    HIP_TRY(hipMalloc(&c->d_pool, sizeof(BrxSlabPool)));
+    HIP_TRY(hipMemset(c->d_pool, 0, sizeof(BrxSlabPool)));
     HIP_TRY(hipMemcpy(c->d_dict, BRX_DICT, sizeof BRX_DICT, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, BRX_CONTEXT_LUT, sizeof BRX_CONTEXT_LUT, hipMemcpyHostToDevice));
     // 121 transforms, serialized in the spec as prefix\0 op suffix\0 (Appendix B)
@@ -159,27 +243,50 @@ extern "C" int brx_ctx_create(brx_ctx **out, int device) {
         HIP_TRY(hipMemcpy(c->d_iac, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
     for (auto &ev : c->ev) HIP_TRY(hipEventCreate(&ev));
-    *out = c;
+    for (auto &ev : c->ev_in) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ev : c->ev_k) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
     return BRX_SUCCESS;
 }
 
+extern "C" int brx_ctx_create(brx_ctx **out, int device) {
+    BRX_GUARD_BEGIN
+    if (!out) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(BRX_ERR_NO_DEVICE, "no HIP device: libbrx has no CPU fallback", e);
+    if (device < 0 || device >= ndev) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    brx_ctx *c = new (std::nothrow) brx_ctx();
+    if (!c) return fail(BRX_ERR_OUT_OF_MEMORY, "brx_ctx_create: host allocation failed");
+    int rc = ctx_init(c, device);
+    if (rc != BRX_SUCCESS) {
+        std::string keep = g_err;
+        ctx_release(c); // nothing leaks on a failed create
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return BRX_SUCCESS;
+    BRX_GUARD_END(BRX_ERR_OUT_OF_MEMORY, BRX_ERR_HIP)
+}
+
+static void stream_detach(brx_stream *s);
+
 extern "C" void brx_ctx_destroy(brx_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_dict);
-    (void)hipFree(c->d_lut);
-    (void)hipFree(c->d_xforms);
-    (void)hipFree(c->d_iac);
-    (void)hipFree(c->d_counter);
-    (void)hipFree(c->d_scratch);
-    (void)hipFree(c->st_in);
-    (void)hipFree(c->st_out);
-    (void)hipFree(c->st_meta);
-    for (auto &ev : c->ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    try {
+        std::vector<brx_stream *> orphans;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            orphans.swap(c->pending);
+        }
+        for (brx_stream *s : orphans) stream_detach(s);
+    } catch (...) {
+    }
+    ctx_release(c);
 }
 
 static int grow(uint8_t **p, size_t *cap, size_t need) {
@@ -191,6 +298,32 @@ static int grow(uint8_t **p, size_t *cap, size_t need) {
     hipError_t e = hipMalloc(p, want);
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "device staging allocation failed", e);
     *cap = want;
+    return BRX_SUCCESS;
+}
+
+// The spill-slab pool serves tables that do not fit the LDS table memory (worst case 256 trees per category,
+// SURVEY 2.2): 896 KiB per slab, claimed by a wave the first time it spills and released at the end of its
+// stream.  One slab per resident wave of the largest grid launched so far means no wave ever waits for one;
+// nothing is allocated before the first launch and small batches stay small.
+static int ensure_pool(brx_ctx *c, unsigned grid) {
+    unsigned want = 64;
+    while (want < grid) want <<= 1;
+    if (want > c->max_grid) want = ((c->max_grid + 31u) / 32u) * 32u;
+    if (c->pool.slabs && c->pool.count >= want) return BRX_SUCCESS;
+    if (c->any_launch) HIP_TRY(hipEventSynchronize(c->ev_last)); // nobody holds a slab of the old pool any more
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->pool.bitmap);
+    (void)hipFree(c->pool.slabs);
+    c->pool.bitmap = nullptr;
+    c->pool.slabs = nullptr;
+    c->pool.count = 0;
+    hipError_t e = hipMalloc(&c->pool.slabs, (size_t)want * BRX_SCRATCH_WORDS * 4u);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab pool allocation failed", e);
+    e = hipMalloc(&c->pool.bitmap, (size_t)(want / 32u) * 4u);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab bitmap allocation failed", e);
+    HIP_TRY(hipMemset(c->pool.bitmap, 0, (size_t)(want / 32u) * 4u));
+    c->pool.count = want;
+    HIP_TRY(hipMemcpy(c->d_pool, &c->pool, sizeof(BrxSlabPool), hipMemcpyHostToDevice));
     return BRX_SUCCESS;
 }
 
@@ -206,33 +339,52 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.out_len = d_out_len;
     a.status = d_status;
     a.n = n;
-    {
-        const char *e = getenv("BRX_DEBUG_STOP");
-        a.debug_stop = e ? (uint32_t)atoi(e) : 0u;
-    }
-    a.work_counter = c->d_counter;
-    a.scratch = c->d_scratch;
+    a.debug_stop = c->debug_stop;
+    unsigned grid = n < c->max_grid ? n : c->max_grid;
+    int rc = ensure_pool(c, grid);
+    if (rc) return rc;
+    a.work_counter = c->d_counters + (size_t)(c->launch_seq++ % BRX_COUNTER_RING) * 16u; // one 64-B line per launch
+    a.pool = c->d_pool;
     a.debug = nullptr;
     unsigned long long *dbg = nullptr;
-    if (getenv("BRX_DEBUG_STATS")) {
+    if (c->debug_stats) {
         if (hipMalloc(&dbg, (size_t)n * 80) == hipSuccess) { (void)hipMemset(dbg, 0, (size_t)n * 80); a.debug = dbg; }
     }
+    a.dump = nullptr;
+    a.dump_interval = c->dump_interval;
+    a.dump_max = c->dump_max;
+    const size_t dump_bytes = (16u + (size_t)c->dump_max * BRX_DUMP_WORDS) * 4u;
+    if (c->dump_max && c->debug_stop == 9u && hipMalloc(&a.dump, dump_bytes) == hipSuccess) (void)hipMemset(a.dump, 0, 64);
     a.t.dict = c->d_dict;
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    unsigned grid = n < c->max_grid ? n : c->max_grid;
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 4, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
+    HIP_TRY(hipEventRecord(c->ev_last, st));
+    c->any_launch = true;
+    if (a.dump) { // bring-up: parked decoder states for tools/asm_emu.py
+        (void)hipStreamSynchronize(st);
+        std::vector<uint32_t> h(dump_bytes / 4u);
+        (void)hipMemcpy(h.data(), a.dump, dump_bytes, hipMemcpyDeviceToHost);
+        const uint32_t nrec = std::min(h[0], c->dump_max);
+        if (FILE *f = fopen(c->dump_path.c_str(), "ab")) {
+            const uint64_t hdr[4] = {0x31504d5544585242ull /* "BRXDUMP1" */, nrec, (uint64_t)(uintptr_t)d_in, (uint64_t)(uintptr_t)d_out};
+            fwrite(hdr, 8, 4, f);
+            fwrite(h.data() + 16, 4, (size_t)nrec * BRX_DUMP_WORDS, f);
+            fclose(f);
+        }
+        (void)hipFree(a.dump);
+    }
     if (dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h((size_t)n * 10);
         (void)hipMemcpy(h.data(), dbg, (size_t)n * 80, hipMemcpyDeviceToHost);
         static const char *nm[10] = {"hdr", "iac", "lit", "dist", "copy", "ncmd", "nlit", "fastmb", "total", "scr_top"};
-        for (uint32_t i = 0; i < n && i < (getenv("BRX_DEBUG_STATS_ALL") ? n : 2u); i++) {
+        for (uint32_t i = 0; i < n && i < (c->debug_stats_all ? n : 2u); i++) {
             fprintf(stderr, "[brx stats] stream %u:", i);
             for (int q = 0; q < 10; q++) fprintf(stderr, " %s=%llu", nm[q], h[(size_t)i * 10 + q]);
             fprintf(stderr, "\n[brx stats] words:");
@@ -244,28 +396,13 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     return BRX_SUCCESS;
 }
 
-extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
-                                const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_opts *opts) {
-    if (!c) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: ctx is NULL");
-    if (n == 0) return BRX_SUCCESS;
-    if (!in_off || !out_off || !out_len || !status) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: NULL table");
-    const uint32_t flags = opts ? opts->flags : 0u;
-    const bool timing = (flags & BRX_OPT_TIMING) != 0;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (opts && opts->hip_stream) ? (hipStream_t)opts->hip_stream : c->stream;
-    c->have_timing = false;
-
-    if (flags & BRX_MEM_DEVICE) {
-        if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status);
-        if (rc) return rc;
-        if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
-        if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
-        c->have_timing = timing;
-        return BRX_SUCCESS;
-    }
-
-    // ---- host pointers: stage through HBM (H2D, decode, D2H); PCIe time is NOT part of any reported rate
+// ---- host pointers: H2D, decode, D2H ----------------------------------------------------------------------
+// The batch is cut into up to BRX_MAX_CHUNKS runs of consecutive streams; chunk k's input copy, decode kernel and
+// output copy run on three HIP streams chained by events, so the copies of one chunk overlap the kernel of
+// another.  With pinned caller memory (BRX_MEM_HOST_PINNED: brx_host_alloc / hipHostMalloc / hipHostRegister) the
+// copies are true asynchronous DMA; with pageable memory the HIP runtime stages them and the overlap is partial.
+static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
+                       const uint64_t *out_off, uint64_t *out_len, int32_t *status, bool timing) {
     for (uint32_t i = 0; i < n; i++)
         if (in_off[i + 1] < in_off[i] || out_off[i + 1] < out_off[i])
             return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: offsets must be non-decreasing");
@@ -285,32 +422,95 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
     }
     uint64_t *d_in_off = c->st_meta, *d_out_off = c->st_meta + (n + 1), *d_out_len = c->st_meta + 2 * (size_t)(n + 1);
     int32_t *d_status = (int32_t *)(c->st_meta + meta_words);
-    // Work-queue order: longest compressed stream first.  The streams of a batch are ragged; a
-    // stream is a serial job on one wavefront, so the batch finishes when its longest job does -- start those first.
     uint32_t *d_order = (uint32_t *)(d_status + n);
+
+    // chunk boundaries: equal shares of (input + output) bytes, at least 16 MiB per chunk
+    const uint64_t total = (uint64_t)in_bytes + out_bytes;
+    unsigned nchunks = (unsigned)std::min<uint64_t>(BRX_MAX_CHUNKS, std::max<uint64_t>(1, total >> 24));
+    if (n < 2 * nchunks) nchunks = 1;
+    std::vector<uint32_t> cut(nchunks + 1, 0);
+    {
+        uint32_t i = 0;
+        for (unsigned k = 1; k < nchunks; k++) {
+            const uint64_t goal = total * k / nchunks;
+            while (i < n && (in_off[i] - in_lo) + (out_off[i] - out_lo) < goal) i++;
+            cut[k] = i;
+        }
+        cut[nchunks] = n;
+    }
+    // Work-queue order inside a chunk: longest compressed stream first.  A stream is a serial job
+    // on one wavefront, so a chunk finishes when its longest job does -- start those first.
     std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        return in_off[x + 1] - in_off[x] > in_off[y + 1] - in_off[y];
-    });
-    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    if (in_bytes) HIP_TRY(hipMemcpyAsync(c->st_in, in + in_lo, in_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, st));
-    if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-    rc = launch(c, st, timing, c->st_in, d_in_off, n, c->st_out, d_out_off, d_out_len, d_status,
-                getenv("BRX_NO_ORDER") ? nullptr : d_order);
-    if (rc) return rc;
-    if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
-    HIP_TRY(hipMemcpyAsync(out_len, d_out_len, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (out_bytes) HIP_TRY(hipMemcpyAsync(out + out_lo, c->st_out, out_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    c->have_timing = timing;
+    for (unsigned k = 0; k < nchunks; k++) {
+        std::iota(order.begin() + cut[k], order.begin() + cut[k + 1], 0u); // indices are relative to the chunk's first stream
+        if (!c->no_order)
+            std::stable_sort(order.begin() + cut[k], order.begin() + cut[k + 1], [&](uint32_t x, uint32_t y) {
+                const uint32_t gx = cut[k] + x, gy = cut[k] + y;
+                return in_off[gx + 1] - in_off[gx] > in_off[gy + 1] - in_off[gy];
+            });
+    }
+    hipStream_t sk = c->stream;
+    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->s_h2d));
+    HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, c->s_h2d));
+    if (timing) HIP_TRY(hipEventRecord(c->ev[0], sk));
+    for (unsigned k = 0; k < nchunks; k++) {
+        const uint32_t a = cut[k], b = cut[k + 1];
+        if (a == b) continue;
+        const uint64_t i0 = in_off[a] - in_lo, i1 = in_off[b] - in_lo;
+        if (i1 > i0) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipEventRecord(c->ev_in[k], c->s_h2d));
+        HIP_TRY(hipStreamWaitEvent(sk, c->ev_in[k], 0));
+        rc = launch(c, sk, timing && k == 0 && nchunks == 1, c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a,
+                    d_out_len + a, d_status + a, d_order + a);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_k[k], sk));
+        HIP_TRY(hipStreamWaitEvent(c->s_d2h, c->ev_k[k], 0));
+        const uint64_t o0 = out_off[a] - out_lo, o1 = out_off[b] - out_lo;
+        if (o1 > o0) HIP_TRY(hipMemcpyAsync(out + out_lo + o0, c->st_out + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost, c->s_d2h));
+    }
+    if (timing) HIP_TRY(hipEventRecord(c->ev[1], sk));
+    HIP_TRY(hipStreamSynchronize(sk));
+    HIP_TRY(hipMemcpyAsync(out_len, d_out_len, (size_t)n * 8, hipMemcpyDeviceToHost, c->s_d2h));
+    HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)n * 4, hipMemcpyDeviceToHost, c->s_d2h));
+    HIP_TRY(hipStreamSynchronize(c->s_d2h));
+    c->have_timing = timing && nchunks == 1;
     return BRX_SUCCESS;
 }
 
+static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
+                               const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_opts *opts) {
+    const uint32_t flags = opts ? opts->flags : 0u;
+    const bool timing = (flags & BRX_OPT_TIMING) != 0;
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_timing = false;
+    if (flags & BRX_MEM_DEVICE) {
+        hipStream_t st = (opts && opts->hip_stream) ? (hipStream_t)opts->hip_stream : c->stream;
+        if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
+        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status);
+        if (rc) return rc;
+        if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
+        if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
+        c->have_timing = timing;
+        return BRX_SUCCESS;
+    }
+    return decode_host(c, in, in_off, n, out, out_off, out_len, status, timing);
+}
+
+extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
+                                const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_opts *opts) {
+    BRX_GUARD_BEGIN
+    if (!c) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: ctx is NULL");
+    if (n == 0) return BRX_SUCCESS;
+    if (!in_off || !out_off || !out_len || !status) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: NULL table");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return decode_batch_locked(c, in, in_off, n, out, out_off, out_len, status, opts);
+    BRX_GUARD_END(BRX_ERR_OUT_OF_MEMORY, BRX_ERR_HIP)
+}
+
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
-    if (!c || !c->have_timing) return -1.0;
+    if (!c) return -1.0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_timing) return -1.0;
     float ms = 0.f;
     hipError_t e = which == 0 ? hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) : hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
     return e == hipSuccess ? (double)ms : -1.0;
@@ -323,7 +523,24 @@ extern "C" int brx_synchronize(brx_ctx *c, void *hip_stream) {
     return BRX_SUCCESS;
 }
 
-// ---- Read-shaped facade: one object = one stream (reference Decompressor<R>, src/lib.rs:377-410, 2173-2193)
+extern "C" void *brx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail(BRX_ERR_OUT_OF_MEMORY, "hipHostMalloc", e);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void brx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+// ---- Read-shaped facade: one object = one stream (reference Decompressor<R>, src/lib.rs:377-410, 2173-2193) ----------
+// Streams created on one context and not yet read are decoded TOGETHER, as one batch, by the first read of any of
+// them (256 live Decompressors cost about one batch, not 256 launches).  A stream keeps the bytes produced before an
+// error and serves them first, like the reference does.
 struct brx_stream {
     brx_ctx *ctx;
     std::vector<uint8_t> in;
@@ -331,47 +548,121 @@ struct brx_stream {
     size_t served = 0;
     bool decoded = false;
     int32_t status = 0;
+    int lib_rc = BRX_SUCCESS;
 };
 
+static void stream_detach(brx_stream *s) {
+    s->ctx = nullptr;
+    if (!s->decoded) {
+        s->decoded = true;
+        s->lib_rc = BRX_ERR_INVALID_ARGUMENT; // the context went away before the stream was read
+    }
+}
+
 extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n) {
+    BRX_GUARD_BEGIN
     if (!ctx || (n && !in)) {
         fail(BRX_ERR_INVALID_ARGUMENT, "brx_stream_new: bad argument");
         return nullptr;
     }
-    brx_stream *s = new (std::nothrow) brx_stream();
-    if (!s) return nullptr;
+    brx_stream *s = new brx_stream();
     s->ctx = ctx;
-    s->in.assign(in, in + n);
+    try {
+        s->in.assign(in, in + n);
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->pending.push_back(s);
+    } catch (...) {
+        delete s;
+        throw;
+    }
     return s;
+    BRX_GUARD_END(nullptr, nullptr)
+}
+
+// Decode every pending stream of the context in one batch; streams whose guessed capacity was too small go into
+// the next round with the size the kernel asked for (at least x4), up to the 4 GiB - 256 B per-stream limit.
+static void decode_pending_locked(brx_ctx *c) {
+    std::vector<brx_stream *> todo;
+    todo.swap(c->pending);
+    std::vector<size_t> cap(todo.size());
+    for (size_t i = 0; i < todo.size(); i++) cap[i] = todo[i]->in.size() * 8 + 65536;
+    while (!todo.empty()) {
+        const uint32_t n = (uint32_t)std::min<size_t>(todo.size(), 1u << 20);
+        std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0), out_len(n, 0);
+        std::vector<int32_t> st(n, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            in_off[i + 1] = in_off[i] + todo[i]->in.size();
+            out_off[i + 1] = out_off[i] + ((cap[i] + 15) & ~(size_t)15);
+        }
+        std::vector<uint8_t> in((size_t)in_off[n] + 1), out((size_t)out_off[n] + 1);
+        for (uint32_t i = 0; i < n; i++)
+            if (!todo[i]->in.empty()) memcpy(in.data() + in_off[i], todo[i]->in.data(), todo[i]->in.size());
+        int rc = decode_batch_locked(c, in.data(), in_off.data(), n, out.data(), out_off.data(), out_len.data(), st.data(), nullptr);
+        std::vector<brx_stream *> again;
+        std::vector<size_t> again_cap;
+        for (uint32_t i = 0; i < n; i++) {
+            brx_stream *s = todo[i];
+            if (rc != BRX_SUCCESS) {
+                s->lib_rc = rc;
+                s->decoded = true;
+                continue;
+            }
+            if (st[i] == BRX_OUTPUT_TOO_SMALL && cap[i] < BRX_STREAM_LIMIT) {
+                size_t want = std::max<size_t>(cap[i] * 4, (size_t)out_len[i]);
+                again.push_back(s);
+                again_cap.push_back((size_t)std::min<uint64_t>(want, BRX_STREAM_LIMIT));
+                continue;
+            }
+            if (st[i] == BRX_OUTPUT_TOO_SMALL) { // the stream expands past the per-stream limit: a definite error
+                s->lib_rc = BRX_ERR_OUT_OF_MEMORY;
+                s->decoded = true;
+                continue;
+            }
+            s->status = st[i];
+            const size_t produced = (size_t)std::min<uint64_t>(out_len[i], cap[i]);
+            s->out.assign(out.data() + out_off[i], out.data() + out_off[i] + produced);
+            s->decoded = true;
+            std::vector<uint8_t>().swap(s->in);
+        }
+        for (size_t i = n; i < todo.size(); i++) { // (more than 2^20 pending streams: next round)
+            again.push_back(todo[i]);
+            again_cap.push_back(cap[i]);
+        }
+        todo.swap(again);
+        cap.swap(again_cap);
+    }
 }
 
 extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
+    BRX_GUARD_BEGIN
     if (!s) return -(int64_t)BRX_UNEXPECTED_EOF;
     if (!s->decoded) {
-        // Brotli carries no total length: start from a guess and grow on BRX_OUTPUT_TOO_SMALL.
-        size_t cap = s->in.size() * 8 + 65536;
-        for (;;) {
-            s->out.resize(cap);
-            uint64_t in_off[2] = {0, s->in.size()}, out_off[2] = {0, cap}, out_len = 0;
-            int32_t st = 0;
-            int rc = brx_decode_batch(s->ctx, s->in.data(), in_off, 1, s->out.data(), out_off, &out_len, &st, nullptr);
-            if (rc != BRX_SUCCESS) return -(int64_t)1000 + rc; // library failure, not a stream status
-            if (st == BRX_OUTPUT_TOO_SMALL) {
-                cap = cap * 4 > out_len ? cap * 4 : (size_t)out_len;
-                continue;
-            }
-            s->status = st;
-            s->out.resize(st == BRX_OK ? (size_t)out_len : 0); // no partial output on error
-            break;
-        }
-        s->decoded = true;
+        brx_ctx *c = s->ctx;
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!s->decoded) decode_pending_locked(c);
     }
-    if (s->status != BRX_OK) return -(int64_t)s->status;
+    if (s->lib_rc != BRX_SUCCESS) {
+        if (s->lib_rc == BRX_ERR_OUT_OF_MEMORY) fail(s->lib_rc, "stream expands past the 4 GiB - 256 B per-stream output limit (or allocation failed)");
+        return -(int64_t)1000 + s->lib_rc; // library failure, not a stream status
+    }
     size_t n = s->out.size() - s->served;
+    if (n == 0 && s->status != BRX_OK) return -(int64_t)s->status; // after the bytes produced before the error
     if (n > len) n = len;
     if (n) memcpy(buf, s->out.data() + s->served, n);
     s->served += n;
     return (int64_t)n;
+    BRX_GUARD_END(-(int64_t)1000 + BRX_ERR_OUT_OF_MEMORY, -(int64_t)1000 + BRX_ERR_HIP)
 }
 
-extern "C" void brx_stream_free(brx_stream *s) { delete s; }
+extern "C" void brx_stream_free(brx_stream *s) {
+    if (!s) return;
+    try {
+        if (s->ctx && !s->decoded) {
+            std::lock_guard<std::mutex> lk(s->ctx->mu);
+            auto &p = s->ctx->pending;
+            p.erase(std::remove(p.begin(), p.end(), s), p.end());
+        }
+    } catch (...) {
+    }
+    delete s;
+}

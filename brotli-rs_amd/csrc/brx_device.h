@@ -10,9 +10,17 @@
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 1024u      // a block is flushed once the write cursor is this far past its end
 
-// Per-workgroup spill area in HBM for tables that do not fit the LDS table memory (worst case: 256 trees
-// per category).  Sized for the worst case so allocation can never fail mid-stream.
-#define BRX_SCRATCH_WORDS (224u * 1024u) // 896 KiB per resident wave
+// Spill slab in HBM for tables that do not fit the LDS table memory (worst case: 256 trees per category,
+// SURVEY 2.2).  Sized for the worst case so a meta-block can never run out of table memory.  Slabs live in a
+// pool; a wave claims one (atomic bitmap) the first time a stream spills and releases it when the stream ends,
+// so concurrent launches on one context share the pool safely.
+#define BRX_SCRATCH_WORDS (224u * 1024u) // 896 KiB per slab
+
+struct BrxSlabPool {
+    uint32_t *bitmap; // count / 32 words, bit set = slab in use
+    uint32_t *slabs;  // count * BRX_SCRATCH_WORDS
+    uint32_t count;   // multiple of 32
+};
 
 // One static-dictionary word transform (spec Appendix B): prefix + elementary op + suffix.
 struct BrxTransform {
@@ -40,10 +48,16 @@ struct BrxKernelArgs {
     uint32_t n;
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
-    uint32_t *work_counter; // zeroed before every launch
-    uint32_t *scratch;      // gridDim.x * BRX_SCRATCH_WORDS
+    uint32_t *work_counter; // this launch's own counter (ring in brx_ctx), zeroed in-stream before the launch
+    const BrxSlabPool *pool; // spill slabs
     unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr
+    uint32_t *dump;         // bring-up (BRX_DEBUG_DUMP, debug_stop 9): word 0 = records written, then records of
+                            // BRX_DUMP_WORDS words: {stream id, command index, 14 spare, the wave's whole LDS}
+    uint32_t dump_interval, dump_max;
     BrxDeviceTables t;
 };
+
+#define BRX_LDS_BYTES 10240u
+#define BRX_DUMP_WORDS (16u + BRX_LDS_BYTES / 4u)
 
 void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream);

@@ -63,6 +63,7 @@ struct __attribute__((aligned(16))) Lds {
     u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
 };
 
+static_assert(sizeof(Lds) == BRX_LDS_BYTES, "Lds layout");
 // One Lds per workgroup (= per wave).  File scope, so the out-of-line segments address it as LDS directly (a
 // generic Lds* parameter would turn every access into a flat_* instruction).
 __shared__ Lds g_lds;
@@ -120,7 +121,8 @@ struct Dec {
     u32 dist0, dist1, dist2, dist3; // last distances, dist0 most recent
     // table memory
     u32 lds_top, scr_top;
-    u32 *scratch;
+    u32 *scratch;              // this stream's spill slab, nullptr until the first spill (scratch_claim)
+    const BrxSlabPool *pool;
     // per-lane constant vectors
     u32 v_ic; // lanes 0..23: insert length codes, lanes 32..55: copy length codes ((base << 5) | extra bits)
     u32 v_lut0, v_lut1, v_lut2;
@@ -182,6 +184,32 @@ FI void tm_zero_bytes(const Dec &d, Lds &s, u32 ba, u32 n) {
     if (ba < TM_BYTES) { for (u32 k = d.lane; k < n; k += 64u) tm_st8<true>(d, s, ba + k, 0u); }
     else { for (u32 k = d.lane; k < n; k += 64u) tm_st8<false>(d, s, ba + k, 0u); }
 }
+// Spill slabs: claimed from the context's pool the first time a stream needs one, released when the stream ends
+// (scratch_release in the dispatcher).  Wave-uniform; lane 0 does the atomics.  A wave that finds every slab taken
+// waits for one: holders never wait for anything, so this cannot deadlock.
+FI u32 *scratch_claim(const BrxSlabPool *pool) {
+    const u32 nwords = pool->count >> 5;
+    u32 w = (blockIdx.x * 7u) % nwords;
+    for (;;) {
+        u32 got = 0xffffffffu;
+        if (threadIdx.x == 0u) {
+            const u32 cur = __hip_atomic_load(&pool->bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur != 0xffffffffu) {
+                const u32 bit = (u32)__builtin_ctz(~cur);
+                const u32 old = atomicOr(&pool->bitmap[w], 1u << bit);
+                if (((old >> bit) & 1u) == 0u) got = w * 32u + bit;
+            }
+        }
+        got = rfl(got);
+        if (got != 0xffffffffu) return pool->slabs + (size_t)got * BRX_SCRATCH_WORDS;
+        w = w + 1u == nwords ? 0u : w + 1u;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+FI void scratch_release(const BrxSlabPool *pool, const u32 *slab) {
+    const u32 idx = (u32)((size_t)(slab - pool->slabs) / BRX_SCRATCH_WORDS);
+    if (threadIdx.x == 0u) atomicAnd(&pool->bitmap[idx >> 5], ~(1u << (idx & 31u)));
+}
 // Objects never straddle the LDS / HBM boundary.
 FI u32 tm_alloc(Dec &d, u32 nwords) {
     if (d.lds_top + nwords <= BRX_TM_WORDS) {
@@ -189,6 +217,7 @@ FI u32 tm_alloc(Dec &d, u32 nwords) {
         d.lds_top += nwords;
         return r;
     }
+    if (d.scratch == nullptr) d.scratch = scratch_claim(d.pool);
     u32 r = BRX_TM_WORDS + d.scr_top;
     d.scr_top += nwords;
     return r;
@@ -257,6 +286,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_ISLAST 34  // ISLAST of the meta-block handed to the command loop
 #define ST_MLEN 35    // its MLEN
 #define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
+#define ST_POOL 38    // (2 words) const BrxSlabPool *
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
 // generic_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
@@ -289,6 +319,7 @@ FI void dec_store(const Dec &d, Lds &s) {
         s.st[18] = d.lds_top; s.st[19] = d.scr_top; put64(s, 20, (u64)(uintptr_t)d.scratch); s.st[22] = d.needed;
         put64(s, 23, (u64)(uintptr_t)d.t_dict); put64(s, 25, (u64)(uintptr_t)d.t_xforms);
         put64(s, 27, (u64)(uintptr_t)d.t_lut); put64(s, 29, d.wd); put64(s, 31, d.wd_limit);
+        put64(s, ST_POOL, (u64)(uintptr_t)d.pool);
     }
 }
 FI void dec_load(Dec &d, const Lds &s) {
@@ -304,6 +335,7 @@ FI void dec_load(Dec &d, const Lds &s) {
     d.needed = rfl(s.st[22]);
     d.t_dict = (const u8 *)(uintptr_t)get64(s, 23); d.t_xforms = (const BrxTransform *)(uintptr_t)get64(s, 25);
     d.t_lut = (const u32 *)(uintptr_t)get64(s, 27); d.wd = get64(s, 29); d.wd_limit = get64(s, 31);
+    d.pool = (const BrxSlabPool *)(uintptr_t)get64(s, ST_POOL);
     {
         u32 ki = K_INS[d.lane < 24u ? d.lane : 23u], kc = K_COPY[(d.lane - 32u) < 24u ? d.lane - 32u : 23u];
         u32 mi = 0u - (u32)(d.lane < 24u), mc = 0u - (u32)((d.lane - 32u) < 24u); // bitwise selects: branch-free
@@ -1430,12 +1462,12 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             const u8 *inp = a.in + i0;
             const u32 mis = (u32)((uintptr_t)inp & 3u);
             d.in_words = (const u32 *)(inp - mis);
-            const u64 in_len = i1 - i0;
+            const u64 in_len = i1 >= i0 ? i1 - i0 : 0ull; // a decreasing offset table gives an empty stream, never a wild range
             d.w_end = (u32)((mis + in_len + 3u) >> 2);
             d.bitend = 8ull * (mis + in_len);
             d.bitpos = 8ull * mis;
             d.out = a.out + o0;
-            const u64 capacity = o1 - o0;
+            const u64 capacity = o1 >= o0 ? o1 - o0 : 0ull;
             d.cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
             d.pos = 0;
             d.a = (u32)((uintptr_t)d.out & 15u);
@@ -1447,7 +1479,8 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             d.wd_limit = 8ull * in_len + (u64)d.cap + 65536ull;
             d.lds_top = 0;
             d.scr_top = 0;
-            d.scratch = a.scratch + (size_t)blockIdx.x * BRX_SCRATCH_WORDS;
+            d.scratch = nullptr;
+            d.pool = a.pool;
             d.t_dict = a.t.dict;
             d.t_xforms = a.t.xforms;
             d.t_lut = (const u32 *)a.t.context_lut;
@@ -1469,6 +1502,23 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
                 st = generic_commands(HC_START);
                 while (st == HC_CONTINUE) st = generic_commands(HC_RESUME_R1);
+            } else if (a.debug_stop == 9u) { // bring-up: as 7, and every dump_interval-th parked state that the assembly
+                                             // loop could be entered with goes to a.dump (input of tools/asm_emu.py)
+                st = generic_commands(HC_START);
+                u32 k = 0;
+                while (st == HC_CONTINUE) {
+                    if (a.dump != nullptr && rfl(s.mbw[MBW_ASM]) != 0u && (k % a.dump_interval) == 0u) {
+                        u32 slot = rdl(atomicAdd(a.dump, lane == 0u ? 1u : 0u), 0);
+                        if (slot < a.dump_max) {
+                            u32 *rec = a.dump + 16u + (size_t)slot * BRX_DUMP_WORDS;
+                            if (lane == 0u) { rec[0] = sid; rec[1] = k; }
+                            const u32 *src = (const u32 *)&s;
+                            for (u32 w = lane; w < BRX_LDS_BYTES / 4u; w += 64u) rec[16u + w] = src[w];
+                        }
+                    }
+                    k++;
+                    st = generic_commands(HC_RESUME_R1);
+                }
             } else {
                 // The assembly loop (brx_hot.S) with the C++ loop as its safety net.  The C++ side reads the first
                 // insert&copy symbol (exact end-of-input rules) and decides whether the meta-block qualifies; then
@@ -1490,6 +1540,10 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             st = seg_frame();
         }
         seg_finish();
+        {
+            const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
+            if (slab != nullptr) scratch_release(a.pool, slab);
+        }
         u32 pos = rfl(s.st[10]), needed = rfl(s.st[22]);
         if (prof_on && lane < 8u) a.debug[(size_t)sid * 10u + lane] = (u64)s.pad[2 * lane] | ((u64)s.pad[2 * lane + 1] << 32);
         if (prof_on && lane == 0u) {

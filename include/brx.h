@@ -79,7 +79,23 @@ typedef struct brx_opts {
     void *hip_stream; /* hipStream_t to launch on, NULL = the context's own stream */
 } brx_opts;
 
-typedef struct brx_ctx brx_ctx; /* one per (process, GPU): device tables, scratch, a stream */
+typedef struct brx_ctx brx_ctx; /* one per (process, GPU): device tables, spill-slab pool, HIP streams */
+
+/* Threading and ordering contract.
+ *  - Every entry point may be called from any thread.  Calls on ONE context are serialised on the host by a mutex
+ *    (a batch call holds it until its work is enqueued -- and, for host pointers, finished); use one context per
+ *    thread for host-side parallelism.  The reference Decompressor owns all of its state (src/lib.rs:377-394); a
+ *    brx_stream does too once decoded.
+ *  - Launches never share device state that matters: each gets its own work counter, and spill slabs are claimed by
+ *    the waves themselves from a pool, so BRX_MEM_DEVICE calls enqueued on different HIP streams may overlap on the
+ *    device.
+ *  - BRX_MEM_DEVICE with hip_stream == NULL runs on the context's own NON-BLOCKING stream: it is not ordered after
+ *    work on the caller's streams (not even the NULL stream).  Either pass the stream that produced the buffers in
+ *    opts->hip_stream, or synchronise before the call.
+ *  - Offset tables: in_off / out_off must be non-decreasing.  Host tables are checked (BRX_ERR_INVALID_ARGUMENT);
+ *    in device memory a decreasing pair gives that stream an empty input (status 24) or zero capacity (status 25).
+ *  - Per-stream limits of the 32-bit position arithmetic: output < 4 GiB - 256 B (more reports status 25 however
+ *    large the capacity), input < 256 MiB for the fast path. */
 
 /* Create a decoder context on HIP device `device` (0-based).  Fails with BRX_ERR_NO_DEVICE when no GPU is
  * present -- the product path never falls back to a CPU decoder. */
@@ -113,11 +129,22 @@ double brx_last_timing(brx_ctx *ctx, int which);
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
 int brx_synchronize(brx_ctx *ctx, void *hip_stream);
 
+/* Pinned (page-locked) host memory for the host-pointer path.  brx_decode_batch with host pointers cuts the batch
+ * into chunks and pipelines input copy / decode / output copy on three HIP streams; with buffers from
+ * brx_host_alloc (or hipHostMalloc / hipHostRegister) the copies are asynchronous DMA and overlap the kernels, with
+ * pageable memory the HIP runtime stages them and the overlap is partial.  (Ingest shape of the reference's file
+ * walker, src/main.rs:49-70: read files straight into such a buffer, decode, write out.) */
+void *brx_host_alloc(size_t bytes);
+void brx_host_free(void *p);
+
 /* ---- Read-shaped stream facade (one object = one stream, like one reference Decompressor) ----------
- * brx_stream_new copies the compressed bytes; the first brx_stream_read decodes the whole stream on the
- * GPU (batch of one) and later reads serve slices, so:  n>0 bytes read, 0 at end of stream forever after
- * (reference src/lib.rs:2155-2166), -status on a decode error (the reference returns
- * io::ErrorKind::InvalidData carrying brx_status_str(status), src/lib.rs:2177). */
+ * brx_stream_new copies the compressed bytes and queues the stream on its context.  The first brx_stream_read of
+ * ANY queued stream decodes ALL streams queued on that context in one batch (N live Decompressors cost about one
+ * batch, not N launches); later reads serve slices:  n>0 bytes read, 0 at end of stream forever after (reference
+ * src/lib.rs:2155-2166).  For an invalid stream the bytes produced before the error are served first, then every
+ * read returns -status (the reference returns io::ErrorKind::InvalidData carrying brx_status_str(status) after an
+ * unspecified prefix, src/lib.rs:2177).  Values below -900 are library failures (-1000 + BRX_ERR_*),
+ * e.g. a stream that expands past the 4 GiB - 256 B per-stream limit; brx_last_error() has the text. */
 typedef struct brx_stream brx_stream;
 brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);

@@ -836,6 +836,8 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
 
     for (;;) {
         /* parse_insert_and_copy_length :1179-1208 */
+        const uint64_t tr_bit0 = d->br.pos; /* (trace only) */
+        const size_t tr_pos0 = d->pos;
         if ((rc = block_tick(d, &I))) goto out;
         unsigned sym;
         int lk = pcode_lookup(&iac[I.btype], &d->br, &sym);
@@ -852,6 +854,7 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
         size_t copy_len = cb + extra;
         if (mlen < mb_count + insert_len) { rc = BRO_EXCEEDED_EXPECTED_BYTES; goto out; } /* :2036 (Q4) */
         if ((rc = out_room(d, insert_len))) goto out;
+        const uint64_t tr_bit1 = d->br.pos;
 
         /* parse_insert_literals :1286-1365 and the InsertLiterals state :2048-2081 */
         for (size_t k = 0; k < insert_len; k++) {
@@ -876,7 +879,11 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
         d->pos += insert_len;
         mb_count += insert_len;
         d->st.literals += insert_len;
+        if (g_trace && mb_count == mlen)
+            fprintf(stderr, "CMDX %zu %llu %zu %zu %llu %llu\n", tr_pos0, (unsigned long long)tr_bit0, insert_len,
+                    (size_t)copy_len, (unsigned long long)tr_bit1, (unsigned long long)d->br.pos);
         if (mb_count == mlen) break; /* :2069: copy part of the last command is ignored */
+        const uint64_t tr_bit2 = d->br.pos;
 
         /* parse_distance_code :1367-1410 */
         unsigned dcode;
@@ -920,9 +927,16 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
             d->dist[0] = (uint32_t)distance;
         }
 
-        if (g_trace) /* analysis aid (BRO_TRACE=1): one line per command on stderr */
+        if (g_trace) { /* analysis aid (BRO_TRACE=1): one line per command on stderr */
             fprintf(stderr, "CMD %zu %zu %zu %llu\n", d->pos, insert_len, (size_t)copy_len,
                     distance <= max_allowed ? (unsigned long long)distance : 0ull);
+            /* position / bit cursor at the command's start, after the insert&copy fields, after the literals, after
+             * the distance; the raw distance and the last-distance ring after its update (tools/asm_emu.py) */
+            fprintf(stderr, "CMDX %zu %llu %zu %zu %llu %llu %llu %u %llu %u %u %u %u\n", tr_pos0,
+                    (unsigned long long)tr_bit0, insert_len, (size_t)copy_len, (unsigned long long)tr_bit1,
+                    (unsigned long long)tr_bit2, (unsigned long long)d->br.pos, dcode, (unsigned long long)distance,
+                    d->dist[0], d->dist[1], d->dist[2], d->dist[3]);
+        }
         /* copy_literals :1483-1542 and the CopyLiterals state :2102-2141 */
         if (distance <= max_allowed) {
             if (mlen < mb_count + copy_len) { rc = BRO_EXCEEDED_EXPECTED_BYTES; goto out; } /* :2105 */
