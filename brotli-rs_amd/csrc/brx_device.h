@@ -4,11 +4,12 @@
 
 // Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
 #define BRX_WAVE 64
-#define BRX_RING_BYTES 4096u     // LDS sliding-window ring: last 4 KiB of the stream's output
-#define BRX_TM_WORDS 1216u       // LDS table memory (prefix-code tables, context maps): 4864 B -> 10 KiB LDS per wave
+#define BRX_RING_BYTES 2048u     // LDS sliding-window ring: last 2 KiB of the stream's output
+#define BRX_TM_WORDS 1728u       // LDS table memory (prefix-code tables, context maps): 6912 B -> 10 KiB LDS per wave
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
-#define BRX_FLUSH_LAG 1024u      // a block is flushed once the write cursor is this far past its end
+#define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that
+                                 // is still in flight lands before a flush, so no lag is needed)
 
 // Spill slab in HBM for tables that do not fit the LDS table memory (worst case: 256 trees per category,
 // SURVEY 2.2).  Sized for the worst case so a meta-block can never run out of table memory.  Slabs live in a
@@ -34,8 +35,9 @@ struct BrxDeviceTables {
     const uint8_t *dict;        // 122784 B, spec Appendix A
     const uint8_t *context_lut; // Lut0 | Lut1 | Lut2, 3 x 256 B
     const BrxTransform *xforms; // 121 entries
-    const uint32_t *iac;        // insert&copy symbol table for the assembly loop (brx_hot.S): 704 x {insert base,
-                                // extra bits, copy base, extra bits}, then 64 dwords DOFFSET | NDBITS << 24
+    const uint32_t *iac;        // insert&copy symbol records for the assembly loop (brx_hot.S): 704 x {insert base | copy
+                                // base << 16, insert extra bits | copy extra bits << 8 | implicit distance 0 << 16 | total
+                                // extra bits << 24}, then at dword 1408 64 dwords DOFFSET | NDBITS << 24
 };
 
 struct BrxKernelArgs {

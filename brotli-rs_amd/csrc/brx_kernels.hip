@@ -348,19 +348,29 @@ FI void dec_load(Dec &d, const Lds &s) {
 }
 
 // ---- prefix codes ----------------------------------------------------------------------------------------
-// Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols as u16 in
-// (length, symbol) order.
-//   header[L], L = 1..15 : limit[L] << 16, limit[L] = (first_code[L] + count[L]) << (15-L) -- the exclusive upper bound
-//                          of the length-L codes as a left-aligned 31-bit value; header[0] = 0 (never matches)
-//   header[16]           : kind | max_len << 8 | x << 16  (kind 0 empty, 1 one symbol x, 2 general with x symbols)
-//   header[16 + L]       : base[L] = offset[L] - first_code[L] (two's complement): code value + base = symbol index
-// One v_cmp of (bit-reversed window >> 1) against header[lane & 15] gives the code length (lowest matching lane).
+// Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols in (length, symbol)
+// order -- as u16 (literal, insert&copy, block-type / block-count / context-map codes) or as u32 (distance codes, WIDE).
+//   header[2L], L = 1..15   : limit[L] << 16, limit[L] = (first_code[L] + count[L]) << (15-L) -- the exclusive upper bound
+//                             of the length-L codes as a left-aligned 31-bit value; header[0] = 0 (never matches)
+//   header[2L + 1], L = 1..15: base[L] = offset[L] - first_code[L] (two's complement): code value + base = symbol index
+//   header[1]               : kind | max_len << 8 | x << 16  (kind 0 empty, 1 one symbol x, 2 general with x symbols)
+// (limit and base of one length sit side by side: the assembly loop fetches both with one ds_read_b64 per lane.)
+// One v_cmp of (bit-reversed window >> 1) against the limits gives the code length (lowest matching lane).
 // Lookup = reference Tree::lookup_symbol (src/huffman/tree/mod.rs:63-93): zero bits for a single-symbol
 // code (Q5); an unassigned codeword of an incomplete code reads max_len+1 bits and yields None (Q15).
+//
+// Symbol entries hold the plain symbol value when the tables are built.  For a meta-block that qualifies for the
+// assembly loop, prepare_fast_tables() rewrites them in place into the form that loop wants (MBW_ASM = 1; the C++ loop
+// reads the same form then):
+//   literal trees      sym | info << 8, info = the literal's share of the NEXT literal's context id (context_info())
+//   insert&copy trees  sym << 3 = byte offset of the symbol's record in BrxDeviceTables::iac
+//   distance trees     0x80000000 | code for the 16 last-distance codes, else nbits | base << 5 with
+//                      distance = base + (extra << NPOSTFIX)  (decode_distance, src/lib.rs:1412-1481)
 #define BRX_HDR_WORDS 32u
-template <bool INL> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) {
-    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 31u)); // lanes 0..15: limits, lanes 16..31: info word and bases
-    u32 h0 = rdl(hv, 16);
+#define BRX_DIST_UNFIT 0xc0000000u
+template <bool INL, bool WIDE> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) {
+    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 31u)); // even lanes 2L: limits, odd lanes 2L+1: bases, lane 1: info word
+    u32 h0 = rdl(hv, 1);
     u32 kind = h0 & 3u;
     if (kind == 0u) return LK_NONE;
     if (kind == 1u) {
@@ -371,28 +381,32 @@ template <bool INL> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) 
     u32 peek = in_peek_raw(d) & 0x7fffu;
     if (rem < 15u) peek &= (1u << (u32)rem) - 1u;
     u32 v = __brev(peek) >> 17; // first stream bit = MSB of a 15-bit left-aligned code
-    u64 m = ballot((v << 16) < hv) & 0xfffeull; // lanes 1..15 carry limit[1..15] << 16
+    u64 m = ballot((v << 16) < hv) & 0x55555554ull; // lanes 2, 4 .. 30 carry limit[1..15] << 16
     if (m == 0ull) {
         u32 maxlen = (h0 >> 8) & 0xffu;
         return rem >= (u64)(maxlen + 1u) ? LK_NONE : LK_EOF;
     }
-    u32 L = (u32)__builtin_ctzll(m);
+    u32 L = (u32)__builtin_ctzll(m) >> 1;
     if ((u64)L > rem) return LK_EOF;
-    u32 base = rdl(hv, 16u + L);
+    u32 base = rdl(hv, 2u * L + 1u);
     u32 idx = ((v >> (15u - L)) + base) & 0xffffu;
-    sym = rfl(tm_ld16<INL>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
+    sym = WIDE ? rfl(tm_ld32<INL>(d, s, h + BRX_HDR_WORDS + idx)) : rfl(tm_ld16<INL>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
     in_consume(d, L);
     return LK_OK;
 }
 FI u32 decode_sym(Dec &d, const Lds &s, u32 h, u32 &sym) {
-    if (h < BRX_TM_WORDS) return decode_sym_as<true>(d, s, h, sym);
-    return decode_sym_as<false>(d, s, h, sym);
+    if (h < BRX_TM_WORDS) return decode_sym_as<true, false>(d, s, h, sym);
+    return decode_sym_as<false, false>(d, s, h, sym);
+}
+FI u32 decode_sym_wide(Dec &d, const Lds &s, u32 h, u32 &sym) {
+    if (h < BRX_TM_WORDS) return decode_sym_as<true, true>(d, s, h, sym);
+    return decode_sym_as<false, true>(d, s, h, sym);
 }
 
 // Build a general code from s.lens[0..n) (canonical assignment, reference src/huffman/mod.rs:19-43; the
 // bl_count[0] quirk Q7 vanishes under the reference's own masking of the code to `len` bits).
 // Precondition (checked by the callers like the reference does): Kraft sum <= 1, at least 2 non-zero lengths.
-FI u32 build_code(Dec &d, Lds &s, u32 n) {
+FI u32 build_code(Dec &d, Lds &s, u32 n, const bool wide = false) {
     const u32 lane = d.lane;
     u32 cnt = 0; // lane L: number of codes of length L
     for (u32 c = 0; c < n; c += 64u) {
@@ -409,11 +423,9 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
     for (u32 l = 1; l <= 15u; l++) {
         u32 c = rdl(cnt, l);
         u32 limit = (code + c) << (15u - l);
-        if (lane == l) {
-            hv = limit << 16;
-            offv = off;
-        }
-        if (lane == 16u + l) hv = off - code; // base[l]
+        if (lane == 2u * l) hv = limit << 16;
+        if (lane == 2u * l + 1u) hv = off - code; // base[l]
+        if (lane == l) offv = off;
         if (c) {
             maxlen = l;
             present |= 1u << l;
@@ -422,8 +434,8 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
         code = (code + c) << 1;
     }
     u32 nnz = off;
-    u32 h = tm_alloc(d, BRX_HDR_WORDS + ((nnz + 1u) >> 1));
-    if (lane == 16u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[16]: kind | max_len | number of symbols
+    u32 h = tm_alloc(d, BRX_HDR_WORDS + (wide ? nnz : ((nnz + 1u) >> 1)));
+    if (lane == 1u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[1]: kind | max_len | number of symbols
     const bool inl = h < BRX_TM_WORDS;
     if (inl) { if (lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + lane, hv); }
     else { if (lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + lane, hv); }
@@ -444,15 +456,20 @@ FI u32 build_code(Dec &d, Lds &s, u32 n) {
             if (my == l) slot = run + (u32)__builtin_popcountll(m & lt);
             if (lane == l) offv += (u32)__builtin_popcountll(m);
         }
-        if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
-        else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
+        if (wide) {
+            if (inl) { if (slot != 0xffffffffu) tm_st32<true>(d, s, h + BRX_HDR_WORDS + slot, i); }
+            else { if (slot != 0xffffffffu) tm_st32<false>(d, s, h + BRX_HDR_WORDS + slot, i); }
+        } else {
+            if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
+            else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
+        }
     }
     return h;
 }
 
 FI u32 build_single(Dec &d, Lds &s, u32 sym) {
     u32 h = tm_alloc(d, BRX_HDR_WORDS);
-    u32 w = d.lane == 16u ? (1u | (sym << 16)) : 0u;
+    u32 w = d.lane == 1u ? (1u | (sym << 16)) : 0u;
     if (h < BRX_TM_WORDS) { if (d.lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + d.lane, w); }
     else { if (d.lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + d.lane, w); }
     return h;
@@ -603,7 +620,7 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 kind, u32 alphabet) {
 }
 
 // parse_prefix_code, src/lib.rs:877-889 = kind (:589-595) + simple (:597-665, Q8) or complex (:667-875, Q6, Q15)
-FI u32 read_prefix_code(Dec &d, Lds &s, u32 alphabet, u32 &h) {
+FI u32 read_prefix_code(Dec &d, Lds &s, u32 alphabet, u32 &h, const bool wide = false) {
     u32 kind, v;
     if (!in_bits(d, 2, kind)) return ST_EOF;
     if (kind == 1u) { // ---- simple
@@ -652,7 +669,7 @@ FI u32 read_prefix_code(Dec &d, Lds &s, u32 alphabet, u32 &h) {
         u32 rc = read_complex_lens(d, s, kind, alphabet);
         if (rc) return rc;
     }
-    h = build_code(d, s, alphabet);
+    h = build_code(d, s, alphabet, wide);
     return ST_OK;
 }
 
@@ -1093,13 +1110,15 @@ __device__ __noinline__ u32 cold_header() {
             step = which ? S_CODES_INIT : S_NTD;
             continue;
         }
-        if ((rc = read_prefix_code(d, s, alphabet, h))) return rc;
+        // distance codes (the last ntd codes of S_CODE) keep 32-bit symbol entries: room for their payload form
+        if ((rc = read_prefix_code(d, s, alphabet, h, step == S_CODE && idx >= ntl + I.nbl))) return rc;
     }
     const u32 hl = ht, hi = ht + ntl, hd = ht + ntl + I.nbl;
     if (d.lane == 0u) {
         u32 *w = s.mbw;
         w[0] = npostfix; w[1] = ndirect; w[2] = cmode_w; w[3] = cml; w[4] = cmd; w[5] = hl; w[6] = hi; w[7] = hd;
         w[8] = ntl; w[9] = ntd; w[10] = dalpha;
+        w[MBW_ASM] = 0u; // symbol entries are plain symbols until prepare_fast_tables() says otherwise
         w[12] = L.nbl; w[13] = L.btype; w[14] = L.btype_prev; w[15] = L.blen; w[16] = L.h_types; w[17] = L.h_counts;
         w[18] = I.nbl; w[19] = I.btype; w[20] = I.btype_prev; w[21] = I.blen; w[22] = I.h_types; w[23] = I.h_counts;
         w[24] = D.nbl; w[25] = D.btype; w[26] = D.btype_prev; w[27] = D.blen; w[28] = D.h_types; w[29] = D.h_counts;
@@ -1132,6 +1151,76 @@ __device__ __noinline__ u32 asm_commands() {
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
           "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69");
     return rfl(g_lds.mbw[MBW_EXIT]);
+}
+
+// ---- the assembly loop's table forms -------------------------------------------------------------------------------
+// A literal's share of the context id of the literals that follow it (reference parse_insert_literals context rules,
+// src/lib.rs:1309-1338, src/lookuptable/mod.rs:1-56), laid out so that the loop gets the pre-scaled id with two masks:
+//   id * 4 = (info(p1) & MA) | ((info(p2) & MB) << SB)
+//   mode 0 LSB6:   info = (p & 63) << 2                MA 0xfc MB 0    SB 0
+//   mode 1 MSB6:   info = (p >> 2) << 2                MA 0xfc MB 0    SB 0
+//   mode 2 UTF8:   info = Lut0[p] << 2 | Lut1[p]       MA 0xfc MB 3    SB 2
+//   mode 3 signed: info = Lut2[p] << 5 | Lut2[p] << 2  MA 0xe0 MB 0x1c SB 0
+FI u32 context_info(const u8 *lut, u32 mode, u32 b) {
+    if (mode == 0u) return (b & 63u) << 2;
+    if (mode == 1u) return (b >> 2) << 2;
+    if (mode == 2u) return ((u32)lut[b] << 2) | (u32)lut[256u + b];
+    return ((u32)lut[512u + b] << 5) | ((u32)lut[512u + b] << 2);
+}
+// Payload form of one distance symbol (decode_distance, src/lib.rs:1412-1481).  A symbol whose base does not fit (only
+// distances far beyond any window: 24 extra bits and more) becomes BRX_DIST_UNFIT | code: the assembly loop hands such
+// a command to the C++ loop before consuming the symbol, the C++ loop decodes it from the code.
+FI u32 distance_payload(u32 code, u32 npostfix, u32 ndirect) {
+    if (code < 16u) return 0x80000000u | code;
+    if (code < 16u + ndirect) return (code - 15u) << 5;
+    const u32 x = code - ndirect - 16u;
+    const u32 nbits = 1u + (x >> (npostfix + 1u));
+    const u32 hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
+    const u64 offset = ((u64)(2u + (hcode & 1u)) << nbits) - 4ull;
+    const u64 base = (offset << npostfix) + lcode + ndirect + 1u;
+    if (nbits > 24u || base >= (1ull << 26)) return BRX_DIST_UNFIT | code;
+    return nbits | ((u32)base << 5);
+}
+// Rewrite the symbol entries of a qualifying meta-block (all tables resident in LDS) into the assembly loop's forms.
+// `uniform`: every literal block type has context mode `mode`, so the literal entries can carry the context info;
+// otherwise they stay plain bytes and the loop looks the info up per literal (table rebuilt at every block switch).
+// Returns false (nothing rewritten) for the one shape that has no payload form: a ONE-symbol distance tree whose symbol
+// is not a last-distance code (its 16-bit slot in the info word cannot hold a base).
+FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mode, bool uniform) {
+    const u8 *lut = (const u8 *)d.t_lut;
+    for (u32 t = 0; t < m.ntd; t++) {
+        const u32 info = rfl(s.tm[rfl(s.tm[m.hd + t]) + 1u]);
+        if ((info & 3u) == 1u && (info >> 16) >= 16u) return false;
+    }
+    for (u32 t = 0; t < m.ntd; t++) {
+        const u32 h = rfl(s.tm[m.hd + t]);
+        const u32 info = rfl(s.tm[h + 1u]);
+        if ((info & 3u) != 2u) continue; // (a one-symbol tree keeps the plain code in its info word)
+        const u32 nnz = info >> 16;
+        for (u32 k = d.lane; k < nnz; k += 64u) s.tm[h + BRX_HDR_WORDS + k] = distance_payload(s.tm[h + BRX_HDR_WORDS + k], m.npostfix, m.ndirect);
+    }
+    for (u32 t = 0; t < n_iac; t++) {
+        const u32 h = rfl(s.tm[m.hi + t]);
+        const u32 nnz = rfl(s.tm[h + 1u]) >> 16;
+        u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
+        for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 3);
+    }
+    for (u32 t = 0; uniform && t < m.ntl; t++) {
+        const u32 h = rfl(s.tm[m.hl + t]);
+        const u32 info = rfl(s.tm[h + 1u]);
+        if ((info & 3u) == 1u) { // one-symbol tree: the symbol lives in the info word
+            const u32 sym = (info >> 16) & 0xffu;
+            if (d.lane == 0u) s.tm[h + 1u] = (info & 0xffffu) | ((sym | (context_info(lut, mode, sym) << 8)) << 16);
+            continue;
+        }
+        const u32 nnz = info >> 16;
+        u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
+        for (u32 k = d.lane; k < nnz; k += 64u) {
+            const u32 sym = sy[k] & 0xffu;
+            sy[k] = (u16)(sym | (context_info(lut, mode, sym) << 8));
+        }
+    }
+    return true;
 }
 
 // The table-memory command loop (reference states DataMetaBlockBegin .. CopyLiterals, src/lib.rs:2003-2141): every
@@ -1170,19 +1259,27 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
             const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
             if (h_ >= BRX_TM_WORDS - BRX_HDR_WORDS) { ok = 0u; why |= 2u; }
             else {
-                const u32 kind_ = rfl(s.tm[h_ + 16u]) & 3u; // literal / distance trees may be one-symbol codes
+                const u32 kind_ = rfl(s.tm[h_ + 1u]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
                 if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u; }
                 // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
                 // the left-aligned upper bound of its longest codes is then exactly 2^15 (<< 16 in the table)
-                const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
+                const u32 hvw_ = s.tm[h_ + 2u * (d.lane & 15u)];
                 const bool full_ = ballot(hvw_ == 0x80000000u) != 0ull;
                 if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }
+        if (ok) { // one context mode for every literal block type (what encoders emit today): literal entries carry the info
+            bool uniform = true;
+            for (u32 i = 1; i < L.nbl; i++)
+                if (tm_u8(d, s, m.cmode_w * 4u + i) != tm_u8(d, s, m.cmode_w * 4u)) uniform = false;
+            if (!prepare_fast_tables(d, s, m, I.nbl, tm_u8(d, s, m.cmode_w * 4u), uniform)) { ok = 0u; why |= 128u; }
+            else ok = uniform ? 1u : 3u; // bit 1: mixed context modes
+        }
         s.mbw[MBW_ASM] = ok;
         if (!ok) s.pad[8] |= why;
     }
+    const bool fast_tables = rfl(s.mbw[MBW_ASM]) != 0u; // symbol entries are in the assembly loop's forms
 
     // parse_insert_and_copy_length :1179-1208 + decode_insert_and_copy_length :1210-1224
 #define G_DECODE_IAC()                                                                     \
@@ -1193,6 +1290,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
         u32 lk_ = decode_sym(d, s, tm_u32(d, s, m.hi + I.btype), sym_);                    \
         if (lk_ == LK_NONE) return ST_PARSE_IAC;                                           \
         if (lk_ == LK_EOF) return ST_EOF;                                                  \
+        if (fast_tables) sym_ >>= 3;                                                       \
         implicit_zero = sym_ < 128u ? 1u : 0u; /* :2012-2015 */                            \
         u32 cell_ = sym_ >> 6;                                                             \
         u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                  \
@@ -1227,6 +1325,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
                 const u32 lk = decode_sym(d, s, tm_u32(d, s, m.hl + ti), lit);
                 if (lk == LK_NONE) return ST_PARSE_LITERALS;
                 if (lk == LK_EOF) return ST_EOF;
+                lit &= 0xffu; // (fast tables carry the context info in the high byte)
                 ring_put(d, s, d.lane == 0u, d.pos + d.a, lit);
                 d.pos++;
                 p2 = p1;
@@ -1244,12 +1343,21 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
                 if ((rc = cat_tick(d, s, D, sw))) return rc;
                 const u32 cid = copy_len >= 5u ? 3u : copy_len - 2u;
                 const u32 ti = tm_u8(d, s, m.cmd + D.btype * 4u + cid);
-                const u32 lk = decode_sym(d, s, tm_u32(d, s, m.hd + ti), dcode);
+                const u32 lk = decode_sym_wide(d, s, tm_u32(d, s, m.hd + ti), dcode);
                 if (lk == LK_NONE) return ST_PARSE_DISTANCE_CODE;
                 if (lk == LK_EOF) return ST_EOF;
             }
             // ---- decode_distance :1412-1481
-            if (dcode <= 3u) {
+            if (fast_tables && (dcode & BRX_DIST_UNFIT) == BRX_DIST_UNFIT) dcode &= 0xffffu; // plain code: the arithmetic below
+            else if (fast_tables && !implicit_zero && dcode >= 16u && (dcode & 0x80000000u) == 0u) {
+                // payload form of a code >= 16: nbits | base << 5 (one-symbol trees keep the plain code, always < 16 here)
+                u32 e;
+                if (!in_bits(d, dcode & 31u, e)) return ST_EOF;
+                distance = (dcode >> 5) + (e << m.npostfix);
+                dcode = 0x10000u; // (only "not a last-distance code" matters below)
+            } else if (fast_tables) dcode &= 0xffffu;
+            if (dcode == 0x10000u) {
+            } else if (dcode <= 3u) {
                 distance = dcode == 0u ? d.dist0 : dcode == 1u ? d.dist1 : dcode == 2u ? d.dist2 : d.dist3;
             } else if (dcode <= 15u) {
                 long long basev = dcode <= 9u ? (long long)d.dist0 : (long long)d.dist1;
