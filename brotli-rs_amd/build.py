@@ -42,7 +42,8 @@ def _build_locked(verbose):
     gen = os.path.join(CSRC, "_gen", "brx_tables_gen.h")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bin2h.py"), gen, "BRX", "static const"])
     # the hand-written command loop: cpp resolves the register names, the text becomes one asm statement
-    hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp", os.path.join(CSRC, "brx_hot.S")]).decode()
+    prof = ["-DBRX_PROF"] if os.environ.get("BRX_PROF") == "1" else []  # bring-up: timers inside the loop
+    hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + [os.path.join(CSRC, "brx_hot.S")]).decode()
     assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
     with open(os.path.join(CSRC, "_gen", "brx_hot_asm.h"), "w") as f:
         f.write("// generated from brx_hot.S by build.py -- do not edit\n")

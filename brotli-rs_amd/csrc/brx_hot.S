@@ -43,6 +43,7 @@
 #define RING 2048
 // the code-length scratch area (Lds::lens, 768 B) is free during the command loop
 #define LDS_ITAB 8960   // byte -> context info (filled by prepare_fast_tables)
+#define LDS_SPARE 9216  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
 #define LDS_CMH 9472    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
 #define SYMOFF 128      // symbol list of a tree: after its 32 header words
 
@@ -72,17 +73,17 @@
 #define FLUSHAT s55
 #define WINDOW s56
 #define D0 s57
-#define D1 s58
-#define D2 s59
-#define D3 s60
-#define MBLEFT s61
-#define INS s62
-#define CPY s63
+#define INS s92                 // INS, CPY, DCTX and s95 are one insert&copy record (s_load_dwordx4)
+#define CPY s93
+#define MBLEFT s61              // scratch: bytes left in the meta-block = MBEND - POS, computed where needed
 #define IZ s64
 #define LBLEN s65
 #define IBLEN s66
 #define DBLEN s67
 #define P1 s68
+#define MBEND s69
+#define SNAV s70
+#define DCTX s94
 #define HISYM s71
 #define CMDW s72
 #define EXITC s73
@@ -106,7 +107,8 @@
 #define LINKB s[98:99]
 #define LINKC s[100:101]
 // FLAGS bits: 0 = block counters poisoned (near the end of the input), 3 = one literal tree, resident in VLITL / VLITB,
-// 4 = the literal block types differ in context mode (literal entries are plain bytes)
+// 4 = the literal block types differ in context mode (literal entries are plain bytes), 5 = <= 8 literal trees, resident
+// in v70..v85
 // ---- VGPRs (v40-v47 are callee-saved in the AMDGPU calling convention: using them would make the wrapper spill them)
 #define VZERO v0
 #define VLANE v1
@@ -114,6 +116,13 @@
 #define VLANE16 v3
 #define VCHA v4
 #define VCHB v5
+#define VSH v6
+#define VS v7
+#define VLEN v54
+#define VDP v55
+#define VD1 v65
+#define VD2 v68
+#define VD3 v69
 #define VPA v8
 #define VLHOFF v9
 #define VDHOFF v10
@@ -138,7 +147,6 @@
 #define VWIN v[32:33]
 #define VWINLO v32
 #define VWINHI v33
-#define VNAV v34
 #define VI v35
 #define VRF v[36:37]
 #define VRFLO v36
@@ -157,19 +165,27 @@
 #define VIAC v[66:67]
 #define VIACL v66
 #define VIACB v67
+#define VTREES v70          // v70 .. v85: limits / bases of up to 8 resident literal trees (pairs; indexed through M0)
+#define VTREES1 v71
+#define VCMIDX v55          // (entry only) 4 * tree index per context id
+#define VCMAP v86           // lane c: 2 * tree index of context id c (the M0 value of its pair)
 
-// The bit window lives in a VGPR pair (the same value in every lane) and is worked on by the VECTOR ALU: the scalar
-// ALU is shared by the CU's 16 waves and is the scarcer pipe.  Bits are taken from the low end of VWIN; VNAV = number of
-// valid bits (>= 32 after a REFILL_CHECK).  Only values that steer control flow or index lanes are moved to SGPRs.
+// The bit window lives in a VGPR pair (the same value in every lane); bits are taken from the low end of VWIN; SNAV =
+// number of valid bits (>= 32 after a REFILL_CHECK).  What a wave pays is cycles, loaded or alone (under load the chip
+// just clocks lower: 4096 streams take the same ~24 M wave-cycles per alice29 stream as one stream does): ~4.2 per
+// instruction, ~10 per scalar conditional branch that falls through, ~21-25 per taken branch, ~24 for a
+// v_cmp + s_cbranch_vccnz pair, ~50 per LDS / scalar-cache round trip, ~6 more per VGPR <-> SGPR crossing
+// (tools/ubench/issue.hip).  So: branch conditions and counters that only steer control flow live in SGPRs, the
+// arithmetic on the window in uniform VGPRs, and the common path of a command has as few branches as it can.
 // Refill discipline: >= 32 valid bits at .Lcmd; an insert&copy symbol (<= 15) leaves >= 17, enough for a literal or a
 // distance symbol (<= 15); every literal, every extra-bit field > 0 and the distance symbol are followed by a check.
 .macro TAKE n
     v_lshrrev_b64 VWIN, \n, VWIN
-    v_subrev_u32 VNAV, \n, VNAV
+    s_sub_u32 SNAV, SNAV, \n
 .endm
 .macro REFILL_CHECK id
-    v_cmp_gt_u32 vcc, 32, VNAV
-    s_cbranch_vccnz .Lrf_stub_\id
+    s_cmp_lt_u32 SNAV, 32
+    s_cbranch_scc1 .Lrf_stub_\id
 .Lrf_back_\id:
 .endm
 // Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
@@ -179,10 +195,10 @@
     v_mov_b32 VRFHI, 0
     s_nop 1                                             // gfx940+: VALU-written SGPR read by a VALU: 2 wait states
     v_mov_b32 VRFLO, T0
-    v_lshlrev_b64 VRF, VNAV, VRF
+    v_lshlrev_b64 VRF, SNAV, VRF
     v_or_b32 VWINLO, VWINLO, VRFLO
     v_or_b32 VWINHI, VWINHI, VRFHI
-    v_add_u32 VNAV, 32, VNAV
+    s_add_u32 SNAV, SNAV, 32
     s_add_u32 WL, WL, 1
     s_cmp_lg_u32 WL, WLSTOP
     s_cbranch_scc1 .Lrf_back_\id
@@ -204,6 +220,22 @@
     v_add_u32 VI, T3, VI
 .endm
 
+// The same lookup with the symbol fetch taken off the dependent chain: every lane L computes the list index its length
+// would give (per-lane shift VSH = 32 - L) and fetches that entry speculatively; the code length (s_ff1 of the compare)
+// then only selects the lane (v_readlane \rd-result, CLEN) after the LDS round trip.  Candidates of the wrong lengths
+// read harmless addresses (out-of-range LDS reads return 0).  Consumes the code's bits.  Out: CLEN, VS (lane CLEN = the entry).
+.macro LOOKUP2 lim, base, symbase, scale, rd, off
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    v_cmp_lt_u32 vcc, VU, \lim
+    v_lshrrev_b32 VI, VSH, VR
+    v_add_u32 VI, \base, VI
+    v_lshl_add_u32 VI, VI, \scale, \symbase
+    \rd VS, VI offset:\off
+    s_ff1_i32_b32 CLEN, vcc_lo                          // code length
+    TAKE CLEN
+.endm
+
 // ======================================================================================================== entry
     s_waitcnt vmcnt(0) lgkmcnt(0)
     v_mov_b32 VZERO, 0
@@ -212,6 +244,9 @@
     v_and_b32 VLANE8, 15, VLANE
     v_lshlrev_b32 VLANE8, 3, VLANE8
     v_lshlrev_b32 VLANE16, 4, VLANE
+    v_and_b32 VSH, 15, VLANE
+    v_sub_u32 VSH, 32, VSH                              // LOOKUP2: lane L shifts the reversed window by 32 - L
+    v_min_u32 VSH, 31, VSH                              // (lane 0 = "length 0" of a one-symbol tree: index 0 or 1 of its 2-entry list)
     // parked decoder state: st[0..17], st[23..26], st[36..37]
     ds_read_b128 v[20:23], VZERO offset:LDS_ST+0       // in_words lo, hi, w_end, bitpos lo
     ds_read_b128 v[24:27], VZERO offset:LDS_ST+16      // bitpos hi, bitend lo, bitend hi, out lo
@@ -231,7 +266,7 @@
     v_readfirstlane_b32 VFL, v32
     v_readfirstlane_b32 WINDOW, v33
     v_readfirstlane_b32 D0, v34
-    v_readfirstlane_b32 D1, v35
+    v_mov_b32 VD1, v35
     ds_read_b64 v[20:21], VZERO offset:LDS_ST+64        // dist2, dist3
     ds_read_b32 v22, VZERO offset:LDS_ST+92             // t_dict (st[23], st[24]: only 4-byte aligned)
     ds_read_b32 v23, VZERO offset:LDS_ST+96
@@ -259,8 +294,8 @@
     v_lshlrev_b32 VT0, 2, VT0
     global_load_dword VCHB, VT0, INP
     s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 D2, v20
-    v_readfirstlane_b32 D3, v21
+    v_mov_b32 VD2, v20
+    v_mov_b32 VD3, v21
     v_readfirstlane_b32 s76, v22
     v_readfirstlane_b32 s77, v23
     v_readfirstlane_b32 T4, v24
@@ -269,10 +304,10 @@
     v_readfirstlane_b32 s27, v27
     v_readfirstlane_b32 s74, v28
     v_readfirstlane_b32 s75, v29
-    // context LUTs (3 x 64 dwords) and the dictionary info vector (dwords 1408.. of the insert&copy table): lane n =
+    // context LUTs (3 x 64 dwords) and the dictionary info vector (dwords 2816.. of the insert&copy table): lane n =
     // DOFFSET[n] | NDBITS[n] << 24
     v_lshlrev_b32 VT0, 2, VLANE
-    v_add_u32 VT1, 5632, VT0
+    v_add_u32 VT1, 11264, VT0
     s_nop 4                                             // v_readfirstlane -> VMEM address SGPR: 5 wait states
     global_load_dword v28, VT0, s[88:89]                // Lut0
     global_load_dword v29, VT0, s[88:89] offset:256     // Lut1
@@ -291,9 +326,9 @@
     v_readfirstlane_b32 T2, v24                         // cmd
     v_readfirstlane_b32 T6, v25                         // hl
     v_readfirstlane_b32 T7, v26                         // hi
-    v_readfirstlane_b32 s92, v27                        // hd
-    v_readfirstlane_b32 s93, v32                        // ntl
-    v_readfirstlane_b32 s94, v33                        // ntd
+    v_readfirstlane_b32 s12, v27                        // hd
+    v_readfirstlane_b32 s13, v32                        // ntl
+    v_readfirstlane_b32 s14, v33                        // ntd
     ds_read_b32 v20, VZERO offset:LDS_MBW+52            // L.btype
     ds_read_b32 v21, VZERO offset:LDS_MBW+60            // L.blen
     ds_read_b32 v22, VZERO offset:LDS_MBW+76            // I.btype
@@ -302,13 +337,14 @@
     ds_read_b32 v25, VZERO offset:LDS_MBW+108           // D.blen
     ds_read_b128 v[32:35], VZERO offset:LDS_MBW+128     // mb_left, insert_len, copy_len, implicit_zero
     s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 s95, v20                        // L.btype
+    v_readfirstlane_b32 s15, v20                        // L.btype
     v_readfirstlane_b32 LBLEN, v21
     v_readfirstlane_b32 s97, v22                        // I.btype
     v_readfirstlane_b32 IBLEN, v23
     v_readfirstlane_b32 DCODE, v24                      // D.btype (DCODE is free until the first distance)
     v_readfirstlane_b32 DBLEN, v25
     v_readfirstlane_b32 MBLEFT, v32
+    s_add_u32 MBEND, MBLEFT, POS                        // end of the meta-block
     v_readfirstlane_b32 INS, v33
     v_readfirstlane_b32 CPY, v34
     v_readfirstlane_b32 IZ, v35
@@ -316,14 +352,14 @@
     // one-symbol tree (kind 1, zero-bit code, SURVEY Q5) 0x80000000 | x  (literal: x = byte | info << 8)
     s_and_b32 FLAGS, FLAGS, 2
     s_lshl_b32 FLAGS, FLAGS, 3                          // bit 4: mixed context modes
-    s_sub_u32 s93, s93, 1
-    v_min_u32 VT0, s93, VLANE
+    s_sub_u32 s13, s13, 1
+    v_min_u32 VT0, s13, VLANE
     v_add_u32 VT0, T6, VT0
     v_lshlrev_b32 VT0, 2, VT0
     ds_read_b32 VLHOFF, VT0 offset:LDS_TM
-    s_sub_u32 s94, s94, 1
-    v_min_u32 VT0, s94, VLANE
-    v_add_u32 VT0, s92, VT0
+    s_sub_u32 s14, s14, 1
+    v_min_u32 VT0, s14, VLANE
+    v_add_u32 VT0, s12, VT0
     v_lshlrev_b32 VT0, 2, VT0
     ds_read_b32 VDHOFF, VT0 offset:LDS_TM
     s_waitcnt lgkmcnt(0)
@@ -350,7 +386,7 @@
     v_mov_b32 VT0, T7
     ds_read_b32 VT1, VT0 offset:LDS_TM
     // literal context map row of the current block type (64 bytes), distance map word, context mode
-    s_lshl_b32 T6, s95, 6
+    s_lshl_b32 T6, s15, 6
     s_add_u32 T1, T1, T6
     v_add_u32 VT0, T1, VLANE
     ds_read_u8 VT4, VT0 offset:LDS_TM                   // lane c: tree index of context id c
@@ -359,7 +395,7 @@
     v_mov_b32 VT0, T2
     ds_read_b32 VT2, VT0 offset:LDS_TM
     s_lshl_b32 T0, T0, 2
-    s_add_u32 T0, T0, s95
+    s_add_u32 T0, T0, s15
     v_mov_b32 VT0, T0
     ds_read_u8 VT3, VT0 offset:LDS_TM
     s_waitcnt lgkmcnt(0)
@@ -369,6 +405,7 @@
     // CMH[c] = descriptor of the literal tree of context id c; VDH4 lane k = descriptor of the distance tree of
     // distance context k (both for the current block types; a block switch leaves the loop and re-enters here)
     v_lshlrev_b32 VT4, 2, VT4
+    v_mov_b32 VCMIDX, VT4
     ds_bpermute_b32 VT4, VT4, VLHOFF
     v_lshlrev_b32 VT3, 3, VLANE
     v_lshrrev_b32 VT3, VT3, CMDW
@@ -422,8 +459,52 @@
 .Lit_not3:
     v_lshlrev_b32 VT0, 2, VLANE
     ds_write_b32 VT0, VT1 offset:LDS_ITAB
+    // up to 8 literal trees, one context mode: limits and bases live in v70..v85 (pair t = tree t, reached through M0),
+    // lane 16 of a tree's limits carries the LDS address of its symbol list.  A one-symbol tree becomes a real table:
+    // limit[0] = all ones ("matches" at length 0, no bits), a two-entry list [x, x].
+    s_bitcmp1_b32 FLAGS, 4
+    s_cbranch_scc1 .Lent_no_r
+    s_cmp_gt_u32 s13, 7
+    s_cbranch_scc1 .Lent_no_r
+    s_bitset1_b32 FLAGS, 5
+    v_lshrrev_b32 VCMAP, 1, VCMIDX                      // (VCMIDX = 4 * tree index per context id)
+    s_mov_b32 T6, 0
+.Lent_r_loop:
+    v_readlane_b32 T7, VLHOFF, T6                       // descriptor of tree T6
+    s_cmp_lt_i32 T7, 0
+    s_cbranch_scc1 .Lent_r_single
+    v_add_u32 VT0, T7, VLANE8
+    ds_read_b64 VLB, VT0
+    s_add_u32 T7, T7, SYMOFF
+    s_waitcnt lgkmcnt(0)
+    v_writelane_b32 VLIM, T7, 16
+    s_branch .Lent_r_store
+.Lent_r_single:
+    v_mov_b32 VLIM, 0
+    v_mov_b32 VBASE, 0
+    s_mov_b32 T5, -1
+    v_writelane_b32 VLIM, T5, 0
+    s_and_b32 T5, T7, 0xffff                            // x = byte | context info << 8
+    s_lshl_b32 T4, T5, 16
+    s_or_b32 T5, T5, T4
+    s_lshl_b32 T4, T6, 2
+    s_add_u32 T4, T4, LDS_SPARE
+    v_mov_b32 VT0, T4
+    v_mov_b32 VT1, T5
+    ds_write_b32 VT0, VT1
+    v_writelane_b32 VLIM, T4, 16
+.Lent_r_store:
+    s_lshl_b32 T4, T6, 1
+    s_set_gpr_idx_on T4, 8                              // VGPR index mode, destination + T4 (gfx9 has no v_movrel)
+    v_mov_b32 VTREES, VLIM
+    v_mov_b32 VTREES1, VBASE
+    s_set_gpr_idx_off
+    s_add_u32 T6, T6, 1
+    s_cmp_le_u32 T6, s13
+    s_cbranch_scc1 .Lent_r_loop
+.Lent_no_r:
     // one literal tree (and a general one): keep it in registers, no contexts
-    s_cmp_lg_u32 s93, 0
+    s_cmp_lg_u32 s13, 0
     s_cbranch_scc1 .Lent_multi
     v_readfirstlane_b32 T6, VLHOFF
     s_cmp_lt_i32 T6, 0
@@ -438,16 +519,27 @@
     v_readlane_b32 s36, VCHA, 0
     v_readlane_b32 s37, VCHA, 1
     s_lshr_b64 s[36:37], s[36:37], T3
-    s_sub_u32 s38, 64, T3
+    s_sub_u32 SNAV, 64, T3
     v_mov_b32 VWINLO, s36
     v_mov_b32 VWINHI, s37
-    v_mov_b32 VNAV, s38
     s_mov_b32 WL, 2
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
     s_min_u32 WLSTOP, T0, 64
+#ifdef BRX_PROF
+    s_mov_b32 s20, 0
+    s_mov_b32 s21, 0
+    s_mov_b32 s22, 0
+    s_memtime s[12:13]
+#endif
     s_mov_b32 PFREE, 0
     s_mov_b32 PBASE, POS
+    s_sub_u32 DCTX, CPY, 2                              // distance context of the parked command; 4 = implicit distance 0
+    s_min_u32 DCTX, DCTX, 3
+    s_cmp_lg_u32 IZ, 0
+    s_cselect_b32 DCTX, 4, DCTX
+    s_mov_b32 T0, 0xc0000000
+    v_writelane_b32 VDH4, T0, 4                         // "tree" of an implicit distance code 0
     s_mov_b32 EXITC, 1
     s_and_b32 T0, VFL, 0xfffffc00
     s_add_u32 T0, T0, 1024                              // BRX_FLUSH_BLOCK + BRX_FLUSH_LAG
@@ -465,26 +557,18 @@
 .Lcmd:
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
-    LOOKUP VIACL, VIACB
-    v_lshl_add_u32 VT0, VI, 1, HISYM
-    ds_read_u16 VT0, VT0
-    TAKE CLEN
+    LOOKUP2 VIACL, VIACB, HISYM, 1, ds_read_u16, 0
     s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 T0, VT0                         // byte offset of the symbol's record in the insert&copy table
-    s_load_dwordx2 s[92:93], IACTAB, T0                 // insert base | copy base << 16,  extra-bit counts | flags
+    v_readlane_b32 T0, VS, CLEN                         // byte offset of the symbol's record in the insert&copy table
+    s_load_dwordx4 s[92:95], IACTAB, T0                 // = INS base, CPY base, DCTX, extra-bit counts
     s_waitcnt lgkmcnt(0)
-    s_and_b32 INS, s92, 0xffff
-    s_lshr_b32 CPY, s92, 16
-    s_bfe_u32 IZ, s93, 0x10010                          // implicit distance code 0 (:2012-2015)
-    s_lshr_b32 T1, s93, 24                              // extra bits of both fields
+    s_cmp_lg_u32 s95, 0
     s_cbranch_scc1 .Liac_extras                         // (three commands in ten on text)
 
 // ======================================================================================================== R1
 .Lr1:
-    // the distance tree depends on the copy length only: request its limits / bases now, use them after the literals
-    s_sub_u32 T0, CPY, 2
-    s_min_u32 T0, T0, 3                                 // distance context
-    v_readlane_b32 DTREE, VDH4, T0
+    // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
+    v_readlane_b32 DTREE, VDH4, DCTX
     s_max_i32 T0, DTREE, 0                              // (a one-symbol tree has no header: read anything)
     v_add_u32 VT0, T0, VLANE8
     ds_read_b64 VDH, VT0
@@ -492,43 +576,40 @@
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
     s_min_u32 MAXA, POS, WINDOW
-    s_cmp_lg_u32 IZ, 0
-    s_cbranch_scc1 .Ldist_zero
+    s_cmp_lt_i32 DTREE, 0
+    s_cbranch_scc1 .Ldist_special                       // implicit distance 0, or a one-symbol tree
     // ---- distance symbol (reference parse_distance_code :1367-1410)
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
-    s_cmp_lt_i32 DTREE, 0
-    s_cbranch_scc1 .Ldist_single
     s_waitcnt lgkmcnt(0)
-    LOOKUP VDHV, VDHB
-    v_lshl_add_u32 VT0, VI, 2, DTREE
-    ds_read_b32 VT2, VT0 offset:SYMOFF
+    LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF
     s_waitcnt lgkmcnt(0)
-    // VT2 = payload of the distance symbol (decode_distance :1412-1481): extra-bit count | base << 5, or (bit 31) one of
-    // the 16 last-distance codes / a symbol without payload form (BRX_DIST_UNFIT: handed over before it is consumed)
-    v_cmp_gt_i32 vcc, 0, VT2
-    s_cbranch_vccnz .Ldist_ring
-    TAKE CLEN
+    // payload of the distance symbol (decode_distance :1412-1481): extra-bit count | base << 5, or (bit 31) one of the 16
+    // last-distance codes / a symbol without payload form (BRX_DIST_UNFIT: handed back with its bits un-taken)
+    v_readlane_b32 DCODE, VS, CLEN
     REFILL_CHECK 5
-    v_and_b32 VN, 31, VT2
-    v_bfe_u32 VEX, VWINLO, 0, VN
-    v_lshrrev_b32 VX, 5, VT2
-    v_lshl_add_u32 VHH, VEX, NPOST, VX                  // base + (extra << NPOSTFIX)
-    v_lshrrev_b64 VWIN, VN, VWIN
-    v_sub_u32 VNAV, VNAV, VN
-    v_readfirstlane_b32 DIST, VHH
+    s_cmp_lt_i32 DCODE, 0
+    s_cbranch_scc1 .Ldist_ring
+    s_and_b32 T1, DCODE, 31
+    s_lshr_b32 T2, DCODE, 5
+    v_bfe_u32 VEX, VWINLO, 0, T1
+    v_lshlrev_b32 VEX, NPOST, VEX
+    v_add_u32 VEX, T2, VEX                              // base + (extra << NPOSTFIX)
+    TAKE T1
+    v_readfirstlane_b32 DIST, VEX
 .Ldist_push:
     s_cmp_gt_u32 DIST, MAXA
     s_cbranch_scc1 .Ldict                               // :1476 not pushed: static dictionary reference
-    s_mov_b32 D3, D2
-    s_mov_b32 D2, D1
-    s_mov_b32 D1, D0
+    v_mov_b32 VD3, VD2                                  // (only the most recent distance lives in an SGPR)
+    v_mov_b32 VD2, VD1
+    v_mov_b32 VD1, D0
     s_mov_b32 D0, DIST
 
 // ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542): takes the next CPY lanes
 // of the pending register
 .Lcopy:
     s_sub_u32 T0, 63, PFREE                             // (63, not 64: s_bfm_b64 takes a 6-bit width)
+    s_sub_u32 MBLEFT, MBEND, POS
     s_min_u32 T0, T0, DIST                              // the common case: CPY <= min(free lanes, distance, bytes left)
     s_min_u32 T0, T0, MBLEFT
     s_cmp_gt_u32 CPY, T0
@@ -544,13 +625,10 @@
 .Lcopy_issued:
     s_add_u32 PFREE, PFREE, CPY
     s_add_u32 POS, POS, CPY
-    s_sub_u32 MBLEFT, MBLEFT, CPY
-.Lcopy_tail:
-    s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc1 .Lflush_stub_cmd
+.Lcopy_tail:                                            // (the flush cursor is checked whenever pending copies land)
 .Lflush_back_cmd:
     REFILL_CHECK 6
-    s_cmp_eq_u32 MBLEFT, 0
+    s_cmp_eq_u32 POS, MBEND
     s_cbranch_scc0 .Lcmd
     s_mov_b32 INS, 0
     s_branch .Lexit
@@ -572,6 +650,9 @@
     s_mov_b64 exec, -1
     s_branch .Lcopy_issued
 
+.Ldist_special:
+    s_bitcmp1_b32 DTREE, 30
+    s_cbranch_scc0 .Ldist_single
 .Ldist_zero:
     s_mov_b32 DIST, D0
     s_cmp_gt_u32 DIST, MAXA
@@ -581,8 +662,8 @@
 // ---- insert&copy extra bits (decode_insert_and_copy_length :1210-1224)
 .Liac_extras:
     REFILL_CHECK 1
-    s_and_b32 T2, s93, 0xff                             // insert extra bits
-    s_bfe_u32 T3, s93, 0x80008                          // copy extra bits
+    s_and_b32 T2, s95, 0xff                             // insert extra bits
+    s_bfe_u32 T3, s95, 0x80008                          // copy extra bits
     v_bfe_u32 VEX, VWINLO, 0, T2
     v_add_u32 VEX, INS, VEX
     TAKE T2
@@ -597,15 +678,17 @@
 
 // ---- literals (reference parse_insert_literals :1286-1365)
 .Lhave_lits:
+    s_sub_u32 MBLEFT, MBEND, POS
     s_cmp_gt_u32 INS, MBLEFT
     s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
     s_bitcmp1_b32 FLAGS, 3
     s_cbranch_scc1 .Lhave_lits1
     s_call_b64 LINKB, .Lland_ctx                        // pending bytes into the ring, context of the first literal
-    s_sub_u32 MBLEFT, MBLEFT, INS
     s_add_u32 T0, POS, SKEW
     v_mov_b32 VPA, T0                                   // ring address of the next literal (masked when used)
     s_sub_u32 INS, INS, 1                               // the loop counts down to the borrow
+    s_bitcmp1_b32 FLAGS, 5
+    s_cbranch_scc1 .Llit_r_start
     s_bitcmp1_b32 FLAGS, 4
     s_cbranch_scc1 .Llit_m
 // \mixed = 0: the entries carry the context info; 1 (meta-blocks whose literal block types differ in context mode): they
@@ -620,14 +703,14 @@
     v_add_u32 VT0, VH, VLANE8
     ds_read_b64 VLB, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP VLIM, VBASE
-    v_lshl_add_u32 VT0, VI, 1, VH
-    ds_read_u16 VE, VT0 offset:SYMOFF                   // byte | context info << 8
-    TAKE CLEN
+    LOOKUP2 VLIM, VBASE, VH, 1, ds_read_u16, SYMOFF
     s_waitcnt lgkmcnt(0)
-.Llit_have\sfx:
+    v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
     v_and_b32 VT0, RMASK, VPA
+    s_nop 0
+    v_mov_b32 VE, T0
     ds_write_b8 VT0, VE
+.Llit_stored\sfx:
 .if \mixed
     v_and_b32 VT1, 0xff, VE
     ds_read_u8 VINFO, VT1 offset:LDS_ITAB
@@ -650,38 +733,77 @@
     s_branch .Lafter_lits
 .Llit_single\sfx:                                       // one-symbol tree: no bits
     v_and_b32 VE, 0xffff, VH
-    s_branch .Llit_have\sfx
+    v_and_b32 VT0, RMASK, VPA
+    ds_write_b8 VT0, VE
+    s_branch .Llit_stored\sfx
 .Lflush_stub_lit\sfx:
     s_call_b64 LINKC, .Lflush
     s_branch .Lflush_back_lit\sfx
 .endm
     LIT_LOOP _u, 0, 4
     LIT_LOOP _m, 1, 8
+// resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway), tree pair through the
+// VGPR index mode
+.Llit_r_start:
+    v_readfirstlane_b32 T4, VC                          // context id * 4 of the first literal
+    v_readfirstlane_b32 T5, VB4                         // p1's share as a later p2
+.Llit_r:
+    s_sub_u32 LBLEN, LBLEN, 1
+    s_cbranch_scc1 .Lx_lit_switch
+    s_lshr_b32 T4, T4, 2
+    v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
+    s_set_gpr_idx_on T6, 1                              // VGPR index mode, source 0 + T6
+    v_mov_b32 VLIM, VTREES
+    v_mov_b32 VBASE, VTREES1
+    s_set_gpr_idx_off
+    v_readlane_b32 T7, VLIM, 16                         // LDS address of the tree's symbol list
+    LOOKUP2 VLIM, VBASE, T7, 1, ds_read_u16, 0
+    s_waitcnt lgkmcnt(0)
+    v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
+    v_and_b32 VT0, RMASK, VPA
+    v_add_u32 VPA, 1, VPA
+    v_mov_b32 VE, T0
+    ds_write_b8 VT0, VE
+    s_lshr_b32 T1, T0, 8                                // context info of this literal
+    s_and_b32 T4, T1, MA
+    s_or_b32 T4, T4, T5                                 // context id * 4 of the next one
+    s_and_b32 T5, T1, MB
+    s_lshl_b32 T5, T5, SB
+    s_add_u32 POS, POS, 1
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lflush_stub_lit_r
+.Lflush_back_lit_r:
+    REFILL_CHECK 9
+    s_sub_u32 INS, INS, 1
+    s_cbranch_scc0 .Llit_r
+    s_branch .Lafter_lits
+.Lflush_stub_lit_r:
+    s_call_b64 LINKC, .Lflush
+    s_branch .Lflush_back_lit_r
 .Lafter_lits:
     s_mov_b32 INS, 0
     s_mov_b32 PBASE, POS                                // (nothing is pending here)
-    s_cmp_eq_u32 MBLEFT, 0
+    s_cmp_eq_u32 POS, MBEND
     s_cbranch_scc0 .Lno_lits
     s_branch .Lexit                                     // :2069 the copy part of the last command is ignored
 
 // one literal tree, resident: no contexts
 .Lhave_lits1:
     s_call_b64 LINKB, .Lland
-    s_sub_u32 MBLEFT, MBLEFT, INS
     s_add_u32 T0, POS, SKEW
     v_mov_b32 VPA, T0
     s_sub_u32 INS, INS, 1
 .Llit1:
     s_sub_u32 LBLEN, LBLEN, 1
     s_cbranch_scc1 .Lx_lit_switch
-    LOOKUP VLITL, VLITB
-    v_lshl_add_u32 VT0, VI, 1, LITSYM
-    ds_read_u16 VE, VT0
-    TAKE CLEN
+    LOOKUP2 VLITL, VLITB, LITSYM, 1, ds_read_u16, 0
     v_and_b32 VT0, RMASK, VPA
     v_add_u32 VPA, 1, VPA
     s_add_u32 POS, POS, 1
     s_waitcnt lgkmcnt(0)
+    v_readlane_b32 T0, VS, CLEN
+    s_nop 1
+    v_mov_b32 VE, T0
     ds_write_b8 VT0, VE
     s_cmp_ge_u32 POS, FLUSHAT
     s_cbranch_scc1 .Lflush_stub_lit1
@@ -693,28 +815,31 @@
 
 // ---- last-distance codes 0..15 (decode_distance :1412-1450)
 .Ldist_single:
+    s_sub_u32 DBLEN, DBLEN, 1
+    s_cbranch_scc1 .Lx_dist_switch
     s_and_b32 DCODE, DTREE, 0xffff
     s_branch .Ldist_ring_s
 .Ldist_ring:
-    v_readfirstlane_b32 DCODE, VT2
     s_bitcmp1_b32 DCODE, 30
     s_cbranch_scc1 .Lx_dist_unfit
-    TAKE CLEN
     s_and_b32 DCODE, DCODE, 0xffff
 .Ldist_ring_s:
     s_cmp_eq_u32 DCODE, 0
     s_cbranch_scc1 .Ldist_zero
+    v_readfirstlane_b32 T5, VD1
+    v_readfirstlane_b32 T6, VD2
+    v_readfirstlane_b32 T7, VD3
     s_cmp_ge_u32 DCODE, 4
     s_cbranch_scc1 .Ldist_delta
-    s_mov_b32 DIST, D1
+    s_mov_b32 DIST, T5
     s_cmp_eq_u32 DCODE, 2
-    s_cselect_b32 DIST, D2, DIST
+    s_cselect_b32 DIST, T6, DIST
     s_cmp_eq_u32 DCODE, 3
-    s_cselect_b32 DIST, D3, DIST
+    s_cselect_b32 DIST, T7, DIST
     s_branch .Ldist_push
 .Ldist_delta:
     s_cmp_lt_u32 DCODE, 10
-    s_cselect_b32 T0, D0, D1
+    s_cselect_b32 T0, D0, T5
     s_cselect_b32 T1, 2, 8
     s_sub_u32 T1, DCODE, T1
     s_lshr_b32 T1, T1, 1
@@ -742,6 +867,7 @@
     s_and_b32 T0, T0, 0xffffff
     s_mul_i32 T1, T1, CPY
     s_add_u32 T0, T0, T1                                // byte offset of the word in the dictionary
+    s_sub_u32 MBLEFT, MBEND, POS
     s_cmp_lg_u32 T3, 0
     s_cbranch_scc1 .Ldict_xform
     s_cmp_gt_u32 CPY, MBLEFT
@@ -763,10 +889,30 @@
 // literals never sit between pending copies: a literal run lands everything first).  One masked byte store.
 // Clobbers T6, VT1.  .Lland_ctx also derives the literal context from the last two bytes of the stream (VC = id * 4,
 // VB4 = p1's share as a future p2) and requests the tree descriptor of the first literal.
+// (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
+#ifdef BRX_PROF
+#define LDS_PAD 10112
+.macro PROF_WAIT_VM
+    s_waitcnt lgkmcnt(0)
+    s_memtime s[16:17]
+    s_waitcnt lgkmcnt(0)
+    s_waitcnt vmcnt(0)
+    s_memtime s[18:19]
+    s_waitcnt lgkmcnt(0)
+    s_sub_u32 s18, s18, s16
+    s_add_u32 s20, s20, s18
+    s_add_u32 s21, s21, 1
+    s_add_u32 s22, s22, PFREE
+.endm
+#else
+.macro PROF_WAIT_VM
+.endm
+#endif
 .macro LAND_BODY
     s_add_u32 T6, PBASE, SKEW
     v_add_u32 VT1, T6, VLANE
     v_and_b32 VT1, RMASK, VT1
+    PROF_WAIT_VM
     s_waitcnt vmcnt(0) lgkmcnt(0)
     s_bfm_b64 exec, PFREE, 0
     ds_write_b8 VT1, VPEND
@@ -774,11 +920,30 @@
     s_mov_b32 PFREE, 0
     s_mov_b32 PBASE, POS
 .endm
+.macro FLUSH_BODY lbl
+\lbl:
+    s_and_b32 T6, VFL, RMASK
+    v_add_u32 VT4, T6, VLANE16
+    ds_read_b128 VQ, VT4
+    s_sub_u32 T7, VFL, SKEW
+    v_add_u32 VT4, T7, VLANE16
+    s_waitcnt lgkmcnt(0)
+    buffer_store_dwordx4 VQ, VT4, RSRC, 0 offen
+    s_add_u32 VFL, VFL, 1024
+    s_add_u32 FLUSHAT, FLUSHAT, 1024
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 \lbl
+.endm
 .Lland:
     s_cmp_eq_u32 PFREE, 0
-    s_cbranch_scc1 .Lland_ret
+    s_cbranch_scc1 .Lland_chk
     LAND_BODY
-.Lland_ret:
+.Lland_chk:
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lland_flush
+    s_setpc_b64 LINKB
+.Lland_flush:
+    FLUSH_BODY .Lland_flush_loop
     s_setpc_b64 LINKB
 .Lland_ctx:
     s_cmp_lt_u32 POS, 2
@@ -828,24 +993,11 @@
     s_cbranch_scc1 .Lflush_go
     LAND_BODY
 .Lflush_go:
-    s_and_b32 T6, VFL, RMASK
-    v_add_u32 VT4, T6, VLANE16
-    ds_read_b128 VQ, VT4
-    s_sub_u32 T7, VFL, SKEW
-    v_add_u32 VT4, T7, VLANE16
-    s_waitcnt lgkmcnt(0)
-    buffer_store_dwordx4 VQ, VT4, RSRC, 0 offen
-    s_add_u32 VFL, VFL, 1024
-    s_add_u32 FLUSHAT, FLUSHAT, 1024
-    s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc1 .Lflush_go
+    FLUSH_BODY .Lflush_loop
     s_setpc_b64 LINKC
 .Lflush_stub_lit1:
     s_call_b64 LINKC, .Lflush
     s_branch .Lflush_back_lit1
-.Lflush_stub_cmd:
-    s_call_b64 LINKC, .Lflush
-    s_branch .Lflush_back_cmd
 
 // Refill reached lane WLSTOP: either the staged chunk is used up (roll the two chunks, request the next one) or
 // the cursor is within 256 bits of the end of the stream (poison the block counters so that the loop leaves at
@@ -887,6 +1039,7 @@
     REFILL_STUB 6
     REFILL_STUB 7
     REFILL_STUB 8
+    REFILL_STUB 9
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
@@ -929,7 +1082,6 @@
     s_waitcnt lgkmcnt(0)
     ds_write_b8 VT0, VT3
     s_add_u32 POS, POS, CPY
-    s_sub_u32 MBLEFT, MBLEFT, CPY
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
 
@@ -965,7 +1117,6 @@
     s_waitcnt vmcnt(0) lgkmcnt(0)
     ds_write_b8 VT0, VT2
     s_add_u32 POS, POS, T0
-    s_sub_u32 MBLEFT, MBLEFT, T0
     s_sub_u32 T5, T5, T0
     s_mov_b32 PBASE, POS
     s_cmp_ge_u32 POS, FLUSHAT
@@ -984,7 +1135,7 @@
     s_cmp_gt_u32 T3, 120
     s_cbranch_scc1 .Lx_r2
     s_mul_i32 T4, T3, 20                                // sizeof(BrxTransform)
-    s_load_dwordx4 s[92:95], XFP, T4                    // prefix[8], suffix[8]
+    s_load_dwordx4 s[12:15], XFP, T4                    // prefix[8], suffix[8]
     s_add_u32 T4, T4, 16
     s_load_dword s97, XFP, T4                           // plen | slen << 8 | op << 16
     s_call_b64 LINKB, .Lland
@@ -1063,12 +1214,12 @@
     v_xor_b32 VT3, VT3, VT1
 .Lxf_store:
     v_lshlrev_b32 VT1, 3, VLANE
-    v_lshrrev_b64 v[6:7], VT1, s[92:93]                 // lane i: prefix byte i
+    v_lshrrev_b64 v[54:55], VT1, s[12:13]                 // lane i: prefix byte i
     s_add_u32 T4, POS, SKEW
     v_add_u32 VT0, T4, VLANE
     v_and_b32 VT0, RMASK, VT0
     s_bfm_b64 exec, T2, 0
-    ds_write_b8 VT0, v6
+    ds_write_b8 VT0, v54
     s_mov_b64 exec, -1
     s_add_u32 T4, T4, T2
     v_add_u32 VT0, T4, VLANE
@@ -1077,14 +1228,13 @@
     ds_write_b8 VT0, VT3
     s_mov_b64 exec, -1
     s_add_u32 T4, T4, T7
-    v_lshrrev_b64 v[6:7], VT1, s[94:95]                 // lane i: suffix byte i
+    v_lshrrev_b64 v[54:55], VT1, s[14:15]                 // lane i: suffix byte i
     v_add_u32 VT0, T4, VLANE
     v_and_b32 VT0, RMASK, VT0
     s_bfm_b64 exec, T3, 0
-    ds_write_b8 VT0, v6
+    ds_write_b8 VT0, v54
     s_mov_b64 exec, -1
     s_add_u32 POS, POS, CLEN
-    s_sub_u32 MBLEFT, MBLEFT, CLEN
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
 
@@ -1096,13 +1246,13 @@
 .Lx_lit_switch:                                         // literal block count exhausted (or poisoned), mid-run
     s_mov_b32 LBLEN, 0
     s_add_u32 INS, INS, 1                               // (the loop counter runs one behind)
-    s_add_u32 MBLEFT, MBLEFT, INS
     s_branch .Lexit
 .Lx_dist_switch:
     s_mov_b32 DBLEN, 0
     s_mov_b32 INS, 0
     s_branch .Lexit
 .Lx_dist_unfit:                                         // back to R1 with the literals done: the C++ side reads the distance
+    s_add_u32 SNAV, SNAV, CLEN                          // (un-take the symbol: the bit cursor is derived from SNAV)
     s_add_u32 DBLEN, DBLEN, 1
     s_mov_b32 INS, 0
     s_branch .Lexit
@@ -1115,6 +1265,19 @@
 .Lexit:
     s_call_b64 LINKB, .Lland
     s_waitcnt vmcnt(0) lgkmcnt(0)
+#ifdef BRX_PROF
+    s_memtime s[14:15]
+    s_waitcnt lgkmcnt(0)
+    s_sub_u32 s14, s14, s12                             // cycles inside the loop (low word)
+    v_mov_b32 VT0, s20
+    v_mov_b32 VT1, s21
+    v_mov_b32 VT2, s22
+    v_mov_b32 VT3, s14
+    ds_add_u32 VZERO, VT0 offset:LDS_PAD+40             // pad[10]: cycles waiting for vmcnt at landings
+    ds_add_u32 VZERO, VT1 offset:LDS_PAD+44             // pad[11]: landings with something pending
+    ds_add_u32 VZERO, VT2 offset:LDS_PAD+48             // pad[12]: bytes landed
+    ds_add_u32 VZERO, VT3 offset:LDS_PAD+52             // pad[13]: cycles inside the assembly loop
+#endif
     // real block counters if they were poisoned
     s_bitcmp1_b32 FLAGS, 0
     s_cselect_b32 LBLEN, LBLEN_REAL, LBLEN
@@ -1122,8 +1285,7 @@
     // bit cursor: 32 * (CBASE + WL) - NAV
     s_add_u32 T0, CBASE, WL
     s_lshl_b32 T0, T0, 5
-    v_readfirstlane_b32 T1, VNAV
-    s_sub_u32 T0, T0, T1
+    s_sub_u32 T0, T0, SNAV
     v_mov_b32 VT0, T0
     v_mov_b32 VT1, 0
     ds_write_b32 VZERO, VT0 offset:LDS_ST+12            // bitpos (st[3], st[4])
@@ -1133,9 +1295,9 @@
     v_mov_b32 VT0, VFL
     ds_write_b32 VZERO, VT0 offset:LDS_ST+48
     v_mov_b32 v20, D0
-    v_mov_b32 v21, D1
-    v_mov_b32 v22, D2
-    v_mov_b32 v23, D3
+    v_mov_b32 v21, VD1
+    v_mov_b32 v22, VD2
+    v_mov_b32 v23, VD3
     ds_write_b64 VZERO, v[20:21] offset:LDS_ST+56
     ds_write_b64 VZERO, v[22:23] offset:LDS_ST+64
     v_mov_b32 VT0, LBLEN
@@ -1144,6 +1306,9 @@
     ds_write_b32 VZERO, VT0 offset:LDS_MBW+84
     v_mov_b32 VT0, DBLEN
     ds_write_b32 VZERO, VT0 offset:LDS_MBW+108
+    s_cmp_eq_u32 DCTX, 4
+    s_cselect_b32 IZ, 1, 0
+    s_sub_u32 MBLEFT, MBEND, POS
     v_mov_b32 v20, MBLEFT
     v_mov_b32 v21, INS
     v_mov_b32 v22, CPY

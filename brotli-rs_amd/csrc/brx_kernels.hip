@@ -363,7 +363,7 @@ FI void dec_load(Dec &d, const Lds &s) {
 // assembly loop, prepare_fast_tables() rewrites them in place into the form that loop wants (MBW_ASM = 1; the C++ loop
 // reads the same form then):
 //   literal trees      sym | info << 8, info = the literal's share of the NEXT literal's context id (context_info())
-//   insert&copy trees  sym << 3 = byte offset of the symbol's record in BrxDeviceTables::iac
+//   insert&copy trees  sym << 4 = byte offset of the symbol's record in BrxDeviceTables::iac
 //   distance trees     0x80000000 | code for the 16 last-distance codes, else nbits | base << 5 with
 //                      distance = base + (extra << NPOSTFIX)  (decode_distance, src/lib.rs:1412-1481)
 #define BRX_HDR_WORDS 32u
@@ -1143,13 +1143,14 @@ __device__ __noinline__ u32 asm_commands() {
 #include "_gen/brx_hot_asm.h"
         :
         :
-        : "memory", "vcc", "scc", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+        : "memory", "vcc", "scc", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
           "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
           "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
           "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
-          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69");
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83",
+          "v84", "v85", "v86", "m0");
     return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
@@ -1203,7 +1204,7 @@ FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mo
         const u32 h = rfl(s.tm[m.hi + t]);
         const u32 nnz = rfl(s.tm[h + 1u]) >> 16;
         u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
-        for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 3);
+        for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 4);
     }
     for (u32 t = 0; uniform && t < m.ntl; t++) {
         const u32 h = rfl(s.tm[m.hl + t]);
@@ -1290,7 +1291,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
         u32 lk_ = decode_sym(d, s, tm_u32(d, s, m.hi + I.btype), sym_);                    \
         if (lk_ == LK_NONE) return ST_PARSE_IAC;                                           \
         if (lk_ == LK_EOF) return ST_EOF;                                                  \
-        if (fast_tables) sym_ >>= 3;                                                       \
+        if (fast_tables) sym_ >>= 4;                                                       \
         implicit_zero = sym_ < 128u ? 1u : 0u; /* :2012-2015 */                            \
         u32 cell_ = sym_ >> 6;                                                             \
         u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                  \

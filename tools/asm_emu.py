@@ -35,7 +35,9 @@ DUMP_WORDS = 16 + LDS_BYTES // 4
 S_VCC, S_M0, S_EXEC = 106, 124, 126
 
 # measured on MI355X (tools/ubench/lat.hip), cycles
-LAT = {"issue": 5, "lds": 53, "smem": 50, "vmem_l2": 210, "vmem_hbm": 900, "branch_taken": 16}
+# measured on MI355X, one lone wave (tools/ubench/lat.hip, issue.hip), cycles
+LAT = {"issue": 4.2, "lds": 52, "smem": 46, "vmem_l2": 210, "vmem_hbm": 900, "branch_taken": 21, "branch_not_taken": 6,
+       "vccnz_extra": 14, "cross": 6}
 
 
 class EmuError(Exception):
@@ -77,12 +79,18 @@ def parse_operand(tok):
         return ("s", S_EXEC, 2)
     if tok == "exec_lo":
         return ("s", S_EXEC, 1)
+    m = re.fullmatch(r"gpr_idx\(([A-Z0-9,]*)\)", tok)
+    if m:
+        bits = {"SRC0": 1, "SRC1": 2, "SRC2": 4, "DST": 8}
+        return ("imm", sum(bits[x] for x in m.group(1).split(",") if x), 0)
     if tok == "m0":
         return ("s", S_M0, 1)
     if tok == "scc":
         return ("scc", 0, 1)
     if re.fullmatch(r"-?\d+", tok):
         return ("imm", int(tok) & 0xFFFFFFFFFFFFFFFF if int(tok) < 0 else int(tok), 0)
+    if re.fullmatch(r"-?\d+\.\d+", tok):  # inline float constant, shown by its value
+        return ("imm", struct.unpack("<I", struct.pack("<f", float(tok)))[0], 0)
     if re.fullmatch(r"0x[0-9a-fA-F]+", tok):
         return ("imm", int(tok, 16), 0)
     raise EmuError("operand? %r" % tok)
@@ -156,6 +164,9 @@ class Wave:
         self.S[S_EXEC + 1] = MASK32
         self.trace = False
         self.lds_conflicts = 0
+        self.gpr_idx = None
+        self.cyc_at, self.hits, self.last_pc, self.last_cyc = None, {}, None, 0
+        self.lg_issue_cycle = None  # cycle count when the oldest outstanding LDS / SMEM op was issued
         self.far_latency = LAT["vmem_l2"]
 
     # ---- helpers ------------------------------------------------------------------------------------------
@@ -266,6 +277,8 @@ class Wave:
         self.lds[addr:addr + len(data)] = data
 
     def queue(self, q, dsts, vals, name, smem=False, mask=None):
+        if q is self.lg_q and not q:
+            self.lg_issue_cycle = self.cycles
         q.append((dsts, vals, smem, mask))
         for d in dsts:
             self.pend[d] = self.pend.get(d, 0) + 1
@@ -289,6 +302,11 @@ class Wave:
         i = self.insts[pc]
         op, ops = i.op, i.ops
         self.count[op] = self.count.get(op, 0) + 1
+        if self.cyc_at is not None:
+            if self.last_pc is not None:
+                self.cyc_at[self.last_pc] = self.cyc_at.get(self.last_pc, 0) + self.cycles - self.last_cyc
+                self.hits[self.last_pc] = self.hits.get(self.last_pc, 0) + 1
+            self.last_pc, self.last_cyc = pc, self.cycles
         self.cycles += LAT["issue"]
         nxt = pc + 1
         if self.pend and op != "s_waitcnt":
@@ -299,6 +317,8 @@ class Wave:
                         continue  # another load into a register with a load in flight (other lanes / in-order counter)
                     raise EmuError("%#x %s: register %s%d has a load in flight (missing s_waitcnt)" % (i.addr, i.text, r[0], r[1]))
         S = self.S
+        if self.gpr_idx is not None and op.startswith("v_") and op != "v_mov_b32":
+            raise EmuError("%#x %s: VALU instruction other than v_mov_b32 inside VGPR index mode (not modelled)" % (i.addr, i.text))
         if op == "s_waitcnt":
             w = i.wait
             if "vmcnt" in w:
@@ -309,7 +329,7 @@ class Wave:
                 if w["lgkmcnt"] > 0 and any(e[2] for e in self.lg_q):
                     raise EmuError("%#x: lgkmcnt(%d) with a scalar load in flight (SMEM returns out of order)" % (i.addr, w["lgkmcnt"]))
                 if len(self.lg_q) > w["lgkmcnt"]:
-                    self.cycles += LAT["lds"] - 2 * LAT["issue"]
+                    self.cycles += (LAT["lds"] - 12) if self.lg_issue_cycle is None else max(0, LAT["lds"] - (self.cycles - self.lg_issue_cycle))
                 self.complete(self.lg_q, w["lgkmcnt"])
         elif op == "s_nop":
             self.cycles += ops[0][1]
@@ -390,7 +410,12 @@ class Wave:
             self.sset(ops[0][1], ((1 << (self.ssrc(ops[1]) & 31)) - 1) << (self.ssrc(ops[2]) & 31))
         elif op == "s_bfm_b64":
             self.sset64(ops[0][1], (((1 << (self.ssrc(ops[1]) & 63)) - 1) << (self.ssrc(ops[2]) & 63)) & 0xFFFFFFFFFFFFFFFF)
+        elif op == "v_ffbl_b32":
+            a = self.vsrc(ops[1])
+            r = np.array([((int(x) & -int(x)).bit_length() - 1) if int(x) else MASK32 for x in a], dtype=np.uint32)
+            self.vset(ops[0], r)
         elif op == "s_ff1_i32_b32":
+            self.cycles += LAT["cross"]
             a = self.ssrc(ops[1])
             self.sset(ops[0][1], (a & -a).bit_length() - 1 if a else MASK32)
         elif op == "s_ff1_i32_b64":
@@ -406,13 +431,16 @@ class Wave:
             self.scc = 1 if r else 0
         elif op == "s_branch":
             nxt = self.index[i.target]
-            self.cycles += LAT["branch_taken"]
+            self.cycles += LAT["branch_taken"] - LAT["issue"]
         elif op.startswith("s_cbranch_"):
             cond = {"scc0": self.scc == 0, "scc1": self.scc == 1, "vccnz": self.s64(S_VCC) != 0, "vccz": self.s64(S_VCC) == 0,
                     "execz": self.s64(S_EXEC) == 0, "execnz": self.s64(S_EXEC) != 0}[op[10:]]
+            self.cycles += LAT["vccnz_extra"] if op[10:].startswith("vcc") else 0
             if cond:
                 nxt = self.index[i.target]
                 self.cycles += LAT["branch_taken"]
+            else:
+                self.cycles += LAT["branch_not_taken"]
         elif op == "s_call_b64":
             self.sset64(ops[0][1], i.addr + 4)
             nxt = self.index[i.target]
@@ -426,8 +454,19 @@ class Wave:
             raw = self.mem_read(addr, 4 * n).view(np.uint32)
             self.queue(self.lg_q, [("s", ops[0][1] + k) for k in range(n)], [int(x) for x in raw], "lg", smem=True)
         # ---- VALU
+        elif op == "s_set_gpr_idx_on":  # gfx9 VGPR index mode: M0[7:0] = index, imm = which operands it applies to
+            self.gpr_idx = (self.ssrc(ops[0]) & 0xFF, ops[1][1] if ops[1][0] == "imm" else 0)
+            self.sset(S_M0, (self.ssrc(ops[0]) & 0xFF) | ((self.gpr_idx[1] & 15) << 12))
+        elif op == "s_set_gpr_idx_off":
+            self.gpr_idx = None
         elif op == "v_mov_b32":
-            self.vset(ops[0], self.vsrc(ops[1]))
+            if self.gpr_idx is not None:
+                idx, mask = self.gpr_idx
+                src = (ops[1][0], ops[1][1] + idx, 1) if (mask & 1) and ops[1][0] == "v" else ops[1]
+                dst = (ops[0][0], ops[0][1] + idx, 1) if (mask & 8) else ops[0]
+                self.vset(dst, self.vsrc(src))
+            else:
+                self.vset(ops[0], self.vsrc(ops[1]))
         elif op in ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_min_u32", "v_max_u32",
                     "v_lshlrev_b32", "v_lshrrev_b32", "v_mul_lo_u32", "v_ashrrev_i32"):
             a, b = self.vsrc(ops[1]), self.vsrc(ops[2])
@@ -504,10 +543,12 @@ class Wave:
             m_ = ((sel >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool)
             self.vset(ops[0], np.where(m_, self.vsrc(ops[2]), self.vsrc(ops[1])))
         elif op == "v_readfirstlane_b32":
+            self.cycles += LAT["cross"]
             m_ = self.exec_mask()
             lane = 0 if m_ is None or not m_.any() else int(np.argmax(m_))
             self.sset(ops[0][1], int(self.V[ops[1][1]][lane]))
         elif op == "v_readlane_b32":
+            self.cycles += LAT["cross"]
             self.sset(ops[0][1], int(self.V[ops[1][1]][self.ssrc(ops[2]) & 63]))
         elif op == "v_writelane_b32":
             self.V[ops[0][1]][self.ssrc(ops[2]) & 63] = self.ssrc(ops[1])
@@ -659,15 +700,14 @@ def load_tables():
     cell_ins = [0, 0, 0, 0, 8, 8, 0, 16, 8, 16, 16]
     cell_cpy = [0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16]
     ndbits = [0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5]
-    iac = np.zeros(704 * 2 + 64, dtype=np.uint32)  # same records as brx_api.cpp ctx_init()
+    iac = np.zeros(704 * 4 + 64, dtype=np.uint32)  # same records as brx_api.cpp ctx_init()
     for sym in range(704):
         cell = sym >> 6
         ic, cc = cell_ins[cell] + ((sym >> 3) & 7), cell_cpy[cell] + (sym & 7)
-        iac[2 * sym] = ins_base[ic] | (cpy_base[cc] << 16)
-        iac[2 * sym + 1] = ins_extra[ic] | (cpy_extra[cc] << 8) | ((1 if sym < 128 else 0) << 16) | ((ins_extra[ic] + cpy_extra[cc]) << 24)
+        iac[4 * sym:4 * sym + 4] = [ins_base[ic], cpy_base[cc], 4 if sym < 128 else min(cc, 3), ins_extra[ic] | (cpy_extra[cc] << 8)]
     off = 0
     for n in range(25):
-        iac[1408 + n] = off | (ndbits[n] << 24)
+        iac[2816 + n] = off | (ndbits[n] << 24)
         if n >= 4:
             off += n << ndbits[n]
     return dic, lut, np.frombuffer(bytes(xf), dtype=np.uint8), iac.view(np.uint8)
@@ -724,6 +764,9 @@ def run_one(insts, index, rec, comp, expect, cmds, tables, args):
     assert 0 <= mis < 4, (hex(d_in), hex(in_words))
     w = Wave(insts, index)
     w.trace = args.trace
+    if getattr(args, "cyc_profile", False):
+        w.cyc_at = run_one.cyc_at
+        w.hits = run_one.hits
     w.far_latency = LAT["vmem_hbm"] if args.hbm else LAT["vmem_l2"]
     w.lds[:LDS_BYTES] = lds
     dic, lut, xf, iac = tables
@@ -809,6 +852,9 @@ def run_one(insts, index, rec, comp, expect, cmds, tables, args):
     return res
 
 
+run_one.cyc_at, run_one.hits = {}, {}
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("dump")
@@ -820,6 +866,7 @@ def main():
     ap.add_argument("--hbm", action="store_true", help="far copies cost an HBM miss instead of an L2 hit in the estimate")
     ap.add_argument("--max-steps", type=int, default=20_000_000)
     ap.add_argument("--profile", action="store_true", help="print instruction counts per opcode")
+    ap.add_argument("--cyc-profile", action="store_true", help="print the estimated cycles per instruction address (listing order)")
     args = ap.parse_args()
     insts, index = decode_program(disassemble(args.src))
     recs = read_dumps(args.dump)
@@ -906,6 +953,12 @@ def main():
         else:
             cls["VMEM"] += v
     print("by class:", {k: round(v / max(1, tot["commands"]), 1) for k, v in cls.items()}, "per command")
+    if args.cyc_profile:
+        ncmd = max(1, tot["commands"])
+        for pc in sorted(run_one.cyc_at):
+            c, h = run_one.cyc_at[pc], run_one.hits[pc]
+            if c / ncmd >= 0.5:
+                print("%#06x %7.1f cyc/cmd %6.2f hits/cmd  %s" % (insts[pc].addr, c / ncmd, h / ncmd, insts[pc].text))
     if args.profile:
         for k, v in sorted(counts.items(), key=lambda kv: -kv[1]):
             print("%8d %6.2f/cmd  %s" % (v, v / max(1, tot["commands"]), k))
