@@ -32,11 +32,20 @@ WORKLOADS = {
     "quickfox_repeatedx8192": (["quickfox_repeated"], 8192),       # configs[3], per-GPU share
     "compressed_repeatedx4096": (["compressed_repeated"], 4096),   # supplementary long-distance copy
     "config5_1MiBx1024": (["c5_0", "c5_1", "c5_2", "c5_3"], 1024), # configs[4], per-GPU share
+    # the LZ77 back-reference on its own (north_star: ">= 40 % of HBM peak on the copy"): hand-assembled streams, 64 KiB of
+    # raw bytes then non-overlapping copies from distance >= 64 KiB doubling the output to 1 MiB (tests/craft.py)
+    "farcopy_1MiBx4096": (["farcopy_0", "farcopy_1", "farcopy_2", "farcopy_3"], 4096),
 }
+# workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
+# copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic
+PHYSICAL_MODEL = {"farcopy_1MiBx4096": "rw", "backward65536x4096": "w", "quickfox_repeatedx8192": "w"}
 
 
 def load_fixture(name):
     """(compressed, expected).  config-5 fixtures carry only a sha256: their expected bytes come from the oracle."""
+    if name.startswith("farcopy_"):
+        import craft
+        return craft.farcopy_stream(int(name.split("_")[1]))
     if name.startswith("c5_"):
         import hashlib
         import oracle_py
@@ -72,6 +81,39 @@ def cpu_baseline(comp, expect, seconds=12.0):
     return {"value": round(reps * len(expect) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
             "sample": "%d sequential decodes of %d B -> %d B in %.1f s, single thread, oracle canonical mode"
                       % (reps, len(comp), len(expect), dt)}, st.as_dict()
+
+
+def config1_monkey(iters=3000):
+    """BASELINE configs[0]: the reference's own bench_monkey plumbing (benches/lib.rs:9-47) on the CPU path that exists
+    here, the oracle: the 425-byte stream in memory -> construct the decoder -> read the whole output, ns per iteration
+    (median of `iters`), next to the reference's published figure (docs/bench_notes.txt:15, unknown 2015 CPU)."""
+    import ctypes
+    import oracle_py
+    comp, expect = load_fixture("monkey")
+    L = oracle_py.lib()
+    buf = ctypes.create_string_buffer(len(expect) + 64)
+    n = ctypes.c_size_t(0)
+    assert L.bro_decode(comp, len(comp), buf, len(buf), ctypes.byref(n), 0, None) == 0 and buf.raw[:n.value] == expect
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter_ns()
+        L.bro_decode(comp, len(comp), buf, len(buf), ctypes.byref(n), 0, None)
+        ts.append(time.perf_counter_ns() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"workload": "data/monkey.compressed, single stream, CPU path (bench_monkey plumbing)", "ns_per_iter": med,
+            "MB_per_s": round(len(expect) / med * 1e3, 1), "iters": iters, "kind": "port",
+            "reference_ns_per_iter": 96182, "reference_source": "docs/bench_notes.txt:15 (2015, CPU not stated)",
+            "note": "includes the ctypes call overhead (~1 us)"}
+
+
+def kernel_source_id():
+    """sha256 (16 hex digits) of the kernel sources: ties a committed PMC traffic measurement to the kernel it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("brx_hot.S", "brx_kernels.hip", "brx_device.h"):
+        h.update(open(os.path.join(ROOT, "brotli-rs_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def libbrotlidec_rate(comp, expect, seconds=3.0):
@@ -114,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", type=int, default=1)
+    ap.add_argument("--gather", action="store_true", help="also time the ragged gather of the outputs to rank 0 (N>1: always)")
     args = ap.parse_args()
 
     import numpy as np
@@ -184,6 +227,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # The RCCL exchange around the decode, timed on its own AFTER the timed region -- never part of `value`:
+    # compaction of the capacity slots + grouped send/recv of the ragged outputs to rank 0 (brotli-rs_amd/shard.py).
+    gather_info = None
+    if world > 1 or args.gather:
+        try:
+            from brotli_rs_amd import shard
+            if world == 1 and not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            produced = torch.where(status == 0, out_len, torch.zeros_like(out_len))
+            times = []
+            for _ in range(3):
+                barrier()
+                tg = time.perf_counter()
+                cdata, coffs = shard.compact(out, out_off, produced)
+                full, offs_all, st_all = shard.gather_ragged(cdata, coffs, status, n * world, dst=0, device=dev)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                times.append(time.perf_counter() - tg)
+            g = min(times)
+            gather_info = {"ms": round(g * 1e3, 3), "bytes_at_root": int(full.numel()) if full is not None else None,
+                           "what": "device-side compaction + grouped send/recv of the ragged outputs to rank 0 (best of 3)"}
+            del full
+        except Exception as e:  # the gather must never take the decode measurement down with it
+            gather_info = {"error": repr(e)[:200]}
+
     # parity on the timed output: status, lengths, and every stream's bytes (checksum of checksums by equality)
     ok = True
     if args.verify:
@@ -212,6 +283,10 @@ def main():
                           "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
                "bit_exact": ok}
+        if gather_info:
+            if "ms" in gather_info:
+                gather_info["decode_plus_gather_MB_per_s"] = round(total_out / (dt / args.steps + gather_info["ms"] * 1e-3) / 1e6, 1)
+            res["gather"] = gather_info
         import oracle_py
         cb = None
         if not args.no_cpu_baseline:
@@ -229,11 +304,16 @@ def main():
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected by
         # tools/gpu_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command) and
         # committed as profiles/hbm_traffic.json.  null when this workload has no committed measurement.
+        # A measurement of another kernel version is not reported: traffic = null, traffic_source says "stale".
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            traffic = tj["workloads"][args.workload]["total_bytes"]
-            traffic_src = "profiles/hbm_traffic.json (%s)" % tj.get("round", "?")
+            if tj.get("kernel_source_id") == kernel_source_id():
+                traffic = tj["workloads"][args.workload]["total_bytes"]
+                traffic_src = "profiles/hbm_traffic.json (%s)" % tj.get("round", "?")
+            else:
+                traffic_src = "stale: profiles/hbm_traffic.json (%s) measured kernel %s, this is %s" % (
+                    tj.get("round", "?"), tj.get("kernel_source_id", "?"), kernel_source_id())
         except (OSError, KeyError, ValueError):
             pass
         res["roofline"] = {"bound": "hbm", "kernel": "brx_decode_kernel", "achieved": round(achieved, 1),
@@ -241,7 +321,24 @@ def main():
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": alg_launch,
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
+        model = PHYSICAL_MODEL.get(args.workload)
+        if model:  # physical HBM bytes known by construction ("report both")
+            phys = []
+            for c, e in fx:
+                st = oracle_py.decode(c, want_stats=True)[2]
+                phys.append(len(c) + len(e) + (st["copy_bytes"] if model == "rw" else 0))
+            phys_launch = sum(phys[i % K] for i in range(n))
+            res["roofline"]["physical_bytes_per_launch"] = phys_launch
+            res["roofline"]["achieved_physical"] = round(phys_launch / (kavg * 1e-3) / 1e9, 1)
+            res["roofline"]["frac_physical"] = round(phys_launch / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            res["roofline"]["physical_model"] = ("input read + output written + every copied byte read from HBM" if model == "rw"
+                                                 else "input read + output written (the fill's source period stays in LDS)")
+        elif traffic:
+            res["roofline"]["achieved_physical"] = round(traffic / (kavg * 1e-3) / 1e9, 1)
+            res["roofline"]["frac_physical"] = round(traffic / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            res["roofline"]["physical_model"] = "PMC traffic (FETCH_SIZE + WRITE_SIZE)"
         if cb:
+            res["config1"] = config1_monkey()
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu_1core"] = round(value / world / cb["value"], 1)
             other = libbrotlidec_rate(comp, expect)

@@ -135,6 +135,19 @@ class Context:
             outs.append(out[int(out_off[i]):int(out_off[i]) + ln].tobytes())
         return outs, status[:n], out_len[:n]
 
+    # ---- host-memory batch in caller-owned (e.g. pinned) buffers ----------------------------------------
+    def decode_batch_host_raw(self, in_ptr, in_off, n, out_ptr, out_off, timing=False):
+        """Host pointers as they are (no copies on the Python side): `in_ptr` / `out_ptr` are addresses, e.g. of
+        buffers from host_alloc(); in_off / out_off are np.uint64[n+1].  Returns (status, out_len)."""
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.full(max(n, 1), -1, dtype=np.int32)
+        opts = _Opts(MEM_HOST | (OPT_TIMING if timing else 0), 0, None)
+        rc = self._lib.brx_decode_batch(self._h, in_ptr, in_off.ctypes.data, n, out_ptr, out_off.ctypes.data,
+                                        out_len.ctypes.data, status.ctypes.data, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        return status[:n], out_len[:n]
+
     # ---- device-memory batch (pointers are raw device addresses, e.g. torch tensor .data_ptr()) ------
     def decode_batch_device(self, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
                             hip_stream=None, timing=False):
@@ -163,6 +176,25 @@ class Context:
             return int(st[0]), outs[0]
 
 
+def host_alloc(nbytes):
+    """Pinned host memory from the library (brx_host_alloc) as a numpy uint8 view; free with host_free(view)."""
+    L = load_library()
+    p = L.brx_host_alloc(nbytes)
+    if not p:
+        raise BrxError("brx_host_alloc(%d) failed: %s" % (nbytes, L.brx_last_error().decode()))
+    arr = np.ctypeslib.as_array((ctypes.c_ubyte * nbytes).from_address(p))
+    arr = arr.view(np.uint8)
+    _PINNED[arr.ctypes.data] = p
+    return arr
+
+
+def host_free(arr):
+    p = _PINNED.pop(arr.ctypes.data, None)
+    if p:
+        load_library().brx_host_free(p)
+
+
+_PINNED = {}
 _default_ctx = None
 
 
@@ -196,13 +228,19 @@ class Decompressor(io.RawIOBase):
     def readable(self):
         return True
 
-    def readinto(self, b):
+    def prepare(self):
+        """Drain the inner reader and queue the stream on its context WITHOUT decoding: the first read of any queued
+        stream then decodes all of them in one batch (many live Decompressors cost about one batch)."""
         if self._stream is None:
             data = self._reader.read() if hasattr(self._reader, "read") else bytes(self._reader)
             ctx = self._ctx or default_context()
             self._stream = self._lib.brx_stream_new(ctx._h, data, len(data))
             if not self._stream:
                 raise BrxError("brx_stream_new failed")
+        return self
+
+    def readinto(self, b):
+        self.prepare()
         mv = memoryview(b).cast("B")
         buf = (ctypes.c_ubyte * len(mv)).from_buffer(mv) if len(mv) else None
         n = self._lib.brx_stream_read(self._stream, buf, len(mv))

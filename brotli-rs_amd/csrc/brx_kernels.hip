@@ -802,6 +802,35 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
     }
 }
 
+// A long copy whose source lies well behind the ring (distance >= 6 KiB: every source byte of a 4 KiB step is final in
+// HBM once the ring is flushed): HBM -> registers -> HBM, 4 KiB per step with four 16 B/lane loads in flight per lane, no
+// LDS traffic at all; both sides stream at 16 B per lane (the destination 16-byte aligned, the source as it falls).
+// This is the LZ77 back-reference at memory speed (reference copy_literals, src/lib.rs:1483-1505); the ring is re-seeded
+// from HBM afterwards, like after a periodic fill.
+FI void direct_far_copy(Dec &d, Lds &s, u32 de, u32 nblocks) {
+    flush_range(d, s, d.vfl, d.pos + d.a);
+    for (u32 k = 0; k < nblocks; k++) {
+        if (de < 16384u) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the source was stored only a few steps ago
+        const u32 src = d.pos - de + 16u * d.lane, dst = d.pos + 16u * d.lane;
+        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src, 0, 0);
+        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 1024u, 0, 0);
+        const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 2048u, 0, 0);
+        const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 3072u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q0, d.out_rsrc, dst, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q1, d.out_rsrc, dst + 1024u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q2, d.out_rsrc, dst + 2048u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q3, d.out_rsrc, dst + 3072u, 0, 0);
+        d.pos += 4096u;
+    }
+    d.vfl = d.pos + d.a;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the stores are done before their bytes are read back
+    for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) {
+        const u32 off = d.pos - BRX_RING_BYTES + 1024u * j + 16u * d.lane;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, off, 0, 0);
+        *(u32x4 *)&s.ring[(off + d.a) & RMASK] = q;
+    }
+}
+
 FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
     u32 done = 0, de = dist;
     bool bulk_used = false;
@@ -814,6 +843,13 @@ FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
             const u32 nb = rem >> 10;
             periodic_fill(d, s, P16, nb);
             done += nb << 10;
+            bulk_used = true;
+            continue;
+        }
+        if (rem >= 16384u && de >= 4096u + BRX_RING_BYTES && ((d.pos + d.a) & 15u) == 0u) {
+            const u32 nb = rem >> 12;
+            direct_far_copy(d, s, de, nb);
+            done += nb << 12;
             bulk_used = true;
             continue;
         }

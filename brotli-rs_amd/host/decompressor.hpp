@@ -14,8 +14,9 @@
 // Semantics of read(): n > 0 bytes, 0 at end of stream forever after; an invalid stream throws
 // brotli::InvalidData whose what() is the reference's description string (the reference returns
 // io::Error::new(ErrorKind::InvalidData, description), src/lib.rs:2177).  Two documented differences of the
-// whole-stream GPU backend: the inner reader is drained eagerly on the first read, and nothing is delivered
-// for a stream that fails (the reference delivers an unspecified prefix).
+// whole-stream GPU backend: the inner reader is drained eagerly on the first read; for a stream that fails the bytes
+// produced before the error are delivered first, then the error (the reference delivers an unspecified prefix too,
+// SURVEY.md Q13).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -68,14 +69,19 @@ template <class R> class Decompressor {
     Decompressor &operator=(const Decompressor &) = delete;
     ~Decompressor() { brx_stream_free(stream_); }
 
+    // Drain the inner reader and queue the stream on the context without decoding: the first read() of ANY queued
+    // Decompressor then decodes all of them in one batch (brx.h, Read facade).
+    void prepare() {
+        if (stream_) return;
+        std::vector<uint8_t> in;
+        uint8_t tmp[65536];
+        for (size_t k; (k = inner_.read(tmp, sizeof tmp)) > 0;) in.insert(in.end(), tmp, tmp + k);
+        stream_ = brx_stream_new(default_context(), in.data(), in.size());
+        if (!stream_) throw std::runtime_error("brx_stream_new failed");
+    }
+
     size_t read(uint8_t *buf, size_t len) {
-        if (!stream_) {
-            std::vector<uint8_t> in;
-            uint8_t tmp[65536];
-            for (size_t k; (k = inner_.read(tmp, sizeof tmp)) > 0;) in.insert(in.end(), tmp, tmp + k);
-            stream_ = brx_stream_new(default_context(), in.data(), in.size());
-            if (!stream_) throw std::runtime_error("brx_stream_new failed");
-        }
+        prepare();
         int64_t n = brx_stream_read(stream_, buf, len);
         if (n < -900) throw std::runtime_error(std::string("libbrx: ") + brx_last_error());
         if (n < 0) throw InvalidData((int)-n, brx_status_str((int32_t)-n));

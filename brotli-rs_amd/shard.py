@@ -2,12 +2,19 @@
 
 Streams share no state (one reference `Decompressor` owns everything it touches, src/lib.rs:378-394), so the
 batch partitions trivially: rank r of G takes the contiguous index range [r*N/G, (r+1)*N/G).  There is NO
-collective inside the decode.  RCCL (torch.distributed backend "nccl") is used only to move data in and out:
-`scatter_streams` hands every rank its slice of the compressed bytes, `gather_outputs` brings the decoded
-streams back to the root.  Both are ragged (sizes differ per rank), hence size exchange + padded tensors.
+collective inside the decode.  RCCL (torch.distributed backend "nccl") is used only to move data in and out, one
+exchange each way, as grouped point-to-point transfers of RAGGED device buffers (`dist.batch_isend_irecv` =
+ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd): `scatter_ragged` hands every rank exactly its slice of the
+compressed bytes, `gather_ragged` brings the decoded bytes back to the root.  Nothing is padded and nothing takes a
+host hop: the buffers are flat uint8 tensors plus int64 offset tables on the device the process group works on.
 
-All functions take a `dist` process group that is already initialised; they work with gloo on CPU tensors
-(the multi-process tests) and with nccl on cuda tensors unchanged.
+xGMI is point to point (7 links x ~153 GB/s per GPU): the root's egress/ingress is the bound of either exchange, e.g.
+BASELINE config 4 (65536 x quickfox_repeated, 8 GPUs): scatter 0.48 MB per rank, gather 1.44 GB per rank = 10.1 GB
+into the root (~9.5 ms over 7 links); config 5 (8192 x 1 MiB): scatter ~360 MB per rank, gather 1.07 GB per rank.
+
+Every function takes the default process group as it is; they run unchanged over gloo with CPU tensors (the
+multi-process CPU tests) and over nccl with cuda tensors.  The decode in the middle is any callable with the
+device-batch signature of `brx.Context.decode_batch_device` (see `decode_sharded`).
 """
 import numpy as np
 import torch
@@ -27,95 +34,155 @@ def _dev(device):
     return torch.device(device) if device is not None else torch.device("cpu")
 
 
-def scatter_streams(streams, src: int = 0, device=None):
-    """Root holds `streams` (list of bytes, only read on `src`); every rank receives its shard as a list of
-    bytes.  One size exchange (broadcast of the length table) + one scatter of padded byte tensors."""
+def _exchange(ops):
+    """One grouped point-to-point exchange."""
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def scatter_ragged(data, offsets, src: int = 0, device=None):
+    """Root holds the concatenated compressed streams `data` (uint8[total]) and `offsets` (int64[n+1]) on `device`
+    (both ignored elsewhere).  Every rank gets (data_shard, offsets_shard rebased to 0, (a, b), n): exactly its bytes,
+    one broadcast of the offset table + one grouped send/recv."""
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = _dev(device)
+    meta = torch.zeros(1, dtype=torch.int64, device=dev)
     if rank == src:
-        lens = torch.tensor([len(s) for s in streams], dtype=torch.int64)
-        meta = torch.tensor([len(streams)], dtype=torch.int64)
-    else:
-        meta = torch.zeros(1, dtype=torch.int64)
-    meta = meta.to(dev)
+        meta[0] = offsets.numel() - 1
     dist.broadcast(meta, src)
     n = int(meta.item())
-    lens = lens.to(dev) if rank == src else torch.zeros(n, dtype=torch.int64, device=dev)
-    if n:
-        dist.broadcast(lens, src)
-    lens_h = lens.cpu().numpy()
+    table = offsets.to(dev) if rank == src else torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    dist.broadcast(table, src)
+    table_h = table.cpu().numpy()
     ranges = shard_ranges(n, world)
-    shard_bytes = [int(lens_h[a:b].sum()) for a, b in ranges]
-    pad = max(shard_bytes + [1])
-    recv = torch.zeros(pad, dtype=torch.uint8, device=dev)
-    if rank == src:
-        chunks = []
-        for a, b in ranges:
-            buf = np.zeros(pad, dtype=np.uint8)
-            blob = b"".join(streams[a:b])
-            buf[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
-            chunks.append(torch.from_numpy(buf).to(dev))
-        dist.scatter(recv, chunks, src=src)
-    else:
-        dist.scatter(recv, None, src=src)
     a, b = ranges[rank]
-    mine = recv.cpu().numpy().tobytes()
-    out, at = [], 0
-    for ln in lens_h[a:b]:
-        out.append(mine[at:at + int(ln)])
-        at += int(ln)
-    return out, (a, b), n
+    lo, hi = int(table_h[a]), int(table_h[b])
+    ops = []
+    if rank == src:
+        mine = data[lo:hi]
+        for r, (ra, rb) in enumerate(ranges):
+            if r != src and table_h[rb] > table_h[ra]:
+                ops.append(dist.P2POp(dist.isend, data[int(table_h[ra]):int(table_h[rb])], r))
+    else:
+        mine = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, mine, src))
+    _exchange(ops)
+    return mine, (table[a:b + 1] - table[a]).contiguous(), (a, b), n
 
 
-def gather_outputs(outputs, status, n_total: int, dst: int = 0, device=None):
-    """Every rank contributes the decoded streams of its shard (list of bytes) and their status codes; the
-    root gets the full lists back in stream order.  Non-root ranks return (None, None)."""
+def compact(out, out_off, out_len):
+    """The decoded bytes of a shard without the slack of the capacity slots: (flat uint8 tensor, int64 offsets[n+1]),
+    computed on the device (one gather by index)."""
+    n = out_len.numel()
+    lens = out_len.to(torch.int64)
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=out.device)
+    if n:
+        offs[1:] = torch.cumsum(lens, 0)
+    total = int(offs[-1].item()) if n else 0
+    if total == 0:
+        return torch.empty(0, dtype=torch.uint8, device=out.device), offs
+    src_start = out_off[:-1].to(torch.int64)
+    idx = torch.repeat_interleave(src_start - offs[:-1], lens) + torch.arange(total, dtype=torch.int64, device=out.device)
+    return out[idx], offs
+
+
+def gather_ragged(data, offsets, status, n_total: int, dst: int = 0, device=None):
+    """Every rank contributes the decoded bytes of its shard (`data` uint8[..], `offsets` int64[k+1] rebased to 0) and
+    the k status codes.  The root returns (data uint8[total] in stream order, offsets int64[n_total+1], status
+    int32[n_total]); the other ranks (None, None, None).  One gather of the small tables + one grouped send/recv."""
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = _dev(device)
     ranges = shard_ranges(n_total, world)
     a, b = ranges[rank]
-    assert len(outputs) == b - a == len(status)
+    k = b - a
+    assert offsets.numel() == k + 1 and status.numel() == k
     width = max((hi - lo for lo, hi in ranges), default=0)
     meta = torch.zeros(2 * max(width, 1), dtype=torch.int64, device=dev)
-    if b > a:
-        meta[:b - a] = torch.tensor([len(o) for o in outputs], dtype=torch.int64)
-        meta[width:width + (b - a)] = torch.tensor([int(s) for s in status], dtype=torch.int64)
+    if k:
+        meta[:k] = (offsets[1:] - offsets[:-1]).to(torch.int64)
+        meta[width:width + k] = status.to(torch.int64)
     metas = [torch.zeros_like(meta) for _ in range(world)] if rank == dst else None
     dist.gather(meta, metas, dst=dst)
-    total = torch.tensor([sum(len(o) for o in outputs)], dtype=torch.int64, device=dev)
-    dist.all_reduce(total, op=dist.ReduceOp.MAX)
-    pad = max(int(total.item()), 1)
-    buf = np.zeros(pad, dtype=np.uint8)
-    blob = b"".join(outputs)
-    buf[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
-    send = torch.from_numpy(buf).to(dev)
-    recvs = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recvs, dst=dst)
+    nbytes = int(offsets[-1].item()) if k else 0
+    ops = []
     if rank != dst:
-        return None, None
-    all_out, all_st = [], []
+        if nbytes:
+            ops.append(dist.P2POp(dist.isend, data[:nbytes].contiguous(), dst))
+        _exchange(ops)
+        return None, None, None
+    lens = torch.cat([metas[r][:hi - lo] for r, (lo, hi) in enumerate(ranges)]) if n_total else torch.zeros(0, dtype=torch.int64, device=dev)
+    st = torch.cat([metas[r][width:width + hi - lo] for r, (lo, hi) in enumerate(ranges)]).to(torch.int32) if n_total else torch.zeros(0, dtype=torch.int32, device=dev)
+    offs = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+    if n_total:
+        offs[1:] = torch.cumsum(lens, 0)
+    offs_h = offs.cpu().numpy()
+    full = torch.empty(int(offs_h[-1]), dtype=torch.uint8, device=dev)
     for r, (lo, hi) in enumerate(ranges):
-        m = metas[r].cpu().numpy()
-        raw = recvs[r].cpu().numpy().tobytes()
-        at = 0
-        for i in range(hi - lo):
-            ln = int(m[i])
-            all_out.append(raw[at:at + ln])
-            all_st.append(int(m[width + i]))
-            at += ln
-    return all_out, all_st
+        p0, p1 = int(offs_h[lo]), int(offs_h[hi])
+        if p1 == p0:
+            continue
+        if r == dst:
+            full[p0:p1] = data[:nbytes]
+        else:
+            ops.append(dist.P2POp(dist.irecv, full[p0:p1], r))  # lands in place: contiguous slice of the result
+    _exchange(ops)
+    return full, offs, st
 
 
-def decode_sharded(streams, capacities, decode_fn, src: int = 0, device=None):
-    """scatter -> local decode -> gather.  `decode_fn(list_of_streams, list_of_capacities)` must return
-    (outputs, status); in production it is `brx.Context.decode_batch` (the HIP path)."""
+def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=None):
+    """scatter -> local decode -> gather, device resident end to end.
+
+    Root passes `data` uint8[total], `offsets` int64[n+1], `capacities` int64[n] (tensors on `device`).
+    `decode_fn(in_t, in_off_t, n, out_t, out_off_t, out_len_t, status_t)` fills the last three for the n streams of the
+    shard; on a GPU it is a thin lambda over `brx.Context.decode_batch_device(in_t.data_ptr(), ...)` -- the HIP path --
+    and in the CPU tests a stand-in with the same signature.  Returns gather_ragged's result."""
     rank = dist.get_rank()
-    shard, (a, b), n = scatter_streams(streams, src=src, device=device)
-    caps_t = torch.zeros(max(n, 1), dtype=torch.int64, device=_dev(device))
+    dev = _dev(device)
+    shard, offs, (a, b), n = scatter_ragged(data, offsets, src=src, device=dev)
+    caps = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
     if rank == src:
-        caps_t[:n] = torch.tensor(list(capacities), dtype=torch.int64)
-    dist.broadcast(caps_t, src)
-    caps = [int(c) for c in caps_t.cpu().numpy()[a:b]]
-    res = decode_fn(shard, caps) if b > a else ([], [])
-    outs, st = res[0], res[1]
-    return gather_outputs(list(outs), list(st), n, dst=src, device=device)
+        caps[:n] = capacities.to(dev)
+    dist.broadcast(caps, src)
+    k = b - a
+    my_caps = (caps[a:b] + 15) & ~15  # 16-byte aligned slots: full-width flushes
+    out_off = torch.zeros(k + 1, dtype=torch.int64, device=dev)
+    if k:
+        out_off[1:] = torch.cumsum(my_caps, 0)
+    out = torch.empty(int(out_off[-1].item()) if k else 0, dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(k, dtype=torch.int64, device=dev)
+    status = torch.full((k,), -1, dtype=torch.int32, device=dev)
+    if k:
+        decode_fn(shard, offs, k, out, out_off, out_len, status)
+    produced = torch.where(status == 0, out_len, torch.zeros_like(out_len))  # a failed stream contributes no bytes
+    cdata, coffs = compact(out, out_off, produced)
+    return gather_ragged(cdata, coffs, status, n, dst=src, device=dev)
+
+
+# ---- convenience for callers that hold Python byte strings ----------------------------------------------------------
+def pack(streams, device=None):
+    """list of bytes -> (uint8 tensor, int64 offsets) on `device`."""
+    dev = _dev(device)
+    lens = np.array([len(s) for s in streams], dtype=np.int64)
+    offs = np.zeros(len(streams) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint8) if offs[-1] else np.zeros(0, dtype=np.uint8)
+    return torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offs).to(dev)
+
+
+def unpack(data, offsets):
+    """(uint8 tensor, int64 offsets) -> list of bytes (host)."""
+    raw = data.cpu().numpy().tobytes()
+    o = offsets.cpu().numpy()
+    return [raw[int(o[i]):int(o[i + 1])] for i in range(len(o) - 1)]
+
+
+def hip_decode_fn(ctx):
+    """The HIP path as a decode_fn for decode_sharded: raw device pointers into brx.Context.decode_batch_device."""
+    def fn(in_t, in_off_t, n, out_t, out_off_t, out_len_t, status_t):
+        torch.cuda.synchronize(in_t.device)  # the library's stream is not ordered after torch's (brx.h)
+        ctx.decode_batch_device(in_t.data_ptr(), in_off_t.data_ptr(), n, out_t.data_ptr(), out_off_t.data_ptr(),
+                                out_len_t.data_ptr(), status_t.data_ptr())
+        ctx.synchronize()
+    return fn

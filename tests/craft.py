@@ -500,3 +500,24 @@ def trailer_nibble_stream(nibbles):
     b.put(0x1234, 4 * nibbles)  # top nibble(s) zero
     b.put(0, 64)
     return b.bytes()
+
+
+def farcopy_stream(seed, first=1 << 16, total=1 << 20, wbits=21):
+    """The LZ77 back-reference at memory speed (BASELINE north_star "copy kernel" evidence): `first` random bytes as one
+    uncompressed meta-block, then ONE compressed meta-block of back-to-back NON-overlapping copies, each doubling the
+    output (copy n bytes from distance n, n = first, 2 first, ...) up to `total` bytes.  Every copied byte is read once
+    from HBM and written once: physical traffic = 2 bytes per output byte (minus the first block).
+    Returns (stream, expected output)."""
+    rng = random.Random(seed)
+    data = bytes(rng.getrandbits(8) for _ in range(first))
+    b = Bits()
+    stream_header(b, wbits)
+    raw_block(b, data)
+    out = bytearray(data)
+    cmds = []
+    while len(out) < total:
+        n = len(out)
+        cmds.append((b"", n, n))
+        out += out[:n]
+    MetaBlock(cmds, mlen=len(out) - first).emit(b, True, 0)
+    return b.bytes(), bytes(out)

@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP path, called through the C ABI (libbrx.so), against the CPU oracle and the
 reference's golden vectors.  Bit-exact output for valid streams, identical error kind for invalid ones."""
+import ctypes
 import hashlib
 import io
 import json
@@ -356,3 +357,134 @@ def test_cpp_only_command_loops(stop):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_farcopy_streams(ctx):
+    """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
+    streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
+    OVERLAPPING copies whose distance (>= 6 KiB) keeps them on the same path; unaligned output slots."""
+    import craft
+    streams, expects = [], []
+    for seed, (first, total) in enumerate([(1 << 16, 1 << 20), (8192, 1 << 16), (1 << 14, 1 << 19), (6145, 200000), (1 << 16, 1 << 18)]):
+        s, e = craft.farcopy_stream(seed, first, total)
+        streams.append(s)
+        expects.append(e)
+    rng = random.Random(5)
+    for dist, length in ((7000, 100000), (6144, 50000), (20000, 300001), (65000, 70000), (6200, 16384), (9999, 16383)):
+        data = bytes(rng.getrandbits(8) for _ in range(max(dist, 8192) + 37))
+        b = craft.Bits()
+        craft.stream_header(b, 22)
+        craft.raw_block(b, data)
+        craft.MetaBlock([(b"ab", length, dist), (b"tail of the stream", 0, None)], mlen=2 + length + 18).emit(b, True, 0)
+        s = b.bytes()
+        st, e = oracle.decode(s)
+        assert st == 0 and len(e) == len(data) + 2 + length + 18
+        streams.append(s)
+        expects.append(e)
+    for pad in (0, 5):
+        outs, status, out_len = ctx.decode_batch(streams * 3, [len(e) + pad for e in expects] * 3)
+        assert not status.any(), status
+        for o, e in zip(outs, expects * 3):
+            assert o == e
+
+
+def test_two_overlapping_device_batches_on_two_hip_streams(ctx):
+    """Two BRX_MEM_DEVICE calls on one context, enqueued back to back on two HIP streams without a host sync in
+    between: each launch has its own work counter, spill slabs are claimed by the waves from the shared pool
+    (metablock_reset spills its tables to HBM), the results must be those of the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    jobs = []
+    for name, n in (("alice29.txt", 700), ("metablock_reset", 96)):
+        comp, exp = _read(name + ".compressed"), _read(name)
+        cap = (len(exp) + 15) & ~15
+        blob = torch.frombuffer(bytearray(comp * n), dtype=torch.uint8).to(dev)
+        in_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * len(comp)
+        out_off = torch.arange(n + 1, dtype=torch.int64, device=dev) * cap
+        out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        jobs.append((n, cap, exp, blob, in_off, out_off, out, out_len, status, torch.cuda.Stream(device=dev)))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for n, cap, exp, blob, in_off, out_off, out, out_len, status, st in jobs:
+            out.zero_()
+        torch.cuda.synchronize()
+        for n, cap, exp, blob, in_off, out_off, out, out_len, status, st in jobs:  # no sync between the two launches
+            ctx.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
+                                    out_len.data_ptr(), status.data_ptr(), hip_stream=st.cuda_stream)
+        for job in jobs:
+            job[-1].synchronize()
+        for n, cap, exp, blob, in_off, out_off, out, out_len, status, st in jobs:
+            assert status.cpu().tolist() == [0] * n
+            assert out_len.cpu().tolist() == [len(exp)] * n
+            want = np.frombuffer(exp, dtype=np.uint8)
+            assert (out.cpu().numpy().reshape(n, cap)[:, :len(exp)] == want[None, :]).all()
+
+
+def test_pooled_decompressors_decode_as_one_batch(ctx):
+    """256 live Decompressors on one context: the first read decodes all of them in ONE batch (brx.h, Read facade);
+    every one must then serve its own bytes.  Also: a stream that fails serves the bytes produced before the error first
+    (the reference delivers a prefix too)."""
+    import time
+    from brotli_rs_amd import brx
+    names = ["alice29.txt", "asyoulik.txt", "monkey", "quickfox_repeated", "x", "10x10y", "lcet10.txt", "zeros"]
+    t0 = time.perf_counter()
+    one = brx.Decompressor(io.BytesIO(_read("alice29.txt.compressed")), ctx)
+    assert one.read() == _read("alice29.txt")
+    t_one = time.perf_counter() - t0
+    one.close()
+    decs = [brx.Decompressor(io.BytesIO(_read(names[i % len(names)] + ".compressed")), ctx) for i in range(256)]
+    for d in decs:
+        d.prepare()  # drain the inner reader, queue on the context; nothing is decoded yet
+    t0 = time.perf_counter()
+    got0 = decs[0].read()
+    t_first = time.perf_counter() - t0
+    assert got0 == _read(names[0])
+    t0 = time.perf_counter()
+    for i, d in enumerate(decs[1:], 1):
+        assert d.read() == _read(names[i % len(names)]), i
+    t_rest = time.perf_counter() - t0
+    for d in decs:
+        d.close()
+    assert t_rest < max(4 * t_first, 0.5), (t_one, t_first, t_rest)  # the other 255 were decoded by the first read
+    # prefix before the error
+    L = brx.load_library()
+    bad = bytearray(_read("alice29.txt.compressed"))[:30000]
+    want = oracle.decode(bytes(bad), 0, cap=1 << 20)
+    assert want[0] != 0 and len(want[1]) > 1000
+    h = L.brx_stream_new(ctx._h, bytes(bad), len(bad))
+    buf = (ctypes.c_ubyte * 65536)()
+    got = bytearray()
+    while True:
+        n = L.brx_stream_read(h, buf, 65536)
+        if n <= 0:
+            break
+        got += bytes(buf[:n])
+    assert n == -want[0]
+    assert len(got) > 1000 and bytes(got) == _read("alice29.txt")[:len(got)]
+    assert L.brx_stream_read(h, buf, 65536) == -want[0]  # and the error again, forever
+    L.brx_stream_free(h)
+
+
+def test_host_pipeline_with_pinned_buffers(ctx):
+    """brx_decode_batch with host pointers into pinned memory (brx_host_alloc): the batch is cut into chunks whose
+    H2D copy / decode / D2H copy overlap on three HIP streams; results as usual."""
+    from brotli_rs_amd import brx
+    comp, exp = _read("alice29.txt.compressed"), _read("alice29.txt")
+    n = 1024
+    cap = (len(exp) + 15) & ~15
+    pin_in = brx.host_alloc(len(comp) * n)
+    pin_out = brx.host_alloc(cap * n)
+    try:
+        pin_in[:] = np.frombuffer(comp * n, dtype=np.uint8)
+        pin_out[:] = 0
+        in_off = (np.arange(n + 1, dtype=np.uint64) * len(comp))
+        out_off = (np.arange(n + 1, dtype=np.uint64) * cap)
+        status, out_len = ctx.decode_batch_host_raw(pin_in.ctypes.data, in_off, n, pin_out.ctypes.data, out_off)
+        assert not status.any() and (out_len == len(exp)).all()
+        want = np.frombuffer(exp, dtype=np.uint8)
+        assert (pin_out.reshape(n, cap)[:, :len(exp)] == want[None, :]).all()
+    finally:
+        brx.host_free(pin_in)
+        brx.host_free(pin_out)
