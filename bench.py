@@ -352,10 +352,19 @@ def main():
                 res["cpu_all_cores"] = json.loads(o.stdout.strip().splitlines()[-1])
             except Exception:
                 pass
-        print(json.dumps(res), flush=True)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()  # (RCCL prints its library path to stdout around here: the JSON line goes last)
+    used_rccl = "gather_info" in dir() and (world > 1 or args.gather)
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
+    if used_rccl:
+        # RCCL prints "Librccl path : ..." to stdout from a destructor at interpreter exit; the contract is ONE JSON line
+        # (and it must be the last thing on stdout): leave without running destructors -- everything is flushed and closed.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0 if ok else 2)
     if not ok:
         sys.exit(2)
 

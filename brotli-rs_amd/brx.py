@@ -64,6 +64,8 @@ def load_library():
     L.brx_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.brx_stream_new.restype = ctypes.c_void_p
     L.brx_stream_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.brx_stream_new_bounded.restype = ctypes.c_void_p
+    L.brx_stream_new_bounded.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.brx_stream_read.restype = ctypes.c_int64
     L.brx_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     L.brx_stream_free.restype = None
@@ -78,7 +80,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
-                    "brx_host_alloc", "brx_host_free"]
+                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded"]
 
 
 def status_str(code: int) -> str:

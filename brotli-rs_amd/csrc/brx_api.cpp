@@ -332,7 +332,7 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
-                  const uint32_t *d_order = nullptr) {
+                  const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr) {
     BrxKernelArgs a;
     a.order = d_order;
     a.in = d_in;
@@ -344,10 +344,14 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.n = n;
     a.debug_stop = c->debug_stop;
     unsigned grid = n < c->max_grid ? n : c->max_grid;
-    int rc = ensure_pool(c, grid);
-    if (rc) return rc;
+    a.pool = d_own_pool;
+    if (!d_own_pool) {
+        int rc = ensure_pool(c, grid);
+        if (rc) return rc;
+        a.pool = c->d_pool;
+    }
+    a.resume = d_resume;
     a.work_counter = c->d_counters + (size_t)(c->launch_seq++ % BRX_COUNTER_RING) * 16u; // one 64-B line per launch
-    a.pool = c->d_pool;
     a.debug = nullptr;
     unsigned long long *dbg = nullptr;
     if (c->debug_stats) {
@@ -552,7 +556,95 @@ struct brx_stream {
     bool decoded = false;
     int32_t status = 0;
     int lib_rc = BRX_SUCCESS;
+    // bounded mode (large streams): decoded slice by slice into a sliding device window, never more resident than
+    // BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK of output (+ the compressed input + one spill slab)
+    bool bounded = false, finished = false;
+    uint8_t *d_in = nullptr, *d_buf = nullptr;
+    BrxResume *d_rec = nullptr;
+    BrxSlabPool *d_pool = nullptr;
+    uint32_t *d_bitmap = nullptr, *d_slab = nullptr;
+    uint64_t *d_meta = nullptr; // in_off[2] | out_off[2] | out_len[1] | status
+    uint64_t shift = 0, pos = 0, delivered = 0;
 };
+#define BRX_BOUNDED_WINDOW (16u << 20) // the largest Brotli window, (1 << 24) - 16, rounded up
+#define BRX_BOUNDED_CHUNK (4u << 20)   // output decoded per slice
+#define BRX_BOUNDED_SLACK ((1u << 20) + 65536u) // room for the command that crosses the slice end
+#define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
+
+static void bounded_release(brx_stream *s) {
+    if (!s->d_buf && !s->d_in) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    (void)hipFree(s->d_in);
+    (void)hipFree(s->d_buf);
+    (void)hipFree(s->d_rec);
+    (void)hipFree(s->d_pool);
+    (void)hipFree(s->d_bitmap);
+    (void)hipFree(s->d_slab);
+    (void)hipFree(s->d_meta);
+    s->d_in = s->d_buf = nullptr;
+    s->d_rec = nullptr;
+    s->d_pool = nullptr;
+    s->d_bitmap = s->d_slab = nullptr;
+    s->d_meta = nullptr;
+}
+
+static int bounded_init(brx_stream *s) {
+    brx_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bufsize = (size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK;
+    HIP_TRY(hipMalloc(&s->d_in, s->in.size() + 16));
+    HIP_TRY(hipMalloc(&s->d_buf, bufsize));
+    HIP_TRY(hipMalloc(&s->d_rec, sizeof(BrxResume)));
+    HIP_TRY(hipMalloc(&s->d_pool, sizeof(BrxSlabPool)));
+    HIP_TRY(hipMalloc(&s->d_bitmap, 4));
+    HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u));
+    HIP_TRY(hipMalloc(&s->d_meta, 64));
+    HIP_TRY(hipMemcpy(s->d_in, s->in.data(), s->in.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_rec, 0, 16));
+    const uint32_t only_slab_0 = 0xfffffffeu; // a private pool of ONE slab that survives between the slices
+    HIP_TRY(hipMemcpy(s->d_bitmap, &only_slab_0, 4, hipMemcpyHostToDevice));
+    BrxSlabPool p = {s->d_bitmap, s->d_slab, 32};
+    HIP_TRY(hipMemcpy(s->d_pool, &p, sizeof p, hipMemcpyHostToDevice));
+    return BRX_SUCCESS;
+}
+
+// Decode the next slice: up to BRX_BOUNDED_CHUNK more bytes (to the next command boundary past it).
+static int bounded_step(brx_stream *s) {
+    brx_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bufsize = (size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK;
+    if (s->pos - s->shift + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK > bufsize) {
+        // slide the window: keep the last BRX_BOUNDED_WINDOW bytes (every back-reference reaches at most that far); the
+        // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged
+        const uint64_t new_shift = (s->pos - BRX_BOUNDED_WINDOW) & ~15ull;
+        const uint64_t delta = new_shift - s->shift, keep = s->pos - new_shift;
+        for (uint64_t done = 0; done < keep; done += delta) { // forward, in pieces no longer than the move: no overlap
+            const size_t piece = (size_t)std::min<uint64_t>(delta, keep - done);
+            HIP_TRY(hipMemcpyAsync(s->d_buf + done, s->d_buf + delta + done, piece, hipMemcpyDeviceToDevice, c->stream));
+        }
+        s->shift = new_shift;
+    }
+    const uint64_t cap_abs = std::min<uint64_t>(s->shift + bufsize, BRX_STREAM_LIMIT);
+    const uint64_t pause_at = s->pos + BRX_BOUNDED_CHUNK;
+    uint64_t meta[4] = {0, s->in.size(), 0, cap_abs};
+    HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), &pause_at, 8, hipMemcpyHostToDevice, c->stream));
+    uint8_t *virt = (uint8_t *)((uintptr_t)s->d_buf - (uintptr_t)s->shift); // address of output byte 0, were it still resident
+    int rc = launch(c, c->stream, false, s->d_in, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
+                    (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
+    if (rc) return rc;
+    uint64_t res[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(res, s->d_meta + 4, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t st = (int32_t)(res[1] & 0xffffffffu);
+    if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // one command larger than the slack (caller falls back)
+    s->pos = res[0];
+    if (st != BRX_PAUSED) {
+        s->finished = true;
+        s->status = st;
+    }
+    return BRX_SUCCESS;
+}
 
 static void stream_detach(brx_stream *s) {
     s->ctx = nullptr;
@@ -572,14 +664,31 @@ extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n)
     s->ctx = ctx;
     try {
         s->in.assign(in, in + n);
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->pending.push_back(s);
+        s->bounded = n >= BRX_BOUNDED_THRESHOLD;
+        if (!s->bounded) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->pending.push_back(s);
+        }
     } catch (...) {
         delete s;
         throw;
     }
     return s;
     BRX_GUARD_END(nullptr, nullptr)
+}
+
+extern "C" brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n) {
+    brx_stream *s = brx_stream_new(ctx, in, n);
+    if (s && !s->bounded) {
+        try {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            auto &p = ctx->pending;
+            p.erase(std::remove(p.begin(), p.end(), s), p.end());
+        } catch (...) {
+        }
+        s->bounded = true;
+    }
+    return s;
 }
 
 // Decode every pending stream of the context in one batch; streams whose guessed capacity was too small go into
@@ -639,6 +748,45 @@ static void decode_pending_locked(brx_ctx *c) {
 extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
     BRX_GUARD_BEGIN
     if (!s) return -(int64_t)BRX_UNEXPECTED_EOF;
+    if (s->bounded) {
+        brx_ctx *c = s->ctx;
+        if (!c) return -(int64_t)1000 + BRX_ERR_INVALID_ARGUMENT;
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (;;) {
+            if (s->lib_rc != BRX_SUCCESS) return -(int64_t)1000 + s->lib_rc;
+            if (s->delivered < s->pos) {
+                const size_t k = (size_t)std::min<uint64_t>(len, s->pos - s->delivered);
+                if (k == 0) return 0;
+                if (hipSetDevice(c->device) != hipSuccess ||
+                    hipMemcpy(buf, s->d_buf + (s->delivered - s->shift), k, hipMemcpyDeviceToHost) != hipSuccess) {
+                    s->lib_rc = fail(BRX_ERR_HIP, "brx_stream_read: device to host copy failed");
+                    continue;
+                }
+                s->delivered += k;
+                return (int64_t)k;
+            }
+            if (s->finished) {
+                bounded_release(s);
+                return s->status == BRX_OK ? 0 : -(int64_t)s->status; // the bytes before an error were served first
+            }
+            if (!s->d_buf) {
+                int rc = bounded_init(s);
+                if (rc) { bounded_release(s); s->lib_rc = rc; continue; }
+            }
+            int rc = bounded_step(s);
+            if (rc == BRX_ERR_OUT_OF_MEMORY && !s->finished) {
+                // a single command (a copy or an uncompressed meta-block) larger than the slack: decode the whole stream
+                // the unbounded way and go on serving from where this reader stands
+                bounded_release(s);
+                s->bounded = false;
+                s->served = (size_t)s->delivered;
+                c->pending.push_back(s);
+                decode_pending_locked(c);
+                break;
+            }
+            if (rc) { bounded_release(s); s->lib_rc = rc; }
+        }
+    }
     if (!s->decoded) {
         brx_ctx *c = s->ctx;
         std::lock_guard<std::mutex> lk(c->mu);
@@ -659,6 +807,7 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
 
 extern "C" void brx_stream_free(brx_stream *s) {
     if (!s) return;
+    bounded_release(s);
     try {
         if (s->ctx && !s->decoded) {
             std::lock_guard<std::mutex> lk(s->ctx->mu);

@@ -40,6 +40,17 @@ struct BrxDeviceTables {
                                 // << 8}, then at dword 2816 64 dwords DOFFSET | NDBITS << 24
 };
 
+// Resumable decode of ONE stream with bounded output memory (the Read facade for very large streams):
+// the kernel stops at the first command boundary at or beyond `pause_at`, flushes its ring, parks the whole wave state
+// (its LDS) here and reports BRX_PAUSED; the next launch picks up from it against a slid output window.
+struct BrxResume {
+    uint32_t state;  // 0 = fresh stream, 1 = paused (lds valid), 2 = finished
+    uint32_t phase;  // where to resume (kernel-internal)
+    uint64_t pause_at;
+    uint32_t lds[2560];
+};
+#define BRX_PAUSED 28 // per-stream status of a paused resumable decode (never leaves brx_api.cpp)
+
 struct BrxKernelArgs {
     const uint8_t *in;
     const uint64_t *in_off;
@@ -56,6 +67,7 @@ struct BrxKernelArgs {
     uint32_t *dump;         // bring-up (BRX_DEBUG_DUMP, debug_stop 9): word 0 = records written, then records of
                             // BRX_DUMP_WORDS words: {stream id, command index, 14 spare, the wave's whole LDS}
     uint32_t dump_interval, dump_max;
+    BrxResume *resume;      // nullptr, or one record per stream: resumable mode (see BrxResume)
     BrxDeviceTables t;
 };
 

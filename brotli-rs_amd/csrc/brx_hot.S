@@ -179,6 +179,35 @@
 // arithmetic on the window in uniform VGPRs, and the common path of a command has as few branches as it can.
 // Refill discipline: >= 32 valid bits at .Lcmd; an insert&copy symbol (<= 15) leaves >= 17, enough for a literal or a
 // distance symbol (<= 15); every literal, every extra-bit field > 0 and the distance symbol are followed by a check.
+// (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
+#ifdef BRX_PROF
+#define LDS_PAD 10112
+.macro PROF_WAIT_VM
+    s_waitcnt lgkmcnt(0)
+    s_memtime s[16:17]
+    s_waitcnt lgkmcnt(0)
+    s_waitcnt vmcnt(0)
+    s_memtime s[18:19]
+    s_waitcnt lgkmcnt(0)
+    s_sub_u32 s18, s18, s16
+    s_add_u32 s20, s20, s18
+    s_add_u32 s21, s21, 1
+    s_add_u32 s22, s22, PFREE
+.endm
+// section timers: s[16:17] = start of the running section; \acc = accumulator of the section that ends here
+.macro PROF_MARK acc
+    s_memtime s[18:19]
+    s_waitcnt lgkmcnt(0)
+    s_sub_u32 s17, s18, s16
+    s_add_u32 \acc, \acc, s17
+    s_mov_b32 s16, s18
+.endm
+#else
+.macro PROF_WAIT_VM
+.endm
+.macro PROF_MARK acc
+.endm
+#endif
 .macro TAKE n
     v_lshrrev_b64 VWIN, \n, VWIN
     s_sub_u32 SNAV, SNAV, \n
@@ -530,7 +559,13 @@
     s_mov_b32 s20, 0
     s_mov_b32 s21, 0
     s_mov_b32 s22, 0
+    s_mov_b32 s23, 0
+    s_mov_b32 s29, 0
+    s_mov_b32 s30, 0
+    s_mov_b32 s31, 0
     s_memtime s[12:13]
+    s_memtime s[16:17]
+    s_waitcnt lgkmcnt(0)
 #endif
     s_mov_b32 PFREE, 0
     s_mov_b32 PBASE, POS
@@ -555,6 +590,7 @@
 
 // ======================================================================================================== R0
 .Lcmd:
+    PROF_MARK s31                                       // copy + tail
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
     LOOKUP2 VIACL, VIACB, HISYM, 1, ds_read_u16, 0
@@ -567,6 +603,7 @@
 
 // ======================================================================================================== R1
 .Lr1:
+    PROF_MARK s23                                       // insert&copy symbol (+ extras; + entry)
     // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
     v_readlane_b32 DTREE, VDH4, DCTX
     s_max_i32 T0, DTREE, 0                              // (a one-symbol tree has no header: read anything)
@@ -575,6 +612,7 @@
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
+    PROF_MARK s29                                       // R1 dispatch + literals
     s_min_u32 MAXA, POS, WINDOW
     s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc1 .Ldist_special                       // implicit distance 0, or a one-symbol tree
@@ -598,6 +636,7 @@
     TAKE T1
     v_readfirstlane_b32 DIST, VEX
 .Ldist_push:
+    PROF_MARK s30                                       // distance symbol
     s_cmp_gt_u32 DIST, MAXA
     s_cbranch_scc1 .Ldict                               // :1476 not pushed: static dictionary reference
     v_mov_b32 VD3, VD2                                  // (only the most recent distance lives in an SGPR)
@@ -889,25 +928,6 @@
 // literals never sit between pending copies: a literal run lands everything first).  One masked byte store.
 // Clobbers T6, VT1.  .Lland_ctx also derives the literal context from the last two bytes of the stream (VC = id * 4,
 // VB4 = p1's share as a future p2) and requests the tree descriptor of the first literal.
-// (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
-#ifdef BRX_PROF
-#define LDS_PAD 10112
-.macro PROF_WAIT_VM
-    s_waitcnt lgkmcnt(0)
-    s_memtime s[16:17]
-    s_waitcnt lgkmcnt(0)
-    s_waitcnt vmcnt(0)
-    s_memtime s[18:19]
-    s_waitcnt lgkmcnt(0)
-    s_sub_u32 s18, s18, s16
-    s_add_u32 s20, s20, s18
-    s_add_u32 s21, s21, 1
-    s_add_u32 s22, s22, PFREE
-.endm
-#else
-.macro PROF_WAIT_VM
-.endm
-#endif
 .macro LAND_BODY
     s_add_u32 T6, PBASE, SKEW
     v_add_u32 VT1, T6, VLANE
@@ -1277,6 +1297,14 @@
     ds_add_u32 VZERO, VT1 offset:LDS_PAD+44             // pad[11]: landings with something pending
     ds_add_u32 VZERO, VT2 offset:LDS_PAD+48             // pad[12]: bytes landed
     ds_add_u32 VZERO, VT3 offset:LDS_PAD+52             // pad[13]: cycles inside the assembly loop
+    v_mov_b32 VT0, s23
+    v_mov_b32 VT1, s29
+    v_mov_b32 VT2, s30
+    v_mov_b32 VT3, s31
+    ds_add_u32 VZERO, VT0 offset:LDS_PAD+24             // pad[6]: insert&copy symbol sections
+    ds_add_u32 VZERO, VT1 offset:LDS_PAD+28             // pad[7]: literal sections
+    ds_add_u32 VZERO, VT2 offset:LDS_PAD+56             // pad[14]: distance sections
+    ds_add_u32 VZERO, VT3 offset:LDS_PAD+60             // pad[15]: copy + tail sections
 #endif
     // real block counters if they were poisoned
     s_bitcmp1_b32 FLAGS, 0

@@ -1179,7 +1179,7 @@ __device__ __noinline__ u32 asm_commands() {
 #include "_gen/brx_hot_asm.h"
         :
         :
-        : "memory", "vcc", "scc", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+        : "memory", "vcc", "scc", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s29", "s30", "s31", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
           "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
           "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
           "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
@@ -1635,6 +1635,68 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                 s.st[ST_IACTAB] = (u32)(uintptr_t)a.t.iac; s.st[ST_IACTAB + 1] = (u32)((u64)(uintptr_t)a.t.iac >> 32);
             }
             if (lane < 32u) s.pad[lane] = 0u;
+        }
+        if (a.resume != nullptr) {
+            // ---- resumable mode: one stream decoded in slices against a sliding output window (brx_api.cpp, streaming
+            // Read facade).  Pauses only between the out-of-line segments, where the whole state sits in LDS.
+            BrxResume *rec = a.resume + sid;
+            enum { PH_FRAME = 0, PH_LOOP = 1 };
+            u32 phase = PH_FRAME;
+            u32 st = 0;
+            if (rfl(rec->state) == 1u) {
+                u32 *dst = (u32 *)&s;
+                for (u32 w = lane; w < BRX_LDS_BYTES / 4u; w += 64u) dst[w] = rec->lds[w];
+                if (lane == 0u) { // the output window has moved: same bytes, new base (a multiple of 16 away) and capacity
+                    const u64 op = (u64)(uintptr_t)(a.out + o0);
+                    const u64 capacity = o1 >= o0 ? o1 - o0 : 0ull;
+                    const u32 cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
+                    s.st[7] = (u32)op; s.st[8] = (u32)(op >> 32); s.st[9] = cap;
+                    const u64 wdl = 8ull * (i1 - i0) + (u64)cap + 65536ull;
+                    s.st[31] = (u32)wdl; s.st[32] = (u32)(wdl >> 32);
+                }
+                phase = rfl(rec->phase);
+                st = phase == PH_LOOP ? HC_CONTINUE : 0u;
+            }
+            const u64 pause_at = rec->pause_at;
+            bool paused = false;
+            for (;;) {
+                if (phase == PH_FRAME) {
+                    if ((u64)rfl(s.st[10]) >= pause_at && rfl(s.st[ST_STARTED]) != 0u && rfl(s.st[ST_ISLAST]) == 0u) { paused = true; break; }
+                    st = seg_frame();
+                    if (st != SEG_NEED_HEADER) break;
+                    st = cold_header();
+                    if (st) break;
+                    st = generic_commands(HC_START);
+                    phase = PH_LOOP;
+                }
+                while (st == HC_CONTINUE) {
+                    if ((u64)rfl(s.st[10]) >= pause_at) { paused = true; break; }
+                    if (rfl(s.mbw[MBW_ASM]) != 0u) {
+                        const u32 r = asm_commands();
+                        st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
+                    } else {
+                        st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
+                    }
+                }
+                if (paused || st) break;
+                phase = PH_FRAME;
+            }
+            seg_finish(); // everything produced so far is in HBM
+            if (paused) {
+                const u32 *src = (const u32 *)&s;
+                for (u32 w = lane; w < BRX_LDS_BYTES / 4u; w += 64u) rec->lds[w] = src[w];
+                if (lane == 0u) { rec->state = 1u; rec->phase = phase; }
+                st = BRX_PAUSED;
+            } else {
+                const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
+                if (slab != nullptr) scratch_release(a.pool, slab);
+                if (lane == 0u) rec->state = 2u;
+            }
+            if (lane == 0u) {
+                a.status[sid] = (int)st;
+                a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)rfl(s.st[22]) : (u64)rfl(s.st[10]);
+            }
+            continue;
         }
         const u32 prof_on = a.debug != nullptr ? 1u : 0u;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;

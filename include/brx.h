@@ -147,6 +147,14 @@ void brx_host_free(void *p);
  * e.g. a stream that expands past the 4 GiB - 256 B per-stream limit; brx_last_error() has the text. */
 typedef struct brx_stream brx_stream;
 brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
+/* The same object in BOUNDED mode (brx_stream_new picks it by itself for compressed inputs of 4 MiB and more): the stream
+ * is decoded slice by slice -- about 4 MiB of output per brx_stream_read that runs dry -- by a resumable kernel into a
+ * sliding window on the device, so the output resident at any time is bounded by the largest Brotli window (16 MiB) plus
+ * one slice plus slack (~21 MiB) however large the stream (like the reference's Decompressor, whose state is its window,
+ * src/lib.rs:377-394, 1560-1567).  Reads see decoded bytes as the slices complete; an invalid stream serves everything
+ * decoded before the error.  A stream with a single command larger than the slack (a > 1 MiB copy or uncompressed
+ * meta-block) falls back to whole-stream decoding. */
+brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);
 void brx_stream_free(brx_stream *s);
 

@@ -10,16 +10,29 @@ LUT = open(os.path.join(ROOT, "brotli-rs_amd", "tables", "context_lut.bin"), "rb
 
 
 class Bits:
+    """LSB-first bit writer (whole bytes go to a bytearray as they fill: linear time for multi-megabyte streams)."""
+
     def __init__(self):
-        self.v, self.n = 0, 0
+        self.buf, self.acc, self.nacc, self.n = bytearray(), 0, 0, 0
 
     def put(self, value, nbits):
         assert 0 <= value < (1 << nbits) or nbits == 0
-        self.v |= value << self.n
+        self.acc |= value << self.nacc
+        self.nacc += nbits
         self.n += nbits
+        if self.nacc >= 8:
+            k = self.nacc >> 3
+            self.buf += (self.acc & ((1 << (8 * k)) - 1)).to_bytes(k, "little")
+            self.acc >>= 8 * k
+            self.nacc -= 8 * k
+
+    def put_bytes(self, data):
+        assert self.nacc == 0
+        self.buf += data
+        self.n += 8 * len(data)
 
     def bytes(self):
-        return self.v.to_bytes((self.n + 7) // 8, "little")
+        return bytes(self.buf) + (self.acc.to_bytes(1, "little") if self.nacc else b"")
 
 
 def context_id(mode, p1, p2):
@@ -305,8 +318,7 @@ def raw_block(b, data):
     b.put(len(data) - 1, 16)
     b.put(1, 1)  # ISUNCOMPRESSED
     b.put(0, (-b.n) % 8)
-    for x in data:
-        b.put(x, 8)
+    b.put_bytes(data)
 
 
 def stream_header(b, wbits=16):
@@ -520,4 +532,28 @@ def farcopy_stream(seed, first=1 << 16, total=1 << 20, wbits=21):
         cmds.append((b"", n, n))
         out += out[:n]
     MetaBlock(cmds, mlen=len(out) - first).emit(b, True, 0)
+    return b.bytes(), bytes(out)
+
+
+def long_stream(seed, rounds, first=1 << 16, total=1 << 20, wbits=22):
+    """`rounds` x (an uncompressed meta-block of `first` fresh random bytes + a compressed meta-block of non-overlapping
+    copies doubling those to `total` bytes): rounds * total bytes of output from rounds * first bytes of input, every
+    back-reference within `total` bytes -- the stream of the bounded-memory Read test.  Returns (stream, expected)."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    out = bytearray()
+    for r in range(rounds):
+        data = rng.randbytes(first)
+        raw_block(b, data)
+        out += data
+        n, cmds = first, []
+        while n < total:
+            cmds.append((b"", n, n))
+            n *= 2
+        MetaBlock(cmds, mlen=total - first).emit(b, r == rounds - 1, 0)
+        base = len(out) - first
+        while len(out) - base < total:
+            k = len(out) - base
+            out += out[base:base + k]
     return b.bytes(), bytes(out)

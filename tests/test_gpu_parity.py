@@ -488,3 +488,63 @@ def test_host_pipeline_with_pinned_buffers(ctx):
     finally:
         brx.host_free(pin_in)
         brx.host_free(pin_out)
+
+
+def test_bounded_memory_stream_of_70_MiB(ctx):
+    """The Read facade in bounded mode: a 70 MiB stream (4.4 MiB compressed: chosen automatically,
+    inputs >= 4 MiB) decoded slice by slice by the resumable kernel into a ~21 MiB sliding device window; the reader sees
+    the bytes as the slices complete.  Device memory in use must stay under 32 MiB above the baseline.  Also a small
+    stream forced into bounded mode, and a corrupted long stream: everything decoded before the error is served, then
+    the oracle's error."""
+    import craft
+    import torch
+    from brotli_rs_amd import brx
+    L = brx.load_library()
+    comp, exp = craft.long_stream(7, 70)
+    assert len(exp) == 70 << 20 and len(comp) >= 4 << 20
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    h = L.brx_stream_new(ctx._h, comp, len(comp))
+    buf = (ctypes.c_ubyte * (1 << 20))()
+    got_hash, want_hash, total, min_free = hashlib.sha256(), hashlib.sha256(exp).hexdigest(), 0, free0
+    while True:
+        n = L.brx_stream_read(h, buf, len(buf))
+        assert n >= 0, (n, total)
+        if n == 0:
+            break
+        got_hash.update(bytes(memoryview(buf)[:n]))
+        total += n
+        min_free = min(min_free, torch.cuda.mem_get_info()[0])
+    assert total == len(exp) and got_hash.hexdigest() == want_hash
+    assert L.brx_stream_read(h, buf, len(buf)) == 0
+    L.brx_stream_free(h)
+    assert free0 - min_free < (32 << 20), (free0 - min_free) >> 20
+    # small stream, bounded on request; odd read sizes
+    comp2, exp2 = _read("alice29.txt.compressed"), _read("alice29.txt")
+    h = L.brx_stream_new_bounded(ctx._h, comp2, len(comp2))
+    got = bytearray()
+    while True:
+        n = L.brx_stream_read(h, buf, 4099)
+        assert n >= 0
+        if n == 0:
+            break
+        got += bytes(memoryview(buf)[:n])
+    L.brx_stream_free(h)
+    assert bytes(got) == exp2
+    # corrupted in the middle: prefix, then the error
+    bad = bytearray(comp)
+    bad[len(bad) // 2 + 1000] ^= 0x55
+    bad = bytes(bad[:len(bad) // 2 + 300000])
+    want = oracle.decode(bad, 0, cap=len(exp) + 64)
+    assert want[0] != 0
+    h = L.brx_stream_new(ctx._h, bad, len(bad))
+    got = bytearray()
+    while True:
+        n = L.brx_stream_read(h, buf, len(buf))
+        if n <= 0:
+            break
+        got += bytes(memoryview(buf)[:n])
+    L.brx_stream_free(h)
+    assert n == -want[0], (n, want[0])
+    m = min(len(got), len(want[1]))  # (how many bytes precede an error is not a stable observable, SURVEY Q13)
+    assert m > (20 << 20) and bytes(got[:m]) == want[1][:m]

@@ -13,7 +13,7 @@ typedef unsigned int u32;
         u32 v0 = threadIdx.x, v1 = 1, v2 = 2, v3 = 3, s0 = 1, s1 = 2, s2 = 3, s3 = 4;                              \
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)\n .rept 256\n" BODY "\n .endr\n s_memtime %1\n s_waitcnt lgkmcnt(0)" \
                      : "=s"(t0), "=s"(t1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) \
-                     : "s"(buf) : "vcc", "scc", "memory", "s90", "s91", "s92", "s93");                             \
+                     : "s"(buf) : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "v10", "v11");                             \
         if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = v0 + v1 + v2 + v3 + s0 + s1 + s2 + s3; }                \
     }
 TIMED(k_vdep, "v_add_u32 %2, 1, %2")
@@ -34,6 +34,12 @@ TIMED(k_lds2, "ds_read_b32 %2, %2\n v_add_u32 %3, 1, %3\n v_add_u32 %4, 1, %4\n 
 TIMED(k_smem, "s_load_dword s90, %10, 0\n s_waitcnt lgkmcnt(0)\n s_add_u32 %6, %6, s90")
 TIMED(k_ff1, "v_cmp_lt_u32 vcc, %3, %2\n s_ff1_i32_b32 s90, vcc_lo\n v_readlane_b32 s91, %2, s90\n s_sub_u32 s92, 32, s90\n v_lshrrev_b32 %3, s92, %3\n v_add_u32 %3, s91, %3")
 TIMED(k_call, "s_getpc_b64 s[90:91]\n s_add_u32 s90, s90, 12\n s_addc_u32 s91, s91, 0\n s_setpc_b64 s[90:91]")
+TIMED(k_gpridx, "s_set_gpr_idx_on %6, 1\n v_mov_b32 %2, %3\n v_mov_b32 %4, %5\n s_set_gpr_idx_off")
+TIMED(k_gpridx1, "s_set_gpr_idx_on %6, 1\n v_mov_b32 %2, %3\n s_set_gpr_idx_off\n v_add_u32 %4, 1, %4")
+TIMED(k_bfm_exec, "s_bfm_b64 exec, 5, 3\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, -1")
+TIMED(k_readlane2, "v_readlane_b32 s90, %2, 3\n v_add_u32 %3, s90, %3")
+TIMED(k_lshl_b64, "v_lshrrev_b64 v[10:11], %6, v[10:11]")
+TIMED(k_ffbl, "v_cmp_lt_u32 vcc, %3, %2\n s_ff1_i32_b32 s90, vcc_lo\n s_add_u32 %6, %6, s90")
 int main() {
     u64 *o; u32 *b;
     hipMalloc(&o, 64); hipMalloc(&b, 4096); hipMemset(b, 0, 4096);
@@ -57,5 +63,11 @@ int main() {
     RUN(k_smem, 3, "s_load_dword -> waitcnt -> s_add chain");
     RUN(k_ff1, 6, "lookup core: v_cmp, s_ff1, v_readlane, s_sub, v_lshrrev, v_add");
     RUN(k_call, 4, "s_getpc + s_add + s_addc + s_setpc (jump to next)");
+    RUN(k_gpridx, 4, "s_set_gpr_idx_on + 2 v_mov + off");
+    RUN(k_gpridx1, 4, "s_set_gpr_idx_on + v_mov + off + v_add");
+    RUN(k_bfm_exec, 3, "s_bfm_b64 exec + v_add + s_mov exec,-1");
+    RUN(k_readlane2, 2, "v_readlane -> v_add (SGPR operand)");
+    RUN(k_lshl_b64, 1, "v_lshrrev_b64 dependent");
+    RUN(k_ffbl, 3, "v_cmp -> s_ff1 -> s_add");
     return 0;
 }
