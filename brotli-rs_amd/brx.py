@@ -15,6 +15,7 @@ from .build import LIB_PATH, build_library
 MEM_HOST = 0
 MEM_DEVICE = 1
 OPT_TIMING = 2
+OPT_ORDER = 4
 
 OK = 0
 OUTPUT_TOO_SMALL = 25
@@ -152,8 +153,8 @@ class Context:
 
     # ---- device-memory batch (pointers are raw device addresses, e.g. torch tensor .data_ptr()) ------
     def decode_batch_device(self, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
-                            hip_stream=None, timing=False):
-        opts = _Opts(MEM_DEVICE | (OPT_TIMING if timing else 0), 0, hip_stream)
+                            hip_stream=None, timing=False, order=False):
+        opts = _Opts(MEM_DEVICE | (OPT_TIMING if timing else 0) | (OPT_ORDER if order else 0), 0, hip_stream)
         rc = self._lib.brx_decode_batch(self._h, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr,
                                         status_ptr, ctypes.byref(opts))
         if rc != 0:

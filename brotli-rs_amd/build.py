@@ -43,6 +43,8 @@ def _build_locked(verbose):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bin2h.py"), gen, "BRX", "static const"])
     # the hand-written command loop: cpp resolves the register names, the text becomes one asm statement
     prof = ["-DBRX_PROF"] if os.environ.get("BRX_PROF") == "1" else []  # bring-up: timers inside the loop
+    if os.environ.get("BRX_NO_SPEC") == "1":
+        prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
     hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + [os.path.join(CSRC, "brx_hot.S")]).decode()
     assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
     with open(os.path.join(CSRC, "_gen", "brx_hot_asm.h"), "w") as f:

@@ -492,8 +492,22 @@ static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in
     c->have_timing = false;
     if (flags & BRX_MEM_DEVICE) {
         hipStream_t st = (opts && opts->hip_stream) ? (hipStream_t)opts->hip_stream : c->stream;
+        const uint32_t *d_order = nullptr;
+        if (flags & BRX_OPT_ORDER) { // longest compressed stream first, from a copy of the device table
+            std::vector<uint64_t> h((size_t)n + 1);
+            HIP_TRY(hipMemcpyAsync(h.data(), in_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<uint32_t> order(n);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x + 1] - h[x] > h[y + 1] - h[y]; });
+            int rc0 = grow((uint8_t **)&c->st_meta, &c->st_meta_cap, (size_t)n * 4);
+            if (rc0) return rc0;
+            HIP_TRY(hipMemcpyAsync(c->st_meta, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st)); // (`order` is a local)
+            d_order = (const uint32_t *)c->st_meta;
+        }
         if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status);
+        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order);
         if (rc) return rc;
         if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));

@@ -253,6 +253,24 @@
 // would give (per-lane shift VSH = 32 - L) and fetches that entry speculatively; the code length (s_ff1 of the compare)
 // then only selects the lane (v_readlane \rd-result, CLEN) after the LDS round trip.  Candidates of the wrong lengths
 // read harmless addresses (out-of-range LDS reads return 0).  Consumes the code's bits.  Out: CLEN, VS (lane CLEN = the entry).
+#ifdef BRX_NO_SPEC
+// (A/B switch, BRX_NO_SPEC=1 at build time: the same lookup with the fetch BEHIND the length -- ballot, s_ff1, base of that
+// length, then one fetch of the one entry; every lane ends up with the same entry.  profiles/r02_spec_ab.txt)
+.macro LOOKUP2 lim, base, symbase, scale, rd, off
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    v_cmp_lt_u32 vcc, VU, \lim
+    s_ff1_i32_b32 CLEN, vcc_lo
+    v_readlane_b32 T3, \base, CLEN
+    s_sub_u32 T2, 32, CLEN
+    s_min_u32 T2, T2, 31                                // ("length 0" of a resident one-symbol tree: index 0 or 1)
+    v_lshrrev_b32 VI, T2, VR
+    v_add_u32 VI, T3, VI
+    v_lshl_add_u32 VI, VI, \scale, \symbase
+    \rd VS, VI offset:\off
+    TAKE CLEN
+.endm
+#else
 .macro LOOKUP2 lim, base, symbase, scale, rd, off
     v_bfrev_b32 VR, VWINLO
     v_lshrrev_b32 VU, 1, VR
@@ -264,6 +282,7 @@
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
     TAKE CLEN
 .endm
+#endif
 
 // ======================================================================================================== entry
     s_waitcnt vmcnt(0) lgkmcnt(0)

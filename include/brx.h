@@ -72,6 +72,10 @@ enum {
 #define BRX_MEM_HOST 0u   /* every pointer argument is host memory; the library stages through HBM */
 #define BRX_MEM_DEVICE 1u /* every pointer argument (data, offset tables, out_len, status) is device memory */
 #define BRX_OPT_TIMING 2u /* record HIP-event timings of the kernels of this call (brx_last_timing) */
+#define BRX_OPT_ORDER 4u  /* BRX_MEM_DEVICE only: queue the longest compressed streams first (a ragged batch finishes when
+                             its longest stream does).  Costs one synchronous read of the offset table; the host-pointer
+                             path always orders.  The work queue itself is dynamic: a wave that finishes a stream takes the
+                             next one, so short streams never wait behind a fixed assignment. */
 
 typedef struct brx_opts {
     uint32_t flags;   /* BRX_MEM_* | BRX_OPT_* */

@@ -548,3 +548,40 @@ def test_bounded_memory_stream_of_70_MiB(ctx):
     assert n == -want[0], (n, want[0])
     m = min(len(got), len(want[1]))  # (how many bytes precede an error is not a stable observable)
     assert m > (20 << 20) and bytes(got[:m]) == want[1][:m]
+
+
+def test_device_path_longest_first_order(ctx):
+    """BRX_OPT_ORDER on the device-pointer path: a ragged batch (many tiny streams, a few 1 MiB ones LAST) queued longest
+    first; same results, and not slower than the caller's order."""
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    d = os.path.join(GOLDEN, "config5")
+    man = json.load(open(os.path.join(d, "manifest.json")))["streams"]
+    big = [open(os.path.join(d, e["name"] + ".compressed"), "rb").read() for e in man]
+    small, exp_small = _read("monkey.compressed"), _read("monkey")
+    streams = [small] * 4096 + [big[i % len(big)] for i in range(32)]
+    caps = [1024] * 4096 + [1 << 20] * 32
+    n = len(streams)
+    in_off = torch.tensor(np.concatenate([[0], np.cumsum([len(s) for s in streams])]), dtype=torch.int64, device=dev)
+    out_off = torch.tensor(np.concatenate([[0], np.cumsum(caps)]), dtype=torch.int64, device=dev)
+    blob = torch.frombuffer(bytearray(b"".join(streams)), dtype=torch.uint8).to(dev)
+    out = torch.zeros(int(out_off[-1].item()), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    times = {}
+    for order in (False, True, False, True):
+        out.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
+                                out_len.data_ptr(), status.data_ptr(), order=order)
+        ctx.synchronize()
+        times[order] = time.perf_counter() - t0
+        assert status.cpu().tolist() == [0] * n
+        host = out.cpu().numpy()
+        assert host[:len(exp_small)].tobytes() == exp_small
+        for i in range(32):
+            o0 = int(out_off[4096 + i].item())
+            assert hashlib.sha256(host[o0:o0 + (1 << 20)].tobytes()).hexdigest() == man[i % len(man)]["sha256"]
+    assert times[True] < times[False] * 1.25, times

@@ -1,0 +1,80 @@
+#!/bin/bash
+# The round's committed evidence (copied from gpurun_out/ into profiles/ afterwards): benches of every workload, rocprofv3
+# kernel stats, SQ counters, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes), occupancy sweep, PCIe-inclusive
+# host path, and the A/B of the lane-speculative symbol fetch.  TAG names the files.
+set -u
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+R=$GRAFT_REPO_ROOT; TAG=${TAG:-r02}
+O=$R/gpurun_out; mkdir -p $O
+cd $R
+WLS="alice29x4096 config5_1MiBx1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192 compressed_repeatedx4096"
+for wl in $WLS; do
+  timeout 600 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${TAG}_${wl}.json
+done
+echo "== sweep"; NS="1 256 1024 2048 4096 4352 8192 16384" bash tools/gpu_sweep.sh 2>/dev/null | tee $O/${TAG}_sweep.txt
+echo "== host path, pinned buffers (PCIe-inclusive)"
+timeout 300 python - <<'PY' 2>/dev/null | tee $O/${TAG}_pcie.txt
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+from brotli_rs_amd import brx
+comp = open('tests/golden/data/alice29.txt.compressed','rb').read(); exp = open('tests/golden/data/alice29.txt','rb').read()
+n = 4096; cap = (len(exp) + 15) & ~15
+ctx = brx.Context(0)
+for kind in ('pinned', 'pageable'):
+    if kind == 'pinned':
+        a, b = brx.host_alloc(len(comp) * n), brx.host_alloc(cap * n)
+    else:
+        a, b = np.zeros(len(comp) * n, dtype=np.uint8), np.zeros(cap * n, dtype=np.uint8)
+    a[:] = np.frombuffer(comp * n, dtype=np.uint8)
+    io = np.arange(n + 1, dtype=np.uint64) * len(comp); oo = np.arange(n + 1, dtype=np.uint64) * cap
+    best = 1e9
+    for r in range(5):
+        t0 = time.perf_counter(); st, ln = ctx.decode_batch_host_raw(a.ctypes.data, io, n, b.ctypes.data, oo); best = min(best, time.perf_counter() - t0)
+    assert not st.any() and b[:len(exp)].tobytes() == exp
+    print("%s host buffers: 4096 x alice29, H2D + decode + D2H: %.2f ms wall, %.1f GB/s decompressed (PCIe-inclusive)" % (kind, best * 1e3, n * len(exp) / best / 1e9))
+PY
+cd /tmp && export TMPDIR=/tmp
+for wl in $WLS; do
+  rm -rf /tmp/kt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o t -- python $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --verify 0 > /tmp/kt.log 2>/dev/null
+  tail -1 /tmp/kt.log > $O/bench_${TAG}_${wl}_under_rocprof.json
+  f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv
+done
+for wl in alice29x4096 config5_1MiBx1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --verify 0 > /dev/null 2>&1
+  done
+  python3 - $wl $TAG <<'PY'
+import csv,sys,glob,json,os
+wl,tag=sys.argv[1:3]; out={"workload":wl}
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    vals=[]
+    for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv"%c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'brx_decode' in r['Kernel_Name'] and r['Counter_Name']==c: vals.append(float(r['Counter_Value']))
+    out[c+"_per_dispatch_raw"]=vals
+json.dump(out, open(os.environ['GRAFT_REPO_ROOT']+"/gpurun_out/traffic_%s_%s.json"%(tag,wl),"w"))
+print(wl, {k:(sum(v)/max(1,len(v)) if isinstance(v,list) else v) for k,v in out.items()})
+PY
+done
+echo "== SQ counters, alice29 x 4096"
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS"; do
+  rm -rf /tmp/pmc_out
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_out -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify 0 > /dev/null 2>&1
+  python3 - <<'PY' | tee -a $O/${TAG}_pmc.txt
+import csv,glob,collections
+agg=collections.defaultdict(float); n=collections.defaultdict(int)
+for f in glob.glob("/tmp/pmc_out/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'brx' in r['Kernel_Name']:
+            agg[r['Counter_Name']]+=float(r['Counter_Value']); n[r['Counter_Name']]+=1
+for k in sorted(agg): print("%-24s %18.0f per dispatch"%(k,agg[k]/n[k]))
+PY
+done
+cd $R
+echo "== A/B: lane-speculative symbol fetch (LOOKUP2) vs serial fetch"
+BRX_NO_SPEC=1 python brotli-rs_amd/build.py --force > /dev/null 2>&1
+( echo "serial fetch (BRX_NO_SPEC=1): streams, MB/s, kernel ms"; NS="1 4096" bash tools/gpu_sweep.sh 2>/dev/null; WL=config5_1MiBx1024 NS="1024" bash tools/gpu_sweep.sh 2>/dev/null ) | tee $O/${TAG}_spec_ab.txt
+python brotli-rs_amd/build.py --force > /dev/null 2>&1
+( echo "lane-speculative fetch (product): streams, MB/s, kernel ms"; NS="1 4096" bash tools/gpu_sweep.sh 2>/dev/null; WL=config5_1MiBx1024 NS="1024" bash tools/gpu_sweep.sh 2>/dev/null ) | tee -a $O/${TAG}_spec_ab.txt
