@@ -69,7 +69,7 @@ struct brx_ctx {
     int device = 0;
     std::mutex mu;
     hipStream_t stream = nullptr;                 // decode stream of the host-pointer path / default device-path stream
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr; // copy streams of the chunked host pipeline
+    hipStream_t s_chunk[8] = {};                  // host-pointer pipeline: one stream per chunk (copy in, decode, copy out)
     uint8_t *d_dict = nullptr;
     uint8_t *d_lut = nullptr;
     BrxTransform *d_xforms = nullptr;
@@ -139,8 +139,8 @@ static void ctx_release(brx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->s_h2d) (void)hipStreamSynchronize(c->s_h2d);
-    if (c->s_d2h) (void)hipStreamSynchronize(c->s_d2h);
+    for (auto &q : c->s_chunk)
+        if (q) (void)hipStreamSynchronize(q);
     if (c->ev_last && c->any_launch) (void)hipEventSynchronize(c->ev_last);
     (void)hipFree(c->d_dict);
     (void)hipFree(c->d_lut);
@@ -161,8 +161,8 @@ static void ctx_release(brx_ctx *c) {
         if (ev) (void)hipEventDestroy(ev);
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
-    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    for (auto &q : c->s_chunk)
+        if (q) (void)hipStreamDestroy(q);
     delete c;
 }
 
@@ -189,8 +189,7 @@ static int ctx_init(brx_ctx *c, int device) {
         }
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    for (auto &q : c->s_chunk) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
@@ -313,8 +312,7 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
     while (want < grid) want <<= 1;
     if (want > c->max_grid) want = ((c->max_grid + 31u) / 32u) * 32u;
     if (c->pool.slabs && c->pool.count >= want) return BRX_SUCCESS;
-    if (c->any_launch) HIP_TRY(hipEventSynchronize(c->ev_last)); // nobody holds a slab of the old pool any more
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize()); // (rare) nobody may hold a slab of the old pool: launches on any stream included
     (void)hipFree(c->pool.bitmap);
     (void)hipFree(c->pool.slabs);
     c->pool.bitmap = nullptr;
@@ -404,10 +402,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
 }
 
 // ---- host pointers: H2D, decode, D2H ----------------------------------------------------------------------
-// The batch is cut into up to BRX_MAX_CHUNKS runs of consecutive streams; chunk k's input copy, decode kernel and
-// output copy run on three HIP streams chained by events, so the copies of one chunk overlap the kernel of
-// another.  With pinned caller memory (BRX_MEM_HOST_PINNED: brx_host_alloc / hipHostMalloc / hipHostRegister) the
-// copies are true asynchronous DMA; with pageable memory the HIP runtime stages them and the overlap is partial.
+// The batch is cut into up to BRX_MAX_CHUNKS runs of consecutive streams, each with its own HIP stream: input copy,
+// decode kernel, output copy.  The chunks' kernels run CONCURRENTLY on the GPU (every launch has its own work counter and
+// the spill slabs are claimed per wave), so the copies of one chunk overlap the decoding of the others.  With pinned caller memory (brx_host_alloc / hipHostMalloc / hipHostRegister) the copies are true asynchronous
+// DMA; with pageable memory the HIP runtime stages them and the overlap is partial.
 static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
                        const uint64_t *out_off, uint64_t *out_len, int32_t *status, bool timing) {
     for (uint32_t i = 0; i < n; i++)
@@ -431,10 +429,11 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
     int32_t *d_status = (int32_t *)(c->st_meta + meta_words);
     uint32_t *d_order = (uint32_t *)(d_status + n);
 
-    // chunk boundaries: equal shares of (input + output) bytes, at least 16 MiB per chunk
+    // chunk boundaries: equal shares of (input + output) bytes, and at least one full grid of streams per chunk -- a
+    // stream is ~9 ms of pure latency however few run, so a batch that fits the GPU at once is fastest as ONE launch
+    // (measured: 4096 x alice29, 33 ms as one chunk, 40 ms as eight); chunks pay off from the second grid-full on
     const uint64_t total = (uint64_t)in_bytes + out_bytes;
-    unsigned nchunks = (unsigned)std::min<uint64_t>(BRX_MAX_CHUNKS, std::max<uint64_t>(1, total >> 24));
-    if (n < 2 * nchunks) nchunks = 1;
+    unsigned nchunks = (unsigned)std::min<uint64_t>(BRX_MAX_CHUNKS, std::max<uint64_t>(1, n / c->max_grid));
     std::vector<uint32_t> cut(nchunks + 1, 0);
     {
         uint32_t i = 0;
@@ -456,30 +455,34 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
                 return in_off[gx + 1] - in_off[gx] > in_off[gy + 1] - in_off[gy];
             });
     }
-    hipStream_t sk = c->stream;
-    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->s_h2d));
-    HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, c->s_h2d));
-    if (timing) HIP_TRY(hipEventRecord(c->ev[0], sk));
-    for (unsigned k = 0; k < nchunks; k++) {
+    if ((rc = ensure_pool(c, n < c->max_grid ? n : c->max_grid))) return rc; // once, for all the chunks' launches together
+    hipStream_t s0 = c->s_chunk[0];
+    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
+    HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, s0));
+    HIP_TRY(hipEventRecord(c->ev_in[0], s0)); // the tables are on the device
+    if (timing) HIP_TRY(hipEventRecord(c->ev[0], s0));
+    for (unsigned k = 0; k < nchunks; k++) { // copy in + decode, every chunk on its own stream
         const uint32_t a = cut[k], b = cut[k + 1];
         if (a == b) continue;
+        hipStream_t sk = c->s_chunk[k];
+        if (k) HIP_TRY(hipStreamWaitEvent(sk, c->ev_in[0], 0));
         const uint64_t i0 = in_off[a] - in_lo, i1 = in_off[b] - in_lo;
-        if (i1 > i0) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, c->s_h2d));
-        HIP_TRY(hipEventRecord(c->ev_in[k], c->s_h2d));
-        HIP_TRY(hipStreamWaitEvent(sk, c->ev_in[k], 0));
-        rc = launch(c, sk, timing && k == 0 && nchunks == 1, c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a,
-                    d_out_len + a, d_status + a, d_order + a);
+        if (i1 > i0) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, sk));
+        rc = launch(c, sk, timing && nchunks == 1, c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a, d_out_len + a,
+                    d_status + a, d_order + a);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(c->ev_k[k], sk));
-        HIP_TRY(hipStreamWaitEvent(c->s_d2h, c->ev_k[k], 0));
-        const uint64_t o0 = out_off[a] - out_lo, o1 = out_off[b] - out_lo;
-        if (o1 > o0) HIP_TRY(hipMemcpyAsync(out + out_lo + o0, c->st_out + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost, c->s_d2h));
     }
-    if (timing) HIP_TRY(hipEventRecord(c->ev[1], sk));
-    HIP_TRY(hipStreamSynchronize(sk));
-    HIP_TRY(hipMemcpyAsync(out_len, d_out_len, (size_t)n * 8, hipMemcpyDeviceToHost, c->s_d2h));
-    HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)n * 4, hipMemcpyDeviceToHost, c->s_d2h));
-    HIP_TRY(hipStreamSynchronize(c->s_d2h));
+    for (unsigned k = 0; k < nchunks; k++) { // copy out (a second loop: a pageable copy blocks the host until it is done)
+        const uint32_t a = cut[k], b = cut[k + 1];
+        if (a == b) continue;
+        hipStream_t sk = c->s_chunk[k];
+        const uint64_t o0 = out_off[a] - out_lo, o1 = out_off[b] - out_lo;
+        if (o1 > o0) HIP_TRY(hipMemcpyAsync(out + out_lo + o0, c->st_out + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost, sk));
+        HIP_TRY(hipMemcpyAsync(out_len + a, d_out_len + a, (size_t)(b - a) * 8, hipMemcpyDeviceToHost, sk));
+        HIP_TRY(hipMemcpyAsync(status + a, d_status + a, (size_t)(b - a) * 4, hipMemcpyDeviceToHost, sk));
+    }
+    if (timing) HIP_TRY(hipEventRecord(c->ev[1], s0));
+    for (unsigned k = 0; k < nchunks; k++) HIP_TRY(hipStreamSynchronize(c->s_chunk[k]));
     c->have_timing = timing && nchunks == 1;
     return BRX_SUCCESS;
 }
