@@ -46,6 +46,10 @@
 #define LDS_SPARE 9216  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
 #define LDS_CMH 9472    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
 #define SYMOFF 128      // symbol list of a tree: after its 32 header words
+// EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup + lane 16, which carries the symbol-list
+// address of a resident tree).  Everything uniform needs one lane; copies, flushes and input staging set their own mask.
+// Fewer switching lanes = less power = a higher clock on the loaded chip (DVFS, MI355X_MICROARCH.md).
+#define XLOOP 0x1ffff
 
 // ---- SGPRs (s36-s38: scratch during entry)
 #define NPOST s4
@@ -605,6 +609,7 @@
     s_and_b32 T0, VFL, 1023
     s_cmp_lg_u32 T0, 0
     s_cbranch_scc1 .Lexit
+    s_mov_b64 exec, XLOOP
     s_branch .Lr1
 
 // ======================================================================================================== R0
@@ -676,10 +681,10 @@
     s_cmp_gt_u32 DIST, RING
     s_cbranch_scc0 .Lcopy_near
     // older than the ring: final in HBM (never pending bytes: what is pending is younger than one flush block)
-    v_add_u32 VT0, T2, VLANE
     s_bfm_b64 exec, CPY, PFREE
+    v_add_u32 VT0, T2, VLANE
     buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, XLOOP
 .Lcopy_issued:
     s_add_u32 PFREE, PFREE, CPY
     s_add_u32 POS, POS, CPY
@@ -701,11 +706,11 @@
     s_sub_u32 T2, PBASE, DIST
 .Lcopy_near_go:
     s_add_u32 T2, T2, SKEW
+    s_bfm_b64 exec, CPY, PFREE
     v_add_u32 VT0, T2, VLANE
     v_and_b32 VT0, RMASK, VT0
-    s_bfm_b64 exec, CPY, PFREE
     ds_read_u8 VPEND, VT0
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, XLOOP
     s_branch .Lcopy_issued
 
 .Ldist_special:
@@ -936,10 +941,10 @@
     s_call_b64 LINKB, .Lland
 .Ldict_go:
     s_sub_u32 T2, T0, PFREE
-    v_add_u32 VT0, T2, VLANE
     s_bfm_b64 exec, CPY, PFREE
+    v_add_u32 VT0, T2, VLANE
     global_load_ubyte VPEND, VT0, DICTP
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, XLOOP
     s_branch .Lcopy_issued
 
 // ======================================================================================================== helpers
@@ -949,17 +954,18 @@
 // VB4 = p1's share as a future p2) and requests the tree descriptor of the first literal.
 .macro LAND_BODY
     s_add_u32 T6, PBASE, SKEW
+    s_bfm_b64 exec, PFREE, 0
     v_add_u32 VT1, T6, VLANE
     v_and_b32 VT1, RMASK, VT1
     PROF_WAIT_VM
     s_waitcnt vmcnt(0) lgkmcnt(0)
-    s_bfm_b64 exec, PFREE, 0
     ds_write_b8 VT1, VPEND
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, XLOOP
     s_mov_b32 PFREE, 0
     s_mov_b32 PBASE, POS
 .endm
 .macro FLUSH_BODY lbl
+    s_mov_b64 exec, -1
 \lbl:
     s_and_b32 T6, VFL, RMASK
     v_add_u32 VT4, T6, VLANE16
@@ -972,6 +978,7 @@
     s_add_u32 FLUSHAT, FLUSHAT, 1024
     s_cmp_ge_u32 POS, FLUSHAT
     s_cbranch_scc1 \lbl
+    s_mov_b64 exec, XLOOP
 .endm
 .Lland:
     s_cmp_eq_u32 PFREE, 0
@@ -1045,6 +1052,7 @@
     s_cmp_lg_u32 WL, 64
     s_cbranch_scc1 .Lnear_end
     s_waitcnt vmcnt(0)
+    s_mov_b64 exec, -1
     v_mov_b32 VCHA, VCHB
     s_add_u32 CBASE, CBASE, 64
     s_add_u32 T0, CBASE, 64
@@ -1052,6 +1060,7 @@
     v_min_u32 VT4, WENDM1, VT4
     v_lshlrev_b32 VT4, 2, VT4
     global_load_dword VCHB, VT4, INP
+    s_mov_b64 exec, XLOOP
     s_mov_b32 WL, 0
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
@@ -1101,6 +1110,7 @@
     s_cmp_gt_u32 CPY, T0
     s_cbranch_scc1 .Lcopy_long
     s_call_b64 LINKB, .Lland
+    s_mov_b64 exec, -1
     s_sub_u32 T0, CPY, 1
     v_min_u32 VT2, T0, VLANE                            // switched-off lanes redo the last byte
     v_mov_b32 VT0, VT2
@@ -1120,6 +1130,7 @@
     v_and_b32 VT0, RMASK, VT0
     s_waitcnt lgkmcnt(0)
     ds_write_b8 VT0, VT3
+    s_mov_b64 exec, XLOOP
     s_add_u32 POS, POS, CPY
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
@@ -1135,6 +1146,7 @@
     s_call_b64 LINKB, .Lland
     s_mov_b32 T5, CPY                                   // bytes left
 .Lcl_chunk:
+    s_mov_b64 exec, -1
     s_min_u32 T0, T5, 64
     s_sub_u32 T1, T0, 1
     v_min_u32 VT1, T1, VLANE                            // clamped lane
@@ -1155,6 +1167,7 @@
     v_and_b32 VT0, RMASK, VT0
     s_waitcnt vmcnt(0) lgkmcnt(0)
     ds_write_b8 VT0, VT2
+    s_mov_b64 exec, XLOOP
     s_add_u32 POS, POS, T0
     s_sub_u32 T5, T5, T0
     s_mov_b32 PBASE, POS
@@ -1179,6 +1192,7 @@
     s_load_dword s97, XFP, T4                           // plen | slen << 8 | op << 16
     s_call_b64 LINKB, .Lland
     s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, -1
     s_bfe_u32 T1, s97, 0x80010                          // op
     s_and_b32 T2, s97, 0xff                             // prefix length
     s_bfe_u32 T3, s97, 0x80008                          // suffix length
@@ -1272,7 +1286,7 @@
     v_and_b32 VT0, RMASK, VT0
     s_bfm_b64 exec, T3, 0
     ds_write_b8 VT0, v54
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, XLOOP
     s_add_u32 POS, POS, CLEN
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
@@ -1302,6 +1316,7 @@
 .Lx_r2:
     s_mov_b32 EXITC, 2
 .Lexit:
+    s_mov_b64 exec, XLOOP
     s_call_b64 LINKB, .Lland
     s_waitcnt vmcnt(0) lgkmcnt(0)
 #ifdef BRX_PROF
@@ -1370,3 +1385,4 @@
     ds_write_b64 VZERO, v[20:21] offset:LDS_MBW+144     // distance, distance-is-bad
     ds_write_b32 VZERO, v22 offset:LDS_MBW+152          // exit point
     s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, -1                                  // the C++ segments run with all lanes
