@@ -85,6 +85,7 @@
 #define IBLEN s66
 #define DBLEN s67
 #define P1 s68
+#define RUN s58                 // literals left in the current run, one behind
 #define MBEND s69
 #define SNAV s70
 #define DCTX s94
@@ -274,6 +275,36 @@
     \rd VS, VI offset:\off
     TAKE CLEN
 .endm
+.macro LOOKUP2F lim, basep, scale, rd
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    v_cmp_lt_u32 vcc, VU, \lim
+    s_ff1_i32_b32 CLEN, vcc_lo
+    v_readlane_b32 T3, \basep, CLEN
+    s_sub_u32 T2, 32, CLEN
+    s_min_u32 T2, T2, 31
+    v_lshrrev_b32 VI, T2, VR
+    v_lshl_add_u32 VI, VI, \scale, T3
+    \rd VS, VI
+    TAKE CLEN
+.endm
+.macro LOOKUP2X
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    s_set_gpr_idx_on T6, 2
+    v_cmp_lt_u32 vcc, VU, VTREES
+    s_set_gpr_idx_off
+    s_ff1_i32_b32 CLEN, vcc_lo
+    s_set_gpr_idx_on T6, 1
+    v_readlane_b32 T3, VTREES1, CLEN
+    s_set_gpr_idx_off
+    s_sub_u32 T2, 32, CLEN
+    s_min_u32 T2, T2, 31
+    v_lshrrev_b32 VI, T2, VR
+    v_lshl_add_u32 VI, VI, 1, T3
+    ds_read_u16 VS, VI
+    TAKE CLEN
+.endm
 #else
 .macro LOOKUP2 lim, base, symbase, scale, rd, off
     v_bfrev_b32 VR, VWINLO
@@ -283,6 +314,32 @@
     v_add_u32 VI, \base, VI
     v_lshl_add_u32 VI, VI, \scale, \symbase
     \rd VS, VI offset:\off
+    s_ff1_i32_b32 CLEN, vcc_lo                          // code length
+    TAKE CLEN
+.endm
+// The lookup in one of the register-resident literal trees, T6 = 2 * its index: the VGPR index mode (gfx9 has no
+// v_movrel) redirects the second source of the compare (limits) and the third of the shift-add (folded bases).
+.macro LOOKUP2X
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    v_lshrrev_b32 VI, VSH, VR
+    s_set_gpr_idx_on T6, 6                              // SRC1 | SRC2 + T6
+    v_cmp_lt_u32 vcc, VU, VTREES
+    v_lshl_add_u32 VI, VI, 1, VTREES1
+    s_set_gpr_idx_off
+    ds_read_u16 VS, VI
+    s_ff1_i32_b32 CLEN, vcc_lo
+    TAKE CLEN
+.endm
+// The lookup of a tree that lives in registers: \basep = per-lane (base[L] << scale) + LDS address of the symbol list,
+// folded once when the tree is loaded, so the candidate address is one shift and one shift-add.
+.macro LOOKUP2F lim, basep, scale, rd
+    v_bfrev_b32 VR, VWINLO
+    v_lshrrev_b32 VU, 1, VR
+    v_cmp_lt_u32 vcc, VU, \lim
+    v_lshrrev_b32 VI, VSH, VR
+    v_lshl_add_u32 VI, VI, \scale, \basep
+    \rd VS, VI
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
     TAKE CLEN
 .endm
@@ -529,11 +586,10 @@
     ds_read_b64 VLB, VT0
     s_add_u32 T7, T7, SYMOFF
     s_waitcnt lgkmcnt(0)
-    v_writelane_b32 VLIM, T7, 16
+    v_lshl_add_u32 VBASE, VBASE, 1, T7                  // folded bases (LOOKUP2F)
     s_branch .Lent_r_store
 .Lent_r_single:
     v_mov_b32 VLIM, 0
-    v_mov_b32 VBASE, 0
     s_mov_b32 T5, -1
     v_writelane_b32 VLIM, T5, 0
     s_and_b32 T5, T7, 0xffff                            // x = byte | context info << 8
@@ -544,7 +600,7 @@
     v_mov_b32 VT0, T4
     v_mov_b32 VT1, T5
     ds_write_b32 VT0, VT1
-    v_writelane_b32 VLIM, T4, 16
+    v_mov_b32 VBASE, T4
 .Lent_r_store:
     s_lshl_b32 T4, T6, 1
     s_set_gpr_idx_on T4, 8                              // VGPR index mode, destination + T4 (gfx9 has no v_movrel)
@@ -609,6 +665,8 @@
     s_and_b32 T0, VFL, 1023
     s_cmp_lg_u32 T0, 0
     s_cbranch_scc1 .Lexit
+    v_lshl_add_u32 VIACB, VIACB, 1, HISYM               // folded bases of the resident trees (LOOKUP2F)
+    v_lshl_add_u32 VLITB, VLITB, 1, LITSYM
     s_mov_b64 exec, XLOOP
     s_branch .Lr1
 
@@ -617,7 +675,7 @@
     PROF_MARK s31                                       // copy + tail
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
-    LOOKUP2 VIACL, VIACB, HISYM, 1, ds_read_u16, 0
+    LOOKUP2F VIACL, VIACB, 1, ds_read_u16
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte offset of the symbol's record in the insert&copy table
     s_load_dwordx4 s[92:95], IACTAB, T0                 // = INS base, CPY base, DCTX, extra-bit counts
@@ -739,6 +797,72 @@
     REFILL_CHECK 3
     s_branch .Lr1
 
+// ---- literal runs (the register-resident loops)
+// The common run is the whole insert: no block end, no flush block end inside it (a flush that falls due exactly at its
+// end is taken by the next landing or run).  Anything else takes the general setup.
+.macro LIT_RUN_FAST general
+    s_sub_u32 T6, FLUSHAT, POS
+    s_cbranch_scc1 \general
+    s_min_u32 T6, T6, LBLEN
+    s_cmp_gt_u32 INS, T6
+    s_cbranch_scc1 \general
+    s_sub_u32 LBLEN, LBLEN, INS
+    s_add_u32 POS, POS, INS
+    s_sub_u32 RUN, INS, 1
+    s_mov_b32 INS, 0
+.endm
+.macro LIT_RUN_SETUP flush_stub
+    s_cmp_eq_u32 LBLEN, 0
+    s_cbranch_scc1 .Lx_lit_block
+    s_min_u32 RUN, INS, LBLEN
+    s_sub_u32 T6, FLUSHAT, POS                          // (a copy may have ended exactly on the flush block: flush first)
+    s_cbranch_scc1 \flush_stub
+    s_cmp_eq_u32 T6, 0
+    s_cbranch_scc1 \flush_stub
+    s_min_u32 RUN, RUN, T6
+    s_sub_u32 INS, INS, RUN
+    s_sub_u32 LBLEN, LBLEN, RUN
+    s_add_u32 POS, POS, RUN
+    s_sub_u32 RUN, RUN, 1
+.endm
+.macro LIT_RUN_END again, flush_stub
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 \flush_stub
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc1 \again
+    s_branch .Lafter_lits
+.endm
+// out of line: the flush at a run's end; the refill of a run's loop, which gives the untouched rest of the run back
+// (INS, LBLEN, POS) before the input staging rolls -- that may poison the block counts or find the end of the input
+.macro LIT_RUN_STUBS id, again, flush_stub
+\flush_stub:
+    s_call_b64 LINKC, .Lflush
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc1 \again
+    s_branch .Lafter_lits
+.Lrf_stub_\id:
+    v_readlane_b32 T0, VCHA, WL
+    v_mov_b32 VRFHI, 0
+    s_nop 1
+    v_mov_b32 VRFLO, T0
+    v_lshlrev_b64 VRF, SNAV, VRF
+    v_or_b32 VWINLO, VWINLO, VRFLO
+    v_or_b32 VWINHI, VWINHI, VRFHI
+    s_add_u32 SNAV, SNAV, 32
+    s_add_u32 WL, WL, 1
+    s_cmp_lg_u32 WL, WLSTOP
+    s_cbranch_scc1 .Lrf_back_\id
+    s_add_u32 INS, INS, RUN
+    s_add_u32 LBLEN, LBLEN, RUN
+    s_sub_u32 POS, POS, RUN
+    s_call_b64 LINKA, .Lspecial
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 \flush_stub
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc1 \again
+    s_branch .Lafter_lits
+.endm
+
 // ---- literals (reference parse_insert_literals :1286-1365)
 .Lhave_lits:
     s_sub_u32 MBLEFT, MBEND, POS
@@ -749,9 +873,9 @@
     s_call_b64 LINKB, .Lland_ctx                        // pending bytes into the ring, context of the first literal
     s_add_u32 T0, POS, SKEW
     v_mov_b32 VPA, T0                                   // ring address of the next literal (masked when used)
-    s_sub_u32 INS, INS, 1                               // the loop counts down to the borrow
     s_bitcmp1_b32 FLAGS, 5
     s_cbranch_scc1 .Llit_r_start
+    s_sub_u32 INS, INS, 1                               // the loop counts down to the borrow
     s_bitcmp1_b32 FLAGS, 4
     s_cbranch_scc1 .Llit_m
 // \mixed = 0: the entries carry the context info; 1 (meta-blocks whose literal block types differ in context mode): they
@@ -810,17 +934,16 @@
 .Llit_r_start:
     v_readfirstlane_b32 T4, VC                          // context id * 4 of the first literal
     v_readfirstlane_b32 T5, VB4                         // p1's share as a later p2
+// A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
+// LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
+    LIT_RUN_FAST .Llit_r_run
+    s_branch .Llit_r
+.Llit_r_run:
+    LIT_RUN_SETUP .Lflush_stub_lit_r
 .Llit_r:
-    s_sub_u32 LBLEN, LBLEN, 1
-    s_cbranch_scc1 .Lx_lit_switch
     s_lshr_b32 T4, T4, 2
     v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
-    s_set_gpr_idx_on T6, 1                              // VGPR index mode, source 0 + T6
-    v_mov_b32 VLIM, VTREES
-    v_mov_b32 VBASE, VTREES1
-    s_set_gpr_idx_off
-    v_readlane_b32 T7, VLIM, 16                         // LDS address of the tree's symbol list
-    LOOKUP2 VLIM, VBASE, T7, 1, ds_read_u16, 0
+    LOOKUP2X
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
     v_and_b32 VT0, RMASK, VPA
@@ -832,49 +955,51 @@
     s_or_b32 T4, T4, T5                                 // context id * 4 of the next one
     s_and_b32 T5, T1, MB
     s_lshl_b32 T5, T5, SB
-    s_add_u32 POS, POS, 1
-    s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc1 .Lflush_stub_lit_r
-.Lflush_back_lit_r:
-    REFILL_CHECK 9
-    s_sub_u32 INS, INS, 1
+    s_cmp_lt_u32 SNAV, 32
+    s_cbranch_scc1 .Lrf_stub_9
+.Lrf_back_9:
+    s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit_r
-    s_branch .Lafter_lits
-.Lflush_stub_lit_r:
-    s_call_b64 LINKC, .Lflush
-    s_branch .Lflush_back_lit_r
+    s_cmp_lg_u32 INS, 0                                 // (a whole-insert run leaves nothing to check)
+    s_cbranch_scc0 .Lafter_lits
+    LIT_RUN_END .Llit_r_run, .Lflush_stub_lit_r
+    LIT_RUN_STUBS 9, .Llit_r_run, .Lflush_stub_lit_r
 .Lafter_lits:
     s_mov_b32 INS, 0
     s_mov_b32 PBASE, POS                                // (nothing is pending here)
     s_cmp_eq_u32 POS, MBEND
     s_cbranch_scc0 .Lno_lits
     s_branch .Lexit                                     // :2069 the copy part of the last command is ignored
+.Lx_lit_block:                                          // literal block count exhausted (or poisoned) at a run start
+    s_branch .Lexit
 
 // one literal tree, resident: no contexts
 .Lhave_lits1:
     s_call_b64 LINKB, .Lland
     s_add_u32 T0, POS, SKEW
     v_mov_b32 VPA, T0
-    s_sub_u32 INS, INS, 1
+    LIT_RUN_FAST .Llit1_run
+    s_branch .Llit1
+.Llit1_run:
+    LIT_RUN_SETUP .Lflush_stub_lit1
 .Llit1:
-    s_sub_u32 LBLEN, LBLEN, 1
-    s_cbranch_scc1 .Lx_lit_switch
-    LOOKUP2 VLITL, VLITB, LITSYM, 1, ds_read_u16, 0
+    LOOKUP2F VLITL, VLITB, 1, ds_read_u16
     v_and_b32 VT0, RMASK, VPA
     v_add_u32 VPA, 1, VPA
-    s_add_u32 POS, POS, 1
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN
     s_nop 1
     v_mov_b32 VE, T0
     ds_write_b8 VT0, VE
-    s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc1 .Lflush_stub_lit1
-.Lflush_back_lit1:
-    REFILL_CHECK 7
-    s_sub_u32 INS, INS, 1
+    s_cmp_lt_u32 SNAV, 32
+    s_cbranch_scc1 .Lrf_stub_7
+.Lrf_back_7:
+    s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit1
-    s_branch .Lafter_lits
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc0 .Lafter_lits
+    LIT_RUN_END .Llit1_run, .Lflush_stub_lit1
+    LIT_RUN_STUBS 7, .Llit1_run, .Lflush_stub_lit1
 
 // ---- last-distance codes 0..15 (decode_distance :1412-1450)
 .Ldist_single:
@@ -1041,9 +1166,6 @@
 .Lflush_go:
     FLUSH_BODY .Lflush_loop
     s_setpc_b64 LINKC
-.Lflush_stub_lit1:
-    s_call_b64 LINKC, .Lflush
-    s_branch .Lflush_back_lit1
 
 // Refill reached lane WLSTOP: either the staged chunk is used up (roll the two chunks, request the next one) or
 // the cursor is within 256 bits of the end of the stream (poison the block counters so that the loop leaves at
@@ -1085,9 +1207,7 @@
     REFILL_STUB 4
     REFILL_STUB 5
     REFILL_STUB 6
-    REFILL_STUB 7
     REFILL_STUB 8
-    REFILL_STUB 9
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.

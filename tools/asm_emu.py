@@ -122,7 +122,7 @@ def decode_program(prog):
                 else:
                     i.mods[m] = True
             core = _MODS.sub("", " " + args).strip()
-            toks = [t for t in re.split(r",\s*", core) if t] if core else []
+            toks = [t for t in re.split(r",\s*(?![A-Z0-9,]*\))", core) if t] if core else []  # (not inside gpr_idx(...))
             i.ops = [parse_operand(t) for t in toks]
             if i.op.startswith(("s_branch", "s_cbranch")):
                 off = i.ops[0][1]
@@ -163,6 +163,7 @@ class Wave:
         self.S[S_EXEC] = MASK32
         self.S[S_EXEC + 1] = MASK32
         self.trace = False
+        self.watch = None
         self.lds_conflicts = 0
         self.gpr_idx = None
         self.cyc_at, self.hits, self.last_pc, self.last_cyc = None, {}, None, 0
@@ -318,7 +319,12 @@ class Wave:
                     raise EmuError("%#x %s: register %s%d has a load in flight (missing s_waitcnt)" % (i.addr, i.text, r[0], r[1]))
         S = self.S
         if self.gpr_idx is not None and op.startswith("v_") and op != "v_mov_b32":
-            raise EmuError("%#x %s: VALU instruction other than v_mov_b32 inside VGPR index mode (not modelled)" % (i.addr, i.text))
+            # VGPR index mode: the operands the mode bits name (ops[0] = destination, ops[k + 1] = source k) move by M0[7:0]
+            idx, mask = self.gpr_idx
+            ops = list(ops)
+            for bit, k in ((1, 1), (2, 2), (4, 3), (8, 0)):
+                if (mask & bit) and k < len(ops) and ops[k][0] == "v":
+                    ops[k] = ("v", ops[k][1] + idx, ops[k][2])
         if op == "s_waitcnt":
             w = i.wait
             if "vmcnt" in w:
@@ -664,6 +670,9 @@ class Wave:
         while pc < end:
             if self.trace:
                 print("%#06x %s" % (self.insts[pc].addr, self.insts[pc].text))
+            if self.watch and self.insts[pc].addr in self.watch:  # --watch ADDR:sN,sM,vK ...: values before the instruction
+                print("watch %#06x %s | %s" % (self.insts[pc].addr, self.insts[pc].text, " ".join(
+                    "%s=%#x" % (r, int(self.S[int(r[1:])]) if r[0] == "s" else int(self.V[int(r[1:])][0])) for r in self.watch[self.insts[pc].addr])))
             pc = self.step(pc)
             n += 1
             if n > max_steps:
@@ -764,6 +773,7 @@ def run_one(insts, index, rec, comp, expect, cmds, tables, args):
     assert 0 <= mis < 4, (hex(d_in), hex(in_words))
     w = Wave(insts, index)
     w.trace = args.trace
+    w.watch = {int(x.split(':')[0], 16): x.split(':')[1].split(',') for x in args.watch} if args.watch else None
     if getattr(args, "cyc_profile", False):
         w.cyc_at = run_one.cyc_at
         w.hits = run_one.hits
@@ -863,6 +873,7 @@ def main():
     ap.add_argument("--only", type=int, default=None, help="run only dump record N")
     ap.add_argument("--every", type=int, default=1, help="run every N-th record")
     ap.add_argument("--trace", action="store_true")
+    ap.add_argument("--watch", action="append", help="ADDR:reg,reg,... print these registers (lane 0 of a VGPR) before the instruction at ADDR")
     ap.add_argument("--hbm", action="store_true", help="far copies cost an HBM miss instead of an L2 hit in the estimate")
     ap.add_argument("--max-steps", type=int, default=20_000_000)
     ap.add_argument("--profile", action="store_true", help="print instruction counts per opcode")
