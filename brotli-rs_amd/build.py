@@ -1,5 +1,6 @@
 """Build libbrx.so (HIP kernels + C ABI) in-tree for gfx950.  hipcc cross-compiles without a GPU."""
 import os
+import re
 import subprocess
 import sys
 
@@ -45,11 +46,17 @@ def _build_locked(verbose):
     prof = ["-DBRX_PROF"] if os.environ.get("BRX_PROF") == "1" else []  # bring-up: timers inside the loop
     if os.environ.get("BRX_NO_SPEC") == "1":
         prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
-    hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + [os.path.join(CSRC, "brx_hot.S")]).decode()
-    assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
-    with open(os.path.join(CSRC, "_gen", "brx_hot_asm.h"), "w") as f:
-        f.write("// generated from brx_hot.S by build.py -- do not edit\n")
-        f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
+    # two builds of the loop (brx_hot.S, "Two builds of this file"): bit window in VGPRs (full chip) / in SGPRs (few waves per CU)
+    for name, defs, prefix in (("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_")):
+        hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + defs + [os.path.join(CSRC, "brx_hot.S")]).decode()
+        assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
+        if prefix:
+            hot = hot.replace(".L", prefix)  # both texts land in one assembly file: distinct local labels
+        macros = re.findall(r"^\s*\.macro\s+(\w+)", hot, flags=re.M)
+        hot += "".join(".purgem %s\n" % m for m in macros)  # ... and macro names free again after each
+        with open(os.path.join(CSRC, "_gen", name), "w") as f:
+            f.write("// generated from brx_hot.S by build.py -- do not edit\n")
+            f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())

@@ -88,6 +88,7 @@ struct brx_ctx {
     // options read once from the environment (bring-up switches)
     uint32_t debug_stop = 0;
     bool debug_stats = false, debug_stats_all = false, no_order = false;
+    int loop_build = -1; // -1 = by occupancy (launch()); bring-up: BRX_LOOP_BUILD forces 0 / 1
     uint32_t dump_interval = 0, dump_max = 0; // BRX_DEBUG_DUMP=interval:max:path (with BRX_DEBUG_STOP=9)
     std::string dump_path;
     // host-mode device staging (grown on demand)
@@ -178,6 +179,7 @@ static int ctx_init(brx_ctx *c, int device) {
         c->debug_stats = getenv("BRX_DEBUG_STATS") != nullptr;
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
         c->no_order = getenv("BRX_NO_ORDER") != nullptr;
+        if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
         if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
             unsigned iv = 0, mx = 0;
             char path[400];
@@ -328,6 +330,9 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
     return BRX_SUCCESS;
 }
 
+// Streams per CU up to which a launch counts as sparse (profiles/r02_loop_build_sweep.txt).
+#define BRX_SW_WAVES_PER_CU 8u
+
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
                   const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr) {
@@ -349,6 +354,9 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         a.pool = c->d_pool;
     }
     a.resume = d_resume;
+    // which build of the command loop (brx_hot.S): with at most BRX_SW_WAVES_PER_CU streams per CU the CU's scalar ALU has
+    // room and the build with the shorter dependent chain wins; fuller CUs take the one that spares the scalar ALU
+    a.loop_build = c->loop_build >= 0 ? (uint32_t)c->loop_build : (grid <= c->max_grid / 16u * BRX_SW_WAVES_PER_CU ? 1u : 0u);
     a.work_counter = c->d_counters + (size_t)(c->launch_seq++ % BRX_COUNTER_RING) * 16u; // one 64-B line per launch
     a.debug = nullptr;
     unsigned long long *dbg = nullptr;

@@ -84,8 +84,13 @@
 #define LBLEN s65
 #define IBLEN s66
 #define DBLEN s67
-#define P1 s68
-#define RUN s58                 // literals left in the current run, one behind
+#define RUN s68                 // literals left in the current run, one behind
+#define NXT s[58:59]            // the next dword of the staged input (lane WL of chunk A), zero-extended
+#define NXTLO s58
+#define NXTHI s59
+#define WIN s[62:63]            // the bit window
+#define WINLO s62
+#define WINHI s63
 #define MBEND s69
 #define SNAV s70
 #define DCTX s94
@@ -175,13 +180,13 @@
 #define VCMIDX v55          // (entry only) 4 * tree index per context id
 #define VCMAP v86           // lane c: 2 * tree index of context id c (the M0 value of its pair)
 
-// The bit window lives in a VGPR pair (the same value in every lane); bits are taken from the low end of VWIN; SNAV =
-// number of valid bits (>= 32 after a REFILL_CHECK).  What a wave pays is cycles, loaded or alone (under load the chip
-// just clocks lower: 4096 streams take the same ~24 M wave-cycles per alice29 stream as one stream does): ~4.2 per
-// instruction, ~10 per scalar conditional branch that falls through, ~21-25 per taken branch, ~24 for a
-// v_cmp + s_cbranch_vccnz pair, ~50 per LDS / scalar-cache round trip, ~6 more per VGPR <-> SGPR crossing
-// (tools/ubench/issue.hip).  So: branch conditions and counters that only steer control flow live in SGPRs, the
-// arithmetic on the window in uniform VGPRs, and the common path of a command has as few branches as it can.
+// The bit window (a VGPR pair with the same value in every lane, or an SGPR pair: see TAKE); bits are taken from its low end; SNAV =
+// number of valid bits (>= 32 after a REFILL_CHECK).  A lone wave pays ~4.2 cycles per instruction, ~10 per scalar
+// conditional branch that falls through, ~21-25 per taken branch, ~24 for a v_cmp + s_cbranch_vccnz pair, ~50 per LDS /
+// scalar-cache round trip, ~16 when a SALU instruction consumes an SGPR a VALU instruction wrote (tools/ubench/issue.hip).
+// Sixteen waves on a CU additionally share its scalar ALU (1 instruction per cycle for all of them), the port for
+// SGPR-writing VALU instructions (v_cmp, v_readlane: ~1 per cycle) and the branch unit (~0.6 per cycle)
+// (tools/ubench/power.hip): on a full chip the scalar instruction count of a command is what bounds it.
 // Refill discipline: >= 32 valid bits at .Lcmd; an insert&copy symbol (<= 15) leaves >= 17, enough for a literal or a
 // distance symbol (<= 15); every literal, every extra-bit field > 0 and the distance symbol are followed by a check.
 // (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
@@ -213,18 +218,62 @@
 .macro PROF_MARK acc
 .endm
 #endif
+// Two builds of this file (tools/ubench/power.hip has the measurements behind the choice): a CU has ONE scalar ALU for
+// all of its waves (1 instruction per cycle), while its four SIMDs retire two uniform VALU instructions per cycle
+// between them.  With 16 streams on a CU the scalar ALU is the busiest unit, so the default build keeps the window
+// arithmetic on the vector side; with few waves per CU nothing is contended and the shortest dependent chain wins:
+// -DBRX_WIN_SGPR keeps the window in SGPRs (no VGPR -> SGPR hand-overs for the extra-bit fields, a shorter refill).
+#ifdef BRX_WIN_SGPR
+#define WSRC WINLO
+.macro TAKE n
+    s_lshr_b64 WIN, WIN, \n
+    s_sub_u32 SNAV, SNAV, \n
+.endm
+// \n (an SGPR, <= 24; >= 32 valid bits) extra bits: \dst = \base + (bits << \shift)
+.macro TAKE_EXTRA dst, base, n, shift=0
+    s_bfm_b32 T0, \n, 0
+    s_and_b32 T0, WINLO, T0
+    .ifnc \shift,0
+    s_lshl_b32 T0, T0, \shift
+    .endif
+    s_add_u32 \dst, \base, T0
+    TAKE \n
+.endm
+// the next dword of the staged input enters the window (it was fetched from its lane when the previous one went in, so
+// the VALU -> SALU hand-over is long done); leaves the WL == WLSTOP test in SCC
+.macro REFILL_CORE
+    s_lshl_b64 T01, NXT, SNAV
+    s_or_b64 WIN, WIN, T01
+    s_add_u32 SNAV, SNAV, 32
+    s_add_u32 WL, WL, 1
+    v_readlane_b32 NXTLO, VCHA, WL
+    s_cmp_lg_u32 WL, WLSTOP
+.endm
+.macro WIN_INIT lo, hi                                  // at entry: the first two dwords, already shifted
+    s_mov_b32 WINLO, \lo
+    s_mov_b32 WINHI, \hi
+    v_readlane_b32 NXTLO, VCHA, 2
+    s_mov_b32 NXTHI, 0
+.endm
+.macro WIN_ROLLED                                       // after the input staging rolled (WL = 0)
+    v_readlane_b32 NXTLO, VCHA, 0
+.endm
+#else
+#define WSRC VWINLO
 .macro TAKE n
     v_lshrrev_b64 VWIN, \n, VWIN
     s_sub_u32 SNAV, SNAV, \n
 .endm
-.macro REFILL_CHECK id
-    s_cmp_lt_u32 SNAV, 32
-    s_cbranch_scc1 .Lrf_stub_\id
-.Lrf_back_\id:
+.macro TAKE_EXTRA dst, base, n, shift=0
+    v_bfe_u32 VEX, VWINLO, 0, \n
+    .ifnc \shift,0
+    v_lshlrev_b32 VEX, \shift, VEX
+    .endif
+    v_add_u32 VEX, \base, VEX
+    TAKE \n
+    v_readfirstlane_b32 \dst, VEX
 .endm
-// Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
-.macro REFILL_STUB id
-.Lrf_stub_\id:
+.macro REFILL_CORE
     v_readlane_b32 T0, VCHA, WL
     v_mov_b32 VRFHI, 0
     s_nop 1                                             // gfx940+: VALU-written SGPR read by a VALU: 2 wait states
@@ -235,6 +284,23 @@
     s_add_u32 SNAV, SNAV, 32
     s_add_u32 WL, WL, 1
     s_cmp_lg_u32 WL, WLSTOP
+.endm
+.macro WIN_INIT lo, hi
+    v_mov_b32 VWINLO, \lo
+    v_mov_b32 VWINHI, \hi
+.endm
+.macro WIN_ROLLED
+.endm
+#endif
+.macro REFILL_CHECK id
+    s_cmp_lt_u32 SNAV, 32
+    s_cbranch_scc1 .Lrf_stub_\id
+.Lrf_back_\id:
+.endm
+// Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
+.macro REFILL_STUB id
+.Lrf_stub_\id:
+    REFILL_CORE
     s_cbranch_scc1 .Lrf_back_\id
     s_call_b64 LINKA, .Lspecial
     s_branch .Lrf_back_\id
@@ -244,7 +310,7 @@
 // Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
 // Every code is complete (precondition), so some lane always matches; the lowest matching lane is the length.
 .macro LOOKUP lim, base
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
     s_ff1_i32_b32 CLEN, vcc_lo
@@ -262,7 +328,7 @@
 // (A/B switch, BRX_NO_SPEC=1 at build time: the same lookup with the fetch BEHIND the length -- ballot, s_ff1, base of that
 // length, then one fetch of the one entry; every lane ends up with the same entry.  profiles/r02_spec_ab.txt)
 .macro LOOKUP2 lim, base, symbase, scale, rd, off
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
     s_ff1_i32_b32 CLEN, vcc_lo
@@ -276,7 +342,7 @@
     TAKE CLEN
 .endm
 .macro LOOKUP2F lim, basep, scale, rd
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
     s_ff1_i32_b32 CLEN, vcc_lo
@@ -289,7 +355,7 @@
     TAKE CLEN
 .endm
 .macro LOOKUP2X
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     s_set_gpr_idx_on T6, 2
     v_cmp_lt_u32 vcc, VU, VTREES
@@ -307,7 +373,7 @@
 .endm
 #else
 .macro LOOKUP2 lim, base, symbase, scale, rd, off
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
     v_lshrrev_b32 VI, VSH, VR
@@ -320,7 +386,7 @@
 // The lookup in one of the register-resident literal trees, T6 = 2 * its index: the VGPR index mode (gfx9 has no
 // v_movrel) redirects the second source of the compare (limits) and the third of the shift-add (folded bases).
 .macro LOOKUP2X
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_lshrrev_b32 VI, VSH, VR
     s_set_gpr_idx_on T6, 6                              // SRC1 | SRC2 + T6
@@ -334,7 +400,7 @@
 // The lookup of a tree that lives in registers: \basep = per-lane (base[L] << scale) + LDS address of the symbol list,
 // folded once when the tree is loaded, so the candidate address is one shift and one shift-add.
 .macro LOOKUP2F lim, basep, scale, rd
-    v_bfrev_b32 VR, VWINLO
+    v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
     v_lshrrev_b32 VI, VSH, VR
@@ -628,8 +694,7 @@
     v_readlane_b32 s37, VCHA, 1
     s_lshr_b64 s[36:37], s[36:37], T3
     s_sub_u32 SNAV, 64, T3
-    v_mov_b32 VWINLO, s36
-    v_mov_b32 VWINHI, s37
+    WIN_INIT s36, s37
     s_mov_b32 WL, 2
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
@@ -712,11 +777,7 @@
     s_cbranch_scc1 .Ldist_ring
     s_and_b32 T1, DCODE, 31
     s_lshr_b32 T2, DCODE, 5
-    v_bfe_u32 VEX, VWINLO, 0, T1
-    v_lshlrev_b32 VEX, NPOST, VEX
-    v_add_u32 VEX, T2, VEX                              // base + (extra << NPOSTFIX)
-    TAKE T1
-    v_readfirstlane_b32 DIST, VEX
+    TAKE_EXTRA DIST, T2, T1, NPOST                      // base + (extra << NPOSTFIX)
 .Ldist_push:
     PROF_MARK s30                                       // distance symbol
     s_cmp_gt_u32 DIST, MAXA
@@ -785,15 +846,9 @@
     REFILL_CHECK 1
     s_and_b32 T2, s95, 0xff                             // insert extra bits
     s_bfe_u32 T3, s95, 0x80008                          // copy extra bits
-    v_bfe_u32 VEX, VWINLO, 0, T2
-    v_add_u32 VEX, INS, VEX
-    TAKE T2
-    v_readfirstlane_b32 INS, VEX
+    TAKE_EXTRA INS, INS, T2
     REFILL_CHECK 2
-    v_bfe_u32 VEX, VWINLO, 0, T3
-    v_add_u32 VEX, CPY, VEX
-    TAKE T3
-    v_readfirstlane_b32 CPY, VEX
+    TAKE_EXTRA CPY, CPY, T3
     REFILL_CHECK 3
     s_branch .Lr1
 
@@ -841,16 +896,7 @@
     s_cbranch_scc1 \again
     s_branch .Lafter_lits
 .Lrf_stub_\id:
-    v_readlane_b32 T0, VCHA, WL
-    v_mov_b32 VRFHI, 0
-    s_nop 1
-    v_mov_b32 VRFLO, T0
-    v_lshlrev_b64 VRF, SNAV, VRF
-    v_or_b32 VWINLO, VWINLO, VRFLO
-    v_or_b32 VWINHI, VWINHI, VRFHI
-    s_add_u32 SNAV, SNAV, 32
-    s_add_u32 WL, WL, 1
-    s_cmp_lg_u32 WL, WLSTOP
+    REFILL_CORE
     s_cbranch_scc1 .Lrf_back_\id
     s_add_u32 INS, INS, RUN
     s_add_u32 LBLEN, LBLEN, RUN
@@ -1184,6 +1230,7 @@
     global_load_dword VCHB, VT4, INP
     s_mov_b64 exec, XLOOP
     s_mov_b32 WL, 0
+    WIN_ROLLED
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
     s_min_u32 WLSTOP, T0, 64

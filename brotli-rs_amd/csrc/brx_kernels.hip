@@ -1174,19 +1174,32 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
 
 // The assembly command loop (brx_hot.S).  No operands: it reads and writes the parked state in LDS and returns the
 // resume point it stopped at (0 = R0, 1 = R1, 2 = R2) in mbw[MBW_EXIT].
+#define BRX_ASM_CLOBBERS \
+        "memory", "vcc", "scc", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s29", "s30", "s31", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", \
+          "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", \
+          "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", \
+          "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", \
+          "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", \
+          "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", \
+          "v84", "v85", "v86", "m0"
+// Two builds of the same loop (brx_hot.S, "Two builds of this file"): the bit window in VGPRs -- for a full chip, where
+// the CU's one scalar ALU is the busiest unit -- or in SGPRs -- for launches that leave the CUs mostly empty, where the
+// shortest dependent chain wins.  BrxKernelArgs::loop_build picks one per launch.
 __device__ __noinline__ u32 asm_commands() {
     asm volatile(
 #include "_gen/brx_hot_asm.h"
         :
         :
-        : "memory", "vcc", "scc", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s29", "s30", "s31", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s24", "s25", "s26", "s27", "s28", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
-          "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",
-          "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
-          "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96",
-          "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
-          "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
-          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83",
-          "v84", "v85", "v86", "m0");
+        : BRX_ASM_CLOBBERS);
+    return rfl(g_lds.mbw[MBW_EXIT]);
+}
+__device__ __noinline__ u32 asm_commands_sw() {
+    asm volatile(
+#include "_gen/brx_hot_asm_sw.h"
+        :
+        :
+        : BRX_ASM_CLOBBERS);
     return rfl(g_lds.mbw[MBW_EXIT]);
 }
 
@@ -1592,6 +1605,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
     if (a.debug_stop == 1u) return;
+    const bool sw_loop = a.loop_build != 0u;
     for (;;) {
         // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
         // behind the lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63
@@ -1672,7 +1686,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                 while (st == HC_CONTINUE) {
                     if ((u64)rfl(s.st[10]) >= pause_at) { paused = true; break; }
                     if (rfl(s.mbw[MBW_ASM]) != 0u) {
-                        const u32 r = asm_commands();
+                        const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
                         st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
                     } else {
                         st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
@@ -1736,7 +1750,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
                 if (prof_on && lane == 0u) s.pad[use_asm ? 2 : 0]++;
                 if (st == HC_CONTINUE && !use_asm) st = generic_commands(HC_RESUME_R1_WHOLE);
                 while (st == HC_CONTINUE) {
-                    const u32 r = asm_commands();
+                    const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                     }

@@ -47,7 +47,7 @@ class EmuError(Exception):
 def disassemble(src):
     with tempfile.TemporaryDirectory() as t:
         pp, obj = os.path.join(t, "hot.s"), os.path.join(t, "hot.o")
-        subprocess.check_call(["cpp", "-P", "-x", "assembler-with-cpp", src, "-o", pp])
+        subprocess.check_call(["cpp", "-P", "-x", "assembler-with-cpp"] + ["-D" + d for d in os.environ.get("ASM_DEFS", "").split()] + [src, "-o", pp])  # ASM_DEFS="BRX_WIN_SGPR": the other build
         subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", pp, "-o", obj])
         out = subprocess.check_output([OBJDUMP, "-d", obj]).decode()
     prog = []

@@ -28,7 +28,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 def disassemble():
     with tempfile.TemporaryDirectory() as t:
         pp, obj = os.path.join(t, "hot.s"), os.path.join(t, "hot.o")
-        subprocess.check_call(["cpp", "-P", "-x", "assembler-with-cpp", SRC, "-o", pp])
+        subprocess.check_call(["cpp", "-P", "-x", "assembler-with-cpp"] + ["-D" + d for d in os.environ.get("ASM_DEFS", "").split()] + [SRC, "-o", pp])
         subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", pp, "-o", obj])
         out = subprocess.check_output([OBJDUMP, "-d", obj]).decode()
     ins = []

@@ -40,6 +40,13 @@ TIMED(k_bfm_exec, "s_bfm_b64 exec, 5, 3\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, 
 TIMED(k_readlane2, "v_readlane_b32 s90, %2, 3\n v_add_u32 %3, s90, %3")
 TIMED(k_lshl_b64, "v_lshrrev_b64 v[10:11], %6, v[10:11]")
 TIMED(k_ffbl, "v_cmp_lt_u32 vcc, %3, %2\n s_ff1_i32_b32 s90, vcc_lo\n s_add_u32 %6, %6, s90")
+TIMED(k_vdep_x16, "s_mov_b64 exec, 0xffff\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, -1")
+TIMED(k_vdep_x17, "s_mov_b64 exec, 0x1ffff\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, -1")
+TIMED(k_vdep_x1, "s_mov_b64 exec, 1\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, -1")
+TIMED(k_vdep_x64, "s_mov_b64 exec, -1\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n v_add_u32 %2, 1, %2\n s_mov_b64 exec, -1")
+TIMED(k_idx_salu, "v_readlane_b32 s90, %2, %6\n s_set_gpr_idx_on s90, 6\n v_cmp_lt_u32 vcc, %3, %4\n v_lshl_add_u32 %5, %5, 1, %4\n s_set_gpr_idx_off")
+TIMED(k_win_s, "s_lshr_b64 s[92:93], s[92:93], %6\n v_bfrev_b32 %2, s92\n v_cmp_lt_u32 vcc, %2, %3\n s_ff1_i32_b32 %6, vcc_lo")
+TIMED(k_win_v, "v_lshrrev_b64 v[10:11], %6, v[10:11]\n v_bfrev_b32 %2, v10\n v_cmp_lt_u32 vcc, %2, %3\n s_ff1_i32_b32 %6, vcc_lo")
 int main() {
     u64 *o; u32 *b;
     hipMalloc(&o, 64); hipMalloc(&b, 4096); hipMemset(b, 0, 4096);
@@ -69,5 +76,12 @@ int main() {
     RUN(k_readlane2, 2, "v_readlane -> v_add (SGPR operand)");
     RUN(k_lshl_b64, 1, "v_lshrrev_b64 dependent");
     RUN(k_ffbl, 3, "v_cmp -> s_ff1 -> s_add");
+    RUN(k_vdep_x64, 6, "exec -1 : s_mov exec + 4 dependent v_add + s_mov exec");
+    RUN(k_vdep_x17, 6, "exec 17 lanes: same");
+    RUN(k_vdep_x16, 6, "exec 16 lanes: same");
+    RUN(k_vdep_x1, 6, "exec 1 lane: same");
+    RUN(k_idx_salu, 5, "v_readlane -> s_set_gpr_idx_on -> v_cmp, v_lshl_add indexed -> off");
+    RUN(k_win_s, 4, "window in SGPRs: s_lshr_b64 -> v_bfrev -> v_cmp -> s_ff1 chain");
+    RUN(k_win_v, 4, "window in VGPRs: v_lshrrev_b64 -> v_bfrev -> v_cmp -> s_ff1 chain");
     return 0;
 }

@@ -1,0 +1,85 @@
+// power.hip -- what the loaded clock of gfx950 does with the instruction mix: every CU runs 16 waves (one 1024-thread
+// workgroup holding most of the LDS) of the same pattern for ~20 ms; clock = s_memtime ticks / wall time.
+// Build: hipcc --offload-arch=gfx950 -O2 power.hip -o power
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned long long u64;
+typedef unsigned int u32;
+#define KERNEL(NAME, BODY)                                                                                         \
+    __global__ void __launch_bounds__(1024) NAME(u64 *out, u32 iters, u32 *buf) {                                            \
+        __shared__ u32 lds[24 * 1024];                                                                             \
+        lds[threadIdx.x] = threadIdx.x * 4;                                                                        \
+        __syncthreads();                                                                                           \
+        u64 t0, t1;                                                                                                \
+        u32 v0 = (threadIdx.x & 63) * 4, v1 = 1, v2 = 2, v3 = 3, s0 = 1, s1 = 2, s2 = 3, s3 = iters;              \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)\n1:\n .rept 64\n" BODY "\n .endr\n s_sub_u32 %9, %9, 1\n s_cmp_lg_u32 %9, 0\n s_cbranch_scc1 1b\n s_mov_b64 exec, -1\n s_memtime %1\n s_waitcnt lgkmcnt(0)" \
+                     : "=s"(t0), "=s"(t1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) \
+                     : "s"(buf) : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "v10", "v11");                         \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = v0 + v1 + v2 + v3 + s0 + s1 + s2 + lds[5]; } \
+    }
+KERNEL(k_s, "s_add_u32 %6, %6, 1")
+KERNEL(k_s64, "s_lshr_b64 s[92:93], s[92:93], 1")
+KERNEL(k_v64, "v_add_u32 %2, 1, %2")
+KERNEL(k_v17, "s_mov_b64 exec, 0x1ffff\n v_add_u32 %2, 1, %2")
+KERNEL(k_v1, "s_mov_b64 exec, 1\n v_add_u32 %2, 1, %2")
+KERNEL(k_vb64, "v_lshrrev_b64 v[10:11], 1, v[10:11]")
+KERNEL(k_nop, "s_nop 0")
+KERNEL(k_br, "s_cmp_eq_u32 %6, 0\n s_cbranch_scc1 2f\n2:")
+KERNEL(k_rl, "v_readlane_b32 s90, %2, 3")
+KERNEL(k_lds16, "s_mov_b64 exec, 0xffff\n ds_read_u16 %3, %2\n s_waitcnt lgkmcnt(0)")
+KERNEL(k_lds1, "s_mov_b64 exec, 1\n ds_read_u16 %3, %2\n s_waitcnt lgkmcnt(0)")
+KERNEL(k_sleep, "s_sleep 1")
+KERNEL(k_s_rl, "s_add_u32 %6, %6, 1\n v_readlane_b32 s90, %2, 3")
+KERNEL(k_s_brn, "s_add_u32 %6, %6, 1\n s_cbranch_scc1 2f\n2:")
+KERNEL(k_nop_brn, "s_nop 0\n s_cbranch_scc1 2f\n2:")
+KERNEL(k_s_brt, "s_add_u32 %6, %6, 1\n s_cbranch_scc0 2f\n s_nop 0\n2:")
+KERNEL(k_s_v, "s_add_u32 %6, %6, 1\n v_add_u32 %2, 1, %2")
+KERNEL(k_s_vv, "s_add_u32 %6, %6, 1\n v_add_u32 %2, 1, %2\n v_add_u32 %3, 1, %3")
+KERNEL(k_s_vcmp, "s_add_u32 %6, %6, 1\n v_cmp_lt_u32 vcc, %2, %3")
+KERNEL(k_vcmp, "v_cmp_lt_u32 vcc, %2, %3")
+KERNEL(k_vcmp_br, "v_cmp_lt_u32 vcc, %2, %3\n s_cbranch_vccnz 2f\n2:")
+KERNEL(k_s_wait, "s_add_u32 %6, %6, 1\n s_waitcnt lgkmcnt(0)")
+KERNEL(k_s_smem, "s_add_u32 %6, %6, 1\n s_load_dword s90, %10, 0\n s_waitcnt lgkmcnt(0)")
+KERNEL(k_s_lds, "s_add_u32 %6, %6, 1\n ds_read_u16 %3, %2")
+KERNEL(k_s_vb64, "s_add_u32 %6, %6, 1\n v_lshrrev_b64 v[10:11], 1, v[10:11]")
+KERNEL(k_rfl, "v_readfirstlane_b32 s90, %2")
+KERNEL(k_s_wl, "s_add_u32 %6, %6, 1\n v_writelane_b32 %3, s90, 5")
+KERNEL(k_s_vs, "s_add_u32 %6, %6, 1\n v_add_u32 %2, %7, %2")
+int main() {
+    u64 *o; hipMalloc(&o, 64);
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    int cus = p.multiProcessorCount;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+#define RUN(K, IT, WHAT) for (int g : {1, cus}) { float ms = 0; u64 h[2]; for (int r = 0; r < 2; r++) { hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(g), dim3(1024), 0, 0, o, IT, (u32 *)o); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, o, 16, hipMemcpyDeviceToHost); } \
+      printf("%-40s %3d CU(s) x 16 waves: %7.2f ms, %6.3f GHz by s_memtime\n", WHAT, g, ms, h[0] / (ms * 1e6)); }
+    RUN(k_s, 60000, "s_add chain");
+    RUN(k_s64, 60000, "s_lshr_b64 chain");
+    RUN(k_v64, 60000, "v_add, 64 lanes");
+    RUN(k_v17, 30000, "s_mov exec + v_add, 17 lanes");
+    RUN(k_v1, 30000, "s_mov exec + v_add, 1 lane");
+    RUN(k_vb64, 60000, "v_lshrrev_b64, 64 lanes");
+    RUN(k_nop, 60000, "s_nop 0");
+    RUN(k_br, 30000, "s_cmp + s_cbranch not taken");
+    RUN(k_rl, 60000, "v_readlane");
+    RUN(k_lds16, 6000, "ds_read_u16 16 lanes + wait");
+    RUN(k_lds1, 6000, "ds_read_u16 1 lane + wait");
+    RUN(k_sleep, 10000, "s_sleep 1");
+    printf("-- mixes (time only matters: 16 waves on one CU; s_add alone = the scalar unit's 1 per cycle)\n");
+    RUN(k_s_rl, 30000, "s_add + v_readlane");
+    RUN(k_rfl, 60000, "v_readfirstlane");
+    RUN(k_s_wl, 30000, "s_add + v_writelane");
+    RUN(k_s_brn, 30000, "s_add + s_cbranch not taken");
+    RUN(k_nop_brn, 30000, "s_nop + s_cbranch not taken");
+    RUN(k_s_brt, 30000, "s_add + s_cbranch taken (+ skipped nop)");
+    RUN(k_s_v, 30000, "s_add + v_add");
+    RUN(k_s_vv, 20000, "s_add + 2 v_add");
+    RUN(k_s_vs, 30000, "s_add + v_add with an SGPR operand");
+    RUN(k_s_vcmp, 30000, "s_add + v_cmp");
+    RUN(k_vcmp, 60000, "v_cmp");
+    RUN(k_vcmp_br, 30000, "v_cmp + s_cbranch_vccnz not taken");
+    RUN(k_s_wait, 30000, "s_add + s_waitcnt");
+    RUN(k_s_smem, 10000, "s_add + s_load_dword + wait");
+    RUN(k_s_lds, 30000, "s_add + ds_read_u16 (no wait)");
+    RUN(k_s_vb64, 30000, "s_add + v_lshrrev_b64");
+    return 0;
+}
