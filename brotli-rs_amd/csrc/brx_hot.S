@@ -95,6 +95,8 @@
 #define SNAV s70
 #define DCTX s94
 #define HISYM s71
+#define MA2 s71                  // (after the entry code) MA >> 2
+#define BFEB s28                 // (after the entry code) s_bfe operand of a literal entry's share as p2
 #define CMDW s72
 #define EXITC s73
 #define IACTAB s[74:75]
@@ -732,6 +734,15 @@
     s_cbranch_scc1 .Lexit
     v_lshl_add_u32 VIACB, VIACB, 1, HISYM               // folded bases of the resident trees (LOOKUP2F)
     v_lshl_add_u32 VLITB, VLITB, 1, LITSYM
+    // (HISYM and LITSYM are free from here on) the context masks of the resident literal loop, which works on id, not id * 4:
+    // id = ((info >> 2) & MA2) | share of the previous literal; share = ((info & MB) << SB) >> 2 = a bit field of the entry
+    s_lshr_b32 MA2, MA, 2
+    s_mov_b32 BFEB, 0
+    s_cmp_eq_u32 SB, 2
+    s_cselect_b32 BFEB, 0x20008, BFEB                   // mode 2: info bits 1:0
+    s_cmp_eq_u32 MB, 0x1c
+    s_cselect_b32 BFEB, 0x3000a, BFEB                   // mode 3: info bits 4:2
+    s_mov_b32 MAXA, 0
     s_mov_b64 exec, XLOOP
     s_branch .Lr1
 
@@ -753,14 +764,13 @@
     PROF_MARK s23                                       // insert&copy symbol (+ extras; + entry)
     // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
     v_readlane_b32 DTREE, VDH4, DCTX
-    s_max_i32 T0, DTREE, 0                              // (a one-symbol tree has no header: read anything)
-    v_add_u32 VT0, T0, VLANE8
+    s_nop 1
+    v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
     ds_read_b64 VDH, VT0
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
     PROF_MARK s29                                       // R1 dispatch + literals
-    s_min_u32 MAXA, POS, WINDOW
     s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc1 .Ldist_special                       // implicit distance 0, or a one-symbol tree
     // ---- distance symbol (reference parse_distance_code :1367-1410)
@@ -780,8 +790,9 @@
     TAKE_EXTRA DIST, T2, T1, NPOST                      // base + (extra << NPOSTFIX)
 .Ldist_push:
     PROF_MARK s30                                       // distance symbol
-    s_cmp_gt_u32 DIST, MAXA
-    s_cbranch_scc1 .Ldict                               // :1476 not pushed: static dictionary reference
+    s_cmp_gt_u32 DIST, MAXA                             // MAXA: min(POS, WINDOW) as of its last exact evaluation (a lower bound)
+    s_cbranch_scc1 .Ldict_check                         // :1476 not pushed: static dictionary reference
+.Ldist_push_ok:
     v_mov_b32 VD3, VD2                                  // (only the most recent distance lives in an SGPR)
     v_mov_b32 VD2, VD1
     v_mov_b32 VD1, D0
@@ -791,10 +802,8 @@
 // of the pending register
 .Lcopy:
     s_sub_u32 T0, 63, PFREE                             // (63, not 64: s_bfm_b64 takes a 6-bit width)
-    s_sub_u32 MBLEFT, MBEND, POS
-    s_min_u32 T0, T0, DIST                              // the common case: CPY <= min(free lanes, distance, bytes left)
-    s_min_u32 T0, T0, MBLEFT
-    s_cmp_gt_u32 CPY, T0
+    s_min_u32 T0, T0, DIST                              // the common case: CPY <= min(free lanes, distance); the end of
+    s_cmp_gt_u32 CPY, T0                                // the meta-block is checked behind the copy (.Lcopy_tail)
     s_cbranch_scc1 .Lcopy_slow
     s_sub_u32 T2, PBASE, DIST                           // + lane = position of this lane's source byte  (PBASE = POS - PFREE)
     s_cmp_gt_u32 DIST, RING
@@ -810,10 +819,16 @@
 .Lcopy_tail:                                            // (the flush cursor is checked whenever pending copies land)
 .Lflush_back_cmd:
     REFILL_CHECK 6
-    s_cmp_eq_u32 POS, MBEND
+    s_cmp_ge_u32 POS, MBEND
     s_cbranch_scc0 .Lcmd
+    s_cmp_eq_u32 POS, MBEND
+    s_cbranch_scc0 .Lcopy_overrun
     s_mov_b32 INS, 0
     s_branch .Lexit
+.Lcopy_overrun:                                         // :2105 the copy runs past the meta-block: take its lanes back (nothing
+    s_sub_u32 POS, POS, CPY                             // of it has landed), the C++ side raises the error at R2
+    s_sub_u32 PFREE, PFREE, CPY
+    s_branch .Lx_r2
 
 // ---- source inside the ring.  If it reaches into bytes that are still pending, land those first.
 .Lcopy_near:
@@ -839,6 +854,14 @@
     s_mov_b32 DIST, D0
     s_cmp_gt_u32 DIST, MAXA
     s_cbranch_scc0 .Lcopy
+    s_min_u32 MAXA, POS, WINDOW
+    s_cmp_gt_u32 DIST, MAXA
+    s_cbranch_scc0 .Lcopy
+    s_branch .Ldict
+.Ldict_check:                                           // the exact bound
+    s_min_u32 MAXA, POS, WINDOW
+    s_cmp_gt_u32 DIST, MAXA
+    s_cbranch_scc0 .Ldist_push_ok
     s_branch .Ldict
 
 // ---- insert&copy extra bits (decode_insert_and_copy_length :1210-1224)
@@ -980,6 +1003,8 @@
 .Llit_r_start:
     v_readfirstlane_b32 T4, VC                          // context id * 4 of the first literal
     v_readfirstlane_b32 T5, VB4                         // p1's share as a later p2
+    s_lshr_b32 T4, T4, 2                                // (this loop works on the id itself)
+    s_lshr_b32 T5, T5, 2
 // A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
 // LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
     LIT_RUN_FAST .Llit_r_run
@@ -987,7 +1012,6 @@
 .Llit_r_run:
     LIT_RUN_SETUP .Lflush_stub_lit_r
 .Llit_r:
-    s_lshr_b32 T4, T4, 2
     v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
     LOOKUP2X
     s_waitcnt lgkmcnt(0)
@@ -996,11 +1020,10 @@
     v_add_u32 VPA, 1, VPA
     v_mov_b32 VE, T0
     ds_write_b8 VT0, VE
-    s_lshr_b32 T1, T0, 8                                // context info of this literal
-    s_and_b32 T4, T1, MA
-    s_or_b32 T4, T4, T5                                 // context id * 4 of the next one
-    s_and_b32 T5, T1, MB
-    s_lshl_b32 T5, T5, SB
+    s_bfe_u32 T1, T0, 0x6000a                           // context info of this literal >> 2
+    s_and_b32 T1, T1, MA2
+    s_or_b32 T4, T1, T5                                 // context id of the next one
+    s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
     s_cmp_lt_u32 SNAV, 32
     s_cbranch_scc1 .Lrf_stub_9
 .Lrf_back_9:
@@ -1259,6 +1282,7 @@
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
 .Lcopy_slow:
+    s_sub_u32 MBLEFT, MBEND, POS
     s_min_u32 T0, DIST, 63
     s_min_u32 T0, T0, MBLEFT
     s_cmp_gt_u32 CPY, T0

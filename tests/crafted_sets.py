@@ -96,5 +96,50 @@ def quirk_streams():
     return sets
 
 
+def boundary_streams():
+    """Copies at the two limits the assembly loop checks lazily: a copy that runs 1..3 bytes past MLEN (taken back after
+    it was issued, raised by the C++ side) -- with and without literals in front, i.e. with the copy's lanes pending or
+    landed -- and distances equal to the bytes produced so far (the largest window reference) and one more (the first
+    dictionary word, or past the window) after a long stretch of short distances (the loop's cached distance bound is
+    stale then).  Expected status / bytes come from the oracle."""
+    import random
+    from craft import Bits, MetaBlock, raw_block, stream_header
+    sets = []
+    for seed, over in enumerate((1, 2, 3, 7)):
+        for lits_first in (0, 2):
+            rng = random.Random(900 + seed)
+            head = rng.randbytes(300)
+            cmds, n = [], len(head)
+            for k in range(400):
+                lit = rng.randbytes(lits_first if k % 3 else 0)
+                cl = rng.choice((2, 3, 4, 5, 7, 9))
+                cmds.append((lit, cl, rng.randrange(1, min(n, 1500) + 1) if k % 5 else rng.randrange(cl, n + 1)))
+                n += len(lit) + cl
+            b = Bits()
+            stream_header(b, 18)
+            raw_block(b, head)
+            MetaBlock(cmds, mlen=n - len(head) - over).emit(b, True, 0)
+            # (64 more bytes behind: the assembly loop hands the last 256 bits of a stream to the C++ side, and this is about the loop)
+            sets.append(("copy_past_mlen_%d_lits%d" % (over, lits_first), b.bytes() + rng.randbytes(64), None, None))
+            sets.append(("copy_past_mlen_%d_lits%d_at_eof" % (over, lits_first), b.bytes(), None, None))
+    for delta in (0, 1, 2):
+        for cl in (4, 6):
+            rng = random.Random(950 + delta)
+            head = rng.randbytes(2000)
+            cmds, n = [], len(head)
+            for k in range(300):
+                if k % 50 == 49:
+                    cmds.append((b"xy", cl, n + 2 + delta))   # distance = position (+ delta) at the copy
+                else:
+                    cmds.append((rng.randbytes(k % 3), 3, rng.randrange(3, 64)))
+                n += len(cmds[-1][0]) + cmds[-1][1]
+            b = Bits()
+            stream_header(b, 18)
+            raw_block(b, head)
+            MetaBlock(cmds, mlen=n - len(head)).emit(b, True, 0)
+            sets.append(("distance_at_position_plus_%d_len%d" % (delta, cl), b.bytes(), None, None))
+    return sets
+
+
 def all_sets():
-    return transform_streams() + transform_edge_streams() + quirk_streams()
+    return transform_streams() + transform_edge_streams() + quirk_streams() + boundary_streams()

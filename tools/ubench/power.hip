@@ -45,6 +45,12 @@ KERNEL(k_s_vb64, "s_add_u32 %6, %6, 1\n v_lshrrev_b64 v[10:11], 1, v[10:11]")
 KERNEL(k_rfl, "v_readfirstlane_b32 s90, %2")
 KERNEL(k_s_wl, "s_add_u32 %6, %6, 1\n v_writelane_b32 %3, s90, 5")
 KERNEL(k_s_vs, "s_add_u32 %6, %6, 1\n v_add_u32 %2, %7, %2")
+KERNEL(k_ldsw17, "s_mov_b64 exec, 0x1ffff\n ds_write_b8 %4, %3")
+KERNEL(k_ldsw1, "s_mov_b64 exec, 1\n ds_write_b8 %4, %3")
+KERNEL(k_ldsw64, "s_mov_b64 exec, -1\n ds_write_b8 %4, %3")
+KERNEL(k_ldsr17s, "s_mov_b64 exec, 0x1ffff\n ds_read_u8 %3, %4")
+KERNEL(k_ldsr17d, "s_mov_b64 exec, 0x1ffff\n ds_read_u16 %3, %2")
+KERNEL(k_ldsr17b64, "s_mov_b64 exec, 0x1ffff\n ds_read_b64 v[10:11], %2")
 int main() {
     u64 *o; hipMalloc(&o, 64);
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
@@ -81,5 +87,12 @@ int main() {
     RUN(k_s_smem, 10000, "s_add + s_load_dword + wait");
     RUN(k_s_lds, 30000, "s_add + ds_read_u16 (no wait)");
     RUN(k_s_vb64, 30000, "s_add + v_lshrrev_b64");
+    printf("-- LDS instruction shapes (6000 x 64 each, no waits in between; v2 = 4 * lane, v4 = uniform 2)\n");
+    RUN(k_ldsw64, 6000, "ds_write_b8 one address, 64 lanes");
+    RUN(k_ldsw17, 6000, "ds_write_b8 one address, 17 lanes");
+    RUN(k_ldsw1, 6000, "ds_write_b8 one address, 1 lane");
+    RUN(k_ldsr17s, 6000, "ds_read_u8 one address, 17 lanes");
+    RUN(k_ldsr17d, 6000, "ds_read_u16 distinct dwords, 17 lanes");
+    RUN(k_ldsr17b64, 6000, "ds_read_b64 stride 4 B, 17 lanes");
     return 0;
 }
