@@ -227,26 +227,28 @@
 // -DBRX_WIN_SGPR keeps the window in SGPRs (no VGPR -> SGPR hand-overs for the extra-bit fields, a shorter refill).
 #ifdef BRX_WIN_SGPR
 #define WSRC WINLO
-.macro TAKE n
+.macro TAKE n, rid
     s_lshr_b64 WIN, WIN, \n
     s_sub_u32 SNAV, SNAV, \n
+    s_cbranch_scc1 .Lrf_stub_\rid
+.Lrf_back_\rid:
 .endm
 // \n (an SGPR, <= 24; >= 32 valid bits) extra bits: \dst = \base + (bits << \shift)
-.macro TAKE_EXTRA dst, base, n, shift=0
+.macro TAKE_EXTRA dst, base, n, rid, shift=0
     s_bfm_b32 T0, \n, 0
     s_and_b32 T0, WINLO, T0
     .ifnc \shift,0
     s_lshl_b32 T0, T0, \shift
     .endif
     s_add_u32 \dst, \base, T0
-    TAKE \n
+    TAKE \n, \rid
 .endm
 // the next dword of the staged input enters the window (it was fetched from its lane when the previous one went in, so
 // the VALU -> SALU hand-over is long done); leaves the WL == WLSTOP test in SCC
 .macro REFILL_CORE
+    s_add_u32 SNAV, SNAV, 32                            // (= the number of valid bits before this dword)
     s_lshl_b64 T01, NXT, SNAV
     s_or_b64 WIN, WIN, T01
-    s_add_u32 SNAV, SNAV, 32
     s_add_u32 WL, WL, 1
     v_readlane_b32 NXTLO, VCHA, WL
     s_cmp_lg_u32 WL, WLSTOP
@@ -262,17 +264,19 @@
 .endm
 #else
 #define WSRC VWINLO
-.macro TAKE n
+.macro TAKE n, rid
     v_lshrrev_b64 VWIN, \n, VWIN
-    s_sub_u32 SNAV, SNAV, \n
+    s_sub_u32 SNAV, SNAV, \n                             // borrow = fewer than 32 valid bits left
+    s_cbranch_scc1 .Lrf_stub_\rid
+.Lrf_back_\rid:
 .endm
-.macro TAKE_EXTRA dst, base, n, shift=0
+.macro TAKE_EXTRA dst, base, n, rid, shift=0
     v_bfe_u32 VEX, VWINLO, 0, \n
     .ifnc \shift,0
     v_lshlrev_b32 VEX, \shift, VEX
     .endif
     v_add_u32 VEX, \base, VEX
-    TAKE \n
+    TAKE \n, \rid
     v_readfirstlane_b32 \dst, VEX
 .endm
 .macro REFILL_CORE
@@ -280,10 +284,10 @@
     v_mov_b32 VRFHI, 0
     s_nop 1                                             // gfx940+: VALU-written SGPR read by a VALU: 2 wait states
     v_mov_b32 VRFLO, T0
+    s_add_u32 SNAV, SNAV, 32                            // (= the number of valid bits before this dword)
     v_lshlrev_b64 VRF, SNAV, VRF
     v_or_b32 VWINLO, VWINLO, VRFLO
     v_or_b32 VWINHI, VWINHI, VRFHI
-    s_add_u32 SNAV, SNAV, 32
     s_add_u32 WL, WL, 1
     s_cmp_lg_u32 WL, WLSTOP
 .endm
@@ -294,11 +298,6 @@
 .macro WIN_ROLLED
 .endm
 #endif
-.macro REFILL_CHECK id
-    s_cmp_lt_u32 SNAV, 32
-    s_cbranch_scc1 .Lrf_stub_\id
-.Lrf_back_\id:
-.endm
 // Out-of-line part of a refill: next dword of the staged input (lane WL of chunk A) enters the window.
 .macro REFILL_STUB id
 .Lrf_stub_\id:
@@ -329,7 +328,7 @@
 #ifdef BRX_NO_SPEC
 // (A/B switch, BRX_NO_SPEC=1 at build time: the same lookup with the fetch BEHIND the length -- ballot, s_ff1, base of that
 // length, then one fetch of the one entry; every lane ends up with the same entry.  profiles/r02_spec_ab.txt)
-.macro LOOKUP2 lim, base, symbase, scale, rd, off
+.macro LOOKUP2 lim, base, symbase, scale, rd, off, rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
@@ -341,9 +340,9 @@
     v_add_u32 VI, T3, VI
     v_lshl_add_u32 VI, VI, \scale, \symbase
     \rd VS, VI offset:\off
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
-.macro LOOKUP2F lim, basep, scale, rd
+.macro LOOKUP2F lim, basep, scale, rd, rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
@@ -354,9 +353,9 @@
     v_lshrrev_b32 VI, T2, VR
     v_lshl_add_u32 VI, VI, \scale, T3
     \rd VS, VI
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
-.macro LOOKUP2X
+.macro LOOKUP2X rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     s_set_gpr_idx_on T6, 2
@@ -371,10 +370,10 @@
     v_lshrrev_b32 VI, T2, VR
     v_lshl_add_u32 VI, VI, 1, T3
     ds_read_u16 VS, VI
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
 #else
-.macro LOOKUP2 lim, base, symbase, scale, rd, off
+.macro LOOKUP2 lim, base, symbase, scale, rd, off, rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
@@ -383,11 +382,11 @@
     v_lshl_add_u32 VI, VI, \scale, \symbase
     \rd VS, VI offset:\off
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
 // The lookup in one of the register-resident literal trees, T6 = 2 * its index: the VGPR index mode (gfx9 has no
 // v_movrel) redirects the second source of the compare (limits) and the third of the shift-add (folded bases).
-.macro LOOKUP2X
+.macro LOOKUP2X rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_lshrrev_b32 VI, VSH, VR
@@ -397,11 +396,11 @@
     s_set_gpr_idx_off
     ds_read_u16 VS, VI
     s_ff1_i32_b32 CLEN, vcc_lo
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
 // The lookup of a tree that lives in registers: \basep = per-lane (base[L] << scale) + LDS address of the symbol list,
 // folded once when the tree is loaded, so the candidate address is one shift and one shift-add.
-.macro LOOKUP2F lim, basep, scale, rd
+.macro LOOKUP2F lim, basep, scale, rd, rid
     v_bfrev_b32 VR, WSRC
     v_lshrrev_b32 VU, 1, VR
     v_cmp_lt_u32 vcc, VU, \lim
@@ -409,7 +408,7 @@
     v_lshl_add_u32 VI, VI, \scale, \basep
     \rd VS, VI
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
-    TAKE CLEN
+    TAKE CLEN, \rid
 .endm
 #endif
 
@@ -695,7 +694,7 @@
     v_readlane_b32 s36, VCHA, 0
     v_readlane_b32 s37, VCHA, 1
     s_lshr_b64 s[36:37], s[36:37], T3
-    s_sub_u32 SNAV, 64, T3
+    s_sub_u32 SNAV, 32, T3                              // SNAV = valid bits - 32 (TAKE)
     WIN_INIT s36, s37
     s_mov_b32 WL, 2
     s_sub_u32 T0, WSAFE, CBASE
@@ -751,7 +750,7 @@
     PROF_MARK s31                                       // copy + tail
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
-    LOOKUP2F VIACL, VIACB, 1, ds_read_u16
+    LOOKUP2F VIACL, VIACB, 1, ds_read_u16, 3
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte offset of the symbol's record in the insert&copy table
     s_load_dwordx4 s[92:95], IACTAB, T0                 // = INS base, CPY base, DCTX, extra-bit counts
@@ -777,17 +776,16 @@
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
     s_waitcnt lgkmcnt(0)
-    LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF
+    LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF, 5
     s_waitcnt lgkmcnt(0)
     // payload of the distance symbol (decode_distance :1412-1481): extra-bit count | base << 5, or (bit 31) one of the 16
     // last-distance codes / a symbol without payload form (BRX_DIST_UNFIT: handed back with its bits un-taken)
     v_readlane_b32 DCODE, VS, CLEN
-    REFILL_CHECK 5
     s_cmp_lt_i32 DCODE, 0
     s_cbranch_scc1 .Ldist_ring
     s_and_b32 T1, DCODE, 31
     s_lshr_b32 T2, DCODE, 5
-    TAKE_EXTRA DIST, T2, T1, NPOST                      // base + (extra << NPOSTFIX)
+    TAKE_EXTRA DIST, T2, T1, 6, NPOST                      // base + (extra << NPOSTFIX)
 .Ldist_push:
     PROF_MARK s30                                       // distance symbol
     s_cmp_gt_u32 DIST, MAXA                             // MAXA: min(POS, WINDOW) as of its last exact evaluation (a lower bound)
@@ -818,7 +816,6 @@
     s_add_u32 POS, POS, CPY
 .Lcopy_tail:                                            // (the flush cursor is checked whenever pending copies land)
 .Lflush_back_cmd:
-    REFILL_CHECK 6
     s_cmp_ge_u32 POS, MBEND
     s_cbranch_scc0 .Lcmd
     s_cmp_eq_u32 POS, MBEND
@@ -866,13 +863,10 @@
 
 // ---- insert&copy extra bits (decode_insert_and_copy_length :1210-1224)
 .Liac_extras:
-    REFILL_CHECK 1
     s_and_b32 T2, s95, 0xff                             // insert extra bits
     s_bfe_u32 T3, s95, 0x80008                          // copy extra bits
-    TAKE_EXTRA INS, INS, T2
-    REFILL_CHECK 2
-    TAKE_EXTRA CPY, CPY, T3
-    REFILL_CHECK 3
+    TAKE_EXTRA INS, INS, T2, 1
+    TAKE_EXTRA CPY, CPY, T3, 2
     s_branch .Lr1
 
 // ---- literal runs (the register-resident loops)
@@ -921,15 +915,12 @@
 .Lrf_stub_\id:
     REFILL_CORE
     s_cbranch_scc1 .Lrf_back_\id
-    s_add_u32 INS, INS, RUN
-    s_add_u32 LBLEN, LBLEN, RUN
+    s_add_u32 INS, INS, RUN                             // the run ends with the literal in progress (its bits are taken):
+    s_add_u32 LBLEN, LBLEN, RUN                         // RUN = the literals behind it
     s_sub_u32 POS, POS, RUN
+    s_mov_b32 RUN, 0
     s_call_b64 LINKA, .Lspecial
-    s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc1 \flush_stub
-    s_cmp_lg_u32 INS, 0
-    s_cbranch_scc1 \again
-    s_branch .Lafter_lits
+    s_branch .Lrf_back_\id
 .endm
 
 // ---- literals (reference parse_insert_literals :1286-1365)
@@ -959,7 +950,7 @@
     v_add_u32 VT0, VH, VLANE8
     ds_read_b64 VLB, VT0
     s_waitcnt lgkmcnt(0)
-    LOOKUP2 VLIM, VBASE, VH, 1, ds_read_u16, SYMOFF
+    LOOKUP2 VLIM, VBASE, VH, 1, ds_read_u16, SYMOFF, \rid
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
     v_and_b32 VT0, RMASK, VPA
@@ -983,7 +974,6 @@
     s_cmp_ge_u32 POS, FLUSHAT
     s_cbranch_scc1 .Lflush_stub_lit\sfx
 .Lflush_back_lit\sfx:
-    REFILL_CHECK \rid
     s_sub_u32 INS, INS, 1
     s_cbranch_scc0 .Llit\sfx
     s_branch .Lafter_lits
@@ -1013,7 +1003,7 @@
     LIT_RUN_SETUP .Lflush_stub_lit_r
 .Llit_r:
     v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
-    LOOKUP2X
+    LOOKUP2X 9
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
     v_and_b32 VT0, RMASK, VPA
@@ -1024,9 +1014,6 @@
     s_and_b32 T1, T1, MA2
     s_or_b32 T4, T1, T5                                 // context id of the next one
     s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
-    s_cmp_lt_u32 SNAV, 32
-    s_cbranch_scc1 .Lrf_stub_9
-.Lrf_back_9:
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit_r
     s_cmp_lg_u32 INS, 0                                 // (a whole-insert run leaves nothing to check)
@@ -1052,7 +1039,7 @@
 .Llit1_run:
     LIT_RUN_SETUP .Lflush_stub_lit1
 .Llit1:
-    LOOKUP2F VLITL, VLITB, 1, ds_read_u16
+    LOOKUP2F VLITL, VLITB, 1, ds_read_u16, 7
     v_and_b32 VT0, RMASK, VPA
     v_add_u32 VPA, 1, VPA
     s_waitcnt lgkmcnt(0)
@@ -1060,9 +1047,6 @@
     s_nop 1
     v_mov_b32 VE, T0
     ds_write_b8 VT0, VE
-    s_cmp_lt_u32 SNAV, 32
-    s_cbranch_scc1 .Lrf_stub_7
-.Lrf_back_7:
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit1
     s_cmp_lg_u32 INS, 0
@@ -1539,6 +1523,7 @@
     s_add_u32 T0, CBASE, WL
     s_lshl_b32 T0, T0, 5
     s_sub_u32 T0, T0, SNAV
+    s_sub_u32 T0, T0, 32                                // (SNAV = valid bits - 32)
     v_mov_b32 VT0, T0
     v_mov_b32 VT1, 0
     ds_write_b32 VZERO, VT0 offset:LDS_ST+12            // bitpos (st[3], st[4])
