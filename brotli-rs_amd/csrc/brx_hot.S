@@ -784,8 +784,13 @@
     s_cmp_lt_i32 DCODE, 0
     s_cbranch_scc1 .Ldist_ring
     s_and_b32 T1, DCODE, 31
+#ifdef BRX_WIN_SGPR
     s_lshr_b32 T2, DCODE, 5
     TAKE_EXTRA DIST, T2, T1, 6, NPOST                      // base + (extra << NPOSTFIX)
+#else
+    v_lshrrev_b32 VT0, 5, DCODE                         // (the base stays on the vector side)
+    TAKE_EXTRA DIST, VT0, T1, 6, NPOST                     // base + (extra << NPOSTFIX)
+#endif
 .Ldist_push:
     PROF_MARK s30                                       // distance symbol
     s_cmp_gt_u32 DIST, MAXA                             // MAXA: min(POS, WINDOW) as of its last exact evaluation (a lower bound)
@@ -930,9 +935,7 @@
     s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
     s_bitcmp1_b32 FLAGS, 3
     s_cbranch_scc1 .Lhave_lits1
-    s_call_b64 LINKB, .Lland_ctx                        // pending bytes into the ring, context of the first literal
-    s_add_u32 T0, POS, SKEW
-    v_mov_b32 VPA, T0                                   // ring address of the next literal (masked when used)
+    s_call_b64 LINKB, .Lland_ctx                        // pending bytes into the ring, context of the first literal, VPA
     s_bitcmp1_b32 FLAGS, 5
     s_cbranch_scc1 .Llit_r_start
     s_sub_u32 INS, INS, 1                               // the loop counts down to the borrow
@@ -1177,13 +1180,12 @@
     LAND_BODY
 .Lland_ctx_ring:
     s_add_u32 T6, POS, SKEW
-    s_sub_u32 T7, T6, 1
-    s_and_b32 T7, T7, RMASK
-    v_mov_b32 VT0, T7
+    v_mov_b32 VPA, T6                                   // ring address of the next literal (masked when used)
+    v_add_u32 VT0, -1, VPA                              // (address arithmetic on the vector side: the scalar ALU is the
+    v_add_u32 VT1, -2, VPA                              // unit all 16 waves of a CU share)
+    v_and_b32 VT0, RMASK, VT0
+    v_and_b32 VT1, RMASK, VT1
     ds_read_u8 VT0, VT0
-    s_sub_u32 T7, T6, 2
-    s_and_b32 T7, T7, RMASK
-    v_mov_b32 VT1, T7
     ds_read_u8 VT1, VT1
     s_waitcnt lgkmcnt(0)
 .Lland_ctx_have:
@@ -1201,6 +1203,8 @@
 // start of the stream: the bytes before it count as 0 (src/lib.rs:389, 407); a copy is at least 2 bytes long, so nothing
 // can be pending with fewer than 2 bytes of output
 .Lland_ctx_start:
+    s_add_u32 T6, POS, SKEW
+    v_mov_b32 VPA, T6
     v_mov_b32 VT0, 0
     v_mov_b32 VT1, 0
     s_cmp_eq_u32 POS, 0
