@@ -331,7 +331,7 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 }
 
 // Streams per CU up to which a launch counts as sparse (profiles/r02_loop_build_sweep.txt).
-#define BRX_SW_WAVES_PER_CU 8u
+#define BRX_SW_WAVES_PER_CU 6u
 
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,

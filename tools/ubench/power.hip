@@ -1,5 +1,8 @@
-// power.hip -- what the loaded clock of gfx950 does with the instruction mix: every CU runs 16 waves (one 1024-thread
-// workgroup holding most of the LDS) of the same pattern for ~20 ms; clock = s_memtime ticks / wall time.
+// power.hip -- which units the 16 waves of a gfx950 CU share: one 1024-thread workgroup per CU (holding most of the LDS,
+// so exactly 16 waves per CU) runs the same instruction pattern for ~10-30 ms; reported: pattern instructions retired
+// per CU per cycle at 2.4 GHz (wall time of the kernel), on one CU and on all of them (the same: nothing chip-wide is
+// involved, and the clock does not move).  The oldest wave is served first, so a cycle counter inside ONE wave
+// (s_memtime) sees no contention at all -- the trap the first reading of this kernel's counters fell into.
 // Build: hipcc --offload-arch=gfx950 -O2 power.hip -o power
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -56,43 +59,44 @@ int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     int cus = p.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#define RUN(K, IT, WHAT) for (int g : {1, cus}) { float ms = 0; u64 h[2]; for (int r = 0; r < 2; r++) { hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(g), dim3(1024), 0, 0, o, IT, (u32 *)o); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, o, 16, hipMemcpyDeviceToHost); } \
-      printf("%-40s %3d CU(s) x 16 waves: %7.2f ms, %6.3f GHz by s_memtime\n", WHAT, g, ms, h[0] / (ms * 1e6)); }
+#define RUNN(K, IT, N, WHAT) for (int g : {1, cus}) { float ms = 0; u64 h[2]; for (int r = 0; r < 2; r++) { hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(g), dim3(1024), 0, 0, o, IT, (u32 *)o); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, o, 16, hipMemcpyDeviceToHost); } \
+      printf("%-44s %3d CU(s) x 16 waves: %7.2f ms = %5.2f instructions per CU per cycle (%d per pattern)\n", WHAT, g, ms, (double)(IT) * 64.0 * (N) * 16.0 / (ms * 2.4e6), N); }
+#define RUN(K, IT, WHAT) RUNN(K, IT, 1, WHAT)
     RUN(k_s, 60000, "s_add chain");
     RUN(k_s64, 60000, "s_lshr_b64 chain");
     RUN(k_v64, 60000, "v_add, 64 lanes");
-    RUN(k_v17, 30000, "s_mov exec + v_add, 17 lanes");
-    RUN(k_v1, 30000, "s_mov exec + v_add, 1 lane");
+    RUNN(k_v17, 30000, 2, "s_mov exec + v_add, 17 lanes");
+    RUNN(k_v1, 30000, 2, "s_mov exec + v_add, 1 lane");
     RUN(k_vb64, 60000, "v_lshrrev_b64, 64 lanes");
     RUN(k_nop, 60000, "s_nop 0");
-    RUN(k_br, 30000, "s_cmp + s_cbranch not taken");
+    RUNN(k_br, 30000, 2, "s_cmp + s_cbranch not taken");
     RUN(k_rl, 60000, "v_readlane");
-    RUN(k_lds16, 6000, "ds_read_u16 16 lanes + wait");
-    RUN(k_lds1, 6000, "ds_read_u16 1 lane + wait");
+    RUNN(k_lds16, 6000, 2, "ds_read_u16 16 lanes + wait");
+    RUNN(k_lds1, 6000, 2, "ds_read_u16 1 lane + wait");
     RUN(k_sleep, 10000, "s_sleep 1");
-    printf("-- mixes (time only matters: 16 waves on one CU; s_add alone = the scalar unit's 1 per cycle)\n");
-    RUN(k_s_rl, 30000, "s_add + v_readlane");
+    printf("-- mixes (s_add alone = the scalar ALU's 1 per cycle; s_waitcnt counts as an instruction of the pattern)\n");
+    RUNN(k_s_rl, 30000, 2, "s_add + v_readlane");
     RUN(k_rfl, 60000, "v_readfirstlane");
-    RUN(k_s_wl, 30000, "s_add + v_writelane");
-    RUN(k_s_brn, 30000, "s_add + s_cbranch not taken");
-    RUN(k_nop_brn, 30000, "s_nop + s_cbranch not taken");
-    RUN(k_s_brt, 30000, "s_add + s_cbranch taken (+ skipped nop)");
-    RUN(k_s_v, 30000, "s_add + v_add");
-    RUN(k_s_vv, 20000, "s_add + 2 v_add");
-    RUN(k_s_vs, 30000, "s_add + v_add with an SGPR operand");
-    RUN(k_s_vcmp, 30000, "s_add + v_cmp");
+    RUNN(k_s_wl, 30000, 2, "s_add + v_writelane");
+    RUNN(k_s_brn, 30000, 2, "s_add + s_cbranch not taken");
+    RUNN(k_nop_brn, 30000, 2, "s_nop + s_cbranch not taken");
+    RUNN(k_s_brt, 30000, 2, "s_add + s_cbranch taken (+ skipped nop)");
+    RUNN(k_s_v, 30000, 2, "s_add + v_add");
+    RUNN(k_s_vv, 20000, 3, "s_add + 2 v_add");
+    RUNN(k_s_vs, 30000, 2, "s_add + v_add with an SGPR operand");
+    RUNN(k_s_vcmp, 30000, 2, "s_add + v_cmp");
     RUN(k_vcmp, 60000, "v_cmp");
-    RUN(k_vcmp_br, 30000, "v_cmp + s_cbranch_vccnz not taken");
-    RUN(k_s_wait, 30000, "s_add + s_waitcnt");
-    RUN(k_s_smem, 10000, "s_add + s_load_dword + wait");
-    RUN(k_s_lds, 30000, "s_add + ds_read_u16 (no wait)");
-    RUN(k_s_vb64, 30000, "s_add + v_lshrrev_b64");
+    RUNN(k_vcmp_br, 30000, 2, "v_cmp + s_cbranch_vccnz not taken");
+    RUNN(k_s_wait, 30000, 2, "s_add + s_waitcnt");
+    RUNN(k_s_smem, 10000, 2, "s_add + s_load_dword + wait");
+    RUNN(k_s_lds, 30000, 2, "s_add + ds_read_u16 (no wait)");
+    RUNN(k_s_vb64, 30000, 2, "s_add + v_lshrrev_b64");
     printf("-- LDS instruction shapes (6000 x 64 each, no waits in between; v2 = 4 * lane, v4 = uniform 2)\n");
-    RUN(k_ldsw64, 6000, "ds_write_b8 one address, 64 lanes");
-    RUN(k_ldsw17, 6000, "ds_write_b8 one address, 17 lanes");
-    RUN(k_ldsw1, 6000, "ds_write_b8 one address, 1 lane");
-    RUN(k_ldsr17s, 6000, "ds_read_u8 one address, 17 lanes");
-    RUN(k_ldsr17d, 6000, "ds_read_u16 distinct dwords, 17 lanes");
-    RUN(k_ldsr17b64, 6000, "ds_read_b64 stride 4 B, 17 lanes");
+    RUNN(k_ldsw64, 6000, 2, "ds_write_b8 one address, 64 lanes");
+    RUNN(k_ldsw17, 6000, 2, "ds_write_b8 one address, 17 lanes");
+    RUNN(k_ldsw1, 6000, 2, "ds_write_b8 one address, 1 lane");
+    RUNN(k_ldsr17s, 6000, 2, "ds_read_u8 one address, 17 lanes");
+    RUNN(k_ldsr17d, 6000, 2, "ds_read_u16 distinct dwords, 17 lanes");
+    RUNN(k_ldsr17b64, 6000, 2, "ds_read_b64 stride 4 B, 17 lanes");
     return 0;
 }
