@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["brx_kernels.hip", "brx_api.cpp"]
-DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "..", "include", "brx.h"),
+DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "build.py")]
 
@@ -65,6 +65,11 @@ def _build_locked(verbose):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(tmp, LIB_PATH)
+    # host program above the C ABI: the reference's file walker (src/main.rs:49-70) on the batched decoder
+    walk = os.path.join(PKG, "brx_walk")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(PKG, "host", "brx_walk.cpp"), "-o", walk + ".tmp", "-L", PKG,
+                           "-lbrx", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    os.replace(walk + ".tmp", walk)
     return LIB_PATH
 
 

@@ -54,6 +54,21 @@ def test_no_cpu_fallback_without_gpu():
         brx.Decompressor(open(os.path.join(ROOT, "tests", "golden", "data", "64x.compressed"), "rb")).read()
 
 
+def test_file_walker_is_built_and_has_no_cpu_path():
+    """brx_walk (the reference's file walker on the batched decoder) is built with the library; without a GPU it stops at
+    brx_ctx_create and says so."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "brotli-rs_amd", "brx_walk")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "data")], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr, r.stderr
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing under brotli-rs_amd/ may import, include or link it."""
     pkg = os.path.join(ROOT, "brotli-rs_amd")
@@ -72,6 +87,8 @@ def test_assembly_loop_passes_the_wait_state_lint():
     assembler inserts no wait states into hand-written code)."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 finding(s)" in r.stdout
+    for defs in ("", "BRX_WIN_SGPR"):  # both builds of the loop
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py")], capture_output=True, text=True,
+                           env=dict(os.environ, ASM_DEFS=defs))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "0 finding(s)" in r.stdout

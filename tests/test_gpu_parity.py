@@ -195,6 +195,45 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_file_walker(ctx, tmp_path):
+    """brx_walk (brotli-rs_amd/host/brx_walk.cpp): the reference's file walker (src/main.rs:49-70) over the reference's own
+    data directory -- every *compressed file into one pinned buffer, one batch, outputs compared with the expected files
+    next to them; then a directory of streams whose outputs exceed the first capacity guess (the size-discovery retry)
+    and one corrupt stream (reported like the reference reports an Err, the others unaffected)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "brotli-rs_amd", "brx_walk")
+    d = os.path.join(GOLDEN, "data")
+    r = subprocess.run([exe, d, "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    n_files = sum(1 for f in os.listdir(d) if f.endswith("compressed"))
+    summary = r.stdout.strip().splitlines()[-1]
+    assert summary.startswith("%d files, " % n_files) and " 0 differ" in summary, summary
+    assert "\"%s\":\noutput length = 152089\nres = Ok(152089)\ncheck = identical" % os.path.join(d, "alice29.txt.compressed") in r.stdout
+    assert r.stdout.count("res = Err(") == int(summary.split(" errors")[0].split()[-1])
+    # outputs far larger than 8 x the input (fills), a corrupt stream, a file that is not a stream at all
+    w = tmp_path / "walk"
+    w.mkdir()
+    out = tmp_path / "out"
+    out.mkdir()
+    for name in ("backward65536", "quickfox_repeated", "zeros", "alice29.txt"):
+        if os.path.exists(os.path.join(d, name + ".compressed")):
+            (w / (name + ".compressed")).write_bytes(_read(name + ".compressed"))
+            (w / name).write_bytes(_read(name))
+    bad = bytearray(_read("alice29.txt.compressed"))
+    bad[len(bad) // 2] ^= 0x10
+    (w / "broken.compressed").write_bytes(bytes(bad))
+    (w / "notes.txt").write_bytes(b"not a stream, not named like one")
+    r = subprocess.run([exe, str(w), "--check", "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    summary = r.stdout.strip().splitlines()[-1]
+    assert " 0 differ" in summary and "batch call(s)" in summary and " 1 batch call(s)" not in summary, summary
+    want = oracle.decode(bytes(bad))
+    assert ("res = Err(\"%s\")  [status %d]" % (brx.status_str(want[0]), want[0])) in r.stdout if want[0] else True
+    assert (out / "alice29.txt.compressed.out").read_bytes() == _read("alice29.txt")
+    assert (out / "backward65536.compressed.out").read_bytes() == _read("backward65536")
+
+
 def test_encoder_streams_batch(ctx):
     """95 libbrotlienc streams (tests/golden/enc: qualities 0-11, WBITS 10-24, NPOSTFIX/NDIRECT != 0, forced
     meta-block flushes, 1-symbol trees, uncompressed meta-blocks) as one batch, bit-exact against the manifest."""
@@ -354,6 +393,19 @@ def test_cpp_only_command_loops(stop):
     import subprocess
     import sys
     env = dict(os.environ, BRX_DEBUG_STOP=stop)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("build", ["0", "1"])
+def test_both_builds_of_the_command_loop(build):
+    """The assembly loop exists in two builds (bit window in VGPRs for full CUs, in SGPRs for sparse launches; the library
+    picks one per launch by occupancy).  BRX_LOOP_BUILD forces one for every launch of a context: the parity subset
+    (reference fixtures, encoder fixtures, a config-5 stream, all hand-assembled streams) through each, fresh process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BRX_LOOP_BUILD=build)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
