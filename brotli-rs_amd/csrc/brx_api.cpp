@@ -87,7 +87,7 @@ struct brx_ctx {
     bool any_launch = false;
     // options read once from the environment (bring-up switches)
     uint32_t debug_stop = 0;
-    bool debug_stats = false, debug_stats_all = false, no_order = false;
+    bool debug_stats = false, debug_stats_all = false, no_order = false, no_mirror = false;
     int loop_build = -1; // -1 = by occupancy (launch()); bring-up: BRX_LOOP_BUILD forces 0 / 1
     uint32_t dump_interval = 0, dump_max = 0; // BRX_DEBUG_DUMP=interval:max:path (with BRX_DEBUG_STOP=9)
     std::string dump_path;
@@ -179,6 +179,7 @@ static int ctx_init(brx_ctx *c, int device) {
         c->debug_stats = getenv("BRX_DEBUG_STATS") != nullptr;
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
         c->no_order = getenv("BRX_NO_ORDER") != nullptr;
+        c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
         if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
         if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
             unsigned iv = 0, mx = 0;
@@ -335,8 +336,10 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
-                  const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr) {
+                  const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr,
+                  uint8_t *d_out_mirror = nullptr) {
     BrxKernelArgs a;
+    a.out_mirror = d_out_mirror;
     a.order = d_order;
     a.in = d_in;
     a.in_off = d_in_off;
@@ -464,6 +467,28 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
             });
     }
     if ((rc = ensure_pool(c, n < c->max_grid ? n : c->max_grid))) return rc; // once, for all the chunks' launches together
+    // Output buffer in pinned, mapped host memory (brx_host_alloc, hipHostMalloc, hipHostRegister) at the 16-byte phase of
+    // the staging slots: the kernel stores every output byte to it as well (BrxKernelArgs::out_mirror) and there is no
+    // device-to-host copy of the data afterwards -- it rode on the decode.  The HBM copy stays: it is the window.
+    // device-visible address of a host range that is pinned and mapped as ONE piece, else nullptr
+    auto mapped = [](const uint8_t *p, size_t bytes) -> uint8_t * {
+        hipPointerAttribute_t at;
+        void *dp = nullptr, *dp_end = nullptr;
+        uint8_t *r = nullptr;
+        if (bytes && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, (void *)p, 0) == hipSuccess && dp &&
+            hipHostGetDevicePointer(&dp_end, (void *)(p + bytes - 1), 0) == hipSuccess && (uint8_t *)dp_end == (uint8_t *)dp + bytes - 1)
+            r = (uint8_t *)dp;
+        (void)hipGetLastError(); // (a pageable pointer makes the queries fail: not an error of this call)
+        return r;
+    };
+    uint8_t *mirror = nullptr;
+    if (!c->no_mirror && (((uintptr_t)(out + out_lo)) & 15u) == 0) mirror = mapped(out + out_lo, out_bytes);
+    // Compressed input in pinned, mapped host memory: the kernel reads it in place.  A wave stages 256 bytes of input one
+    // chunk ahead of its cursor and needs the next one ~40 us later (25 bits per command, ~0.5 us per command): the PCIe
+    // round trip hides behind that, 205 MB per 11 ms is a third of the link, and the batch starts decoding at once
+    // instead of after its own copy.
+    const uint8_t *in_dev = c->no_mirror ? nullptr : mapped(in + in_lo, in_bytes);
     hipStream_t s0 = c->s_chunk[0];
     HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
     HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, s0));
@@ -475,9 +500,9 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
         hipStream_t sk = c->s_chunk[k];
         if (k) HIP_TRY(hipStreamWaitEvent(sk, c->ev_in[0], 0));
         const uint64_t i0 = in_off[a] - in_lo, i1 = in_off[b] - in_lo;
-        if (i1 > i0) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, sk));
-        rc = launch(c, sk, timing && nchunks == 1, c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a, d_out_len + a,
-                    d_status + a, d_order + a);
+        if (i1 > i0 && !in_dev) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, sk));
+        rc = launch(c, sk, timing && nchunks == 1, in_dev ? in_dev : c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a, d_out_len + a,
+                    d_status + a, d_order + a, nullptr, nullptr, mirror);
         if (rc) return rc;
     }
     for (unsigned k = 0; k < nchunks; k++) { // copy out (a second loop: a pageable copy blocks the host until it is done)
@@ -485,7 +510,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
         if (a == b) continue;
         hipStream_t sk = c->s_chunk[k];
         const uint64_t o0 = out_off[a] - out_lo, o1 = out_off[b] - out_lo;
-        if (o1 > o0) HIP_TRY(hipMemcpyAsync(out + out_lo + o0, c->st_out + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost, sk));
+        if (o1 > o0 && !mirror) HIP_TRY(hipMemcpyAsync(out + out_lo + o0, c->st_out + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost, sk));
         HIP_TRY(hipMemcpyAsync(out_len + a, d_out_len + a, (size_t)(b - a) * 8, hipMemcpyDeviceToHost, sk));
         HIP_TRY(hipMemcpyAsync(status + a, d_status + a, (size_t)(b - a) * 4, hipMemcpyDeviceToHost, sk));
     }

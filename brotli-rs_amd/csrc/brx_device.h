@@ -68,6 +68,8 @@ struct BrxKernelArgs {
                             // BRX_DUMP_WORDS words: {stream id, command index, 14 spare, the wave's whole LDS}
     uint32_t dump_interval, dump_max;
     BrxResume *resume;      // nullptr, or one record per stream: resumable mode (see BrxResume)
+    uint8_t *out_mirror;    // nullptr, or the device-visible address of pinned host memory laid out like `out`: output bytes are
+                            // stored to both (the D2H copy fused into the decode)
     uint32_t loop_build;    // which build of the assembly loop: 0 = bit window in VGPRs (full CUs), 1 = in SGPRs (sparse launch)
     BrxDeviceTables t;
 };

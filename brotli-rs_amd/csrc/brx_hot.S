@@ -71,6 +71,7 @@
 #define CBASE s46
 #define DIST s47
 #define RSRC s[48:51]
+#define RSRC2 s[16:19]           // the host-visible mirror of the output slot (Dec::mirror), or a resource without records
 #define POS s52
 #define SKEW s53
 #define VFL s54
@@ -453,6 +454,17 @@
     ds_read_b64 v[28:29], VZERO offset:LDS_ST+144       // insert&copy / dictionary info table
     s_and_b32 s49, s49, 0xffff
     s_mov_b32 s51, 0x00020000
+#ifndef BRX_PROF
+    ds_read_b64 v[30:31], VZERO offset:LDS_ST+160       // st[40], st[41]: mirror of the output slot in host memory, or 0
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 s16, v30
+    v_readfirstlane_b32 s17, v31
+    s_and_b32 s17, s17, 0xffff
+    s_or_b32 s18, s16, s17
+    s_cmp_lg_u32 s18, 0
+    s_cselect_b32 s18, s50, 0                           // no mirror: no records, every store to it is dropped
+    s_mov_b32 s19, 0x00020000
+#endif
     s_sub_u32 WENDM1, T0, 1
     s_lshr_b32 WSAFE, T2, 5
     s_sub_u32 WSAFE, WSAFE, 8
@@ -1155,6 +1167,9 @@
     v_add_u32 VT4, T7, VLANE16
     s_waitcnt lgkmcnt(0)
     buffer_store_dwordx4 VQ, VT4, RSRC, 0 offen
+#ifndef BRX_PROF
+    buffer_store_dwordx4 VQ, VT4, RSRC2, 0 offen        // (the device-to-host copy rides on the decode)
+#endif
     s_add_u32 VFL, VFL, 1024
     s_add_u32 FLUSHAT, FLUSHAT, 1024
     s_cmp_ge_u32 POS, FLUSHAT

@@ -113,6 +113,8 @@ struct Dec {
     __amdgpu_buffer_rsrc_t out_rsrc; // same, as a buffer resource: far back-references are buffer_load_ubyte
                                      // (a plain pointer load next to the LDS ring read gets merged into ONE flat
                                      // load by LLVM, and that trips a backend bug in non-kernel functions)
+    u8 *mirror;          // nullptr, or the same slot in host-visible (pinned, mapped) memory: every store of output
+    __amdgpu_buffer_rsrc_t out2_rsrc; // bytes goes there too (the D2H copy fused into the decode); null resource = dropped
     u32 cap;             // capacity (clamped to < 2^32-64)
     u32 pos;             // bytes produced (reference: Decompressor.count_output)
     u32 a;               // (uintptr_t)out & 15: ring/global 16-B alignment skew
@@ -287,6 +289,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_MLEN 35    // its MLEN
 #define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
 #define ST_POOL 38    // (2 words) const BrxSlabPool *
+#define ST_MIRROR 40  // (2 words) host-visible mirror of the output slot, or 0
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
 // generic_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
@@ -320,6 +323,7 @@ FI void dec_store(const Dec &d, Lds &s) {
         put64(s, 23, (u64)(uintptr_t)d.t_dict); put64(s, 25, (u64)(uintptr_t)d.t_xforms);
         put64(s, 27, (u64)(uintptr_t)d.t_lut); put64(s, 29, d.wd); put64(s, 31, d.wd_limit);
         put64(s, ST_POOL, (u64)(uintptr_t)d.pool);
+        put64(s, ST_MIRROR, (u64)(uintptr_t)d.mirror);
     }
 }
 FI void dec_load(Dec &d, const Lds &s) {
@@ -328,6 +332,8 @@ FI void dec_load(Dec &d, const Lds &s) {
     d.bitend = get64(s, 5);
     d.out = (u8 *)(uintptr_t)get64(s, 7); d.cap = rfl(s.st[9]);
     d.out_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.cap, 0x00020000); // range-checked against the capacity
+    d.mirror = (u8 *)(uintptr_t)get64(s, ST_MIRROR);
+    d.out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.mirror, 0, d.mirror ? d.cap : 0u, 0x00020000);
     d.pos = rfl(s.st[10]); d.a = rfl(s.st[11]);
     d.vfl = rfl(s.st[12]); d.window = rfl(s.st[13]);
     d.dist0 = rfl(s.st[14]); d.dist1 = rfl(s.st[15]); d.dist2 = rfl(s.st[16]); d.dist3 = rfl(s.st[17]);
@@ -683,6 +689,14 @@ FI void ring_put(const Dec &d, Lds &s, bool on, u32 vpos, u32 byte) {
     u8 *p = on ? &s.ring[vpos & RMASK] : &s.trash[d.lane];
     *p = (u8)byte;
 }
+// ---- output stores: to the stream's slot in HBM (which is also its sliding window) and, when the caller's output buffer is
+// pinned host memory, to the same offset of that buffer (BrxKernelArgs::out_mirror): the device-to-host copy rides on
+// the decode as 1 KiB posted writes instead of following it.  Without a mirror the second resource has no records and the
+// store is dropped by the range check -- no branch.
+#define OUT_STORE128(q, off) do { const u32 off_ = (off); __builtin_amdgcn_raw_buffer_store_b128((q), d.out_rsrc, off_, 0, 0); \
+                                  __builtin_amdgcn_raw_buffer_store_b128((q), d.out2_rsrc, off_, 0, 0); } while (0)
+#define OUT_STORE8(b, off) do { const u32 off_ = (off); __builtin_amdgcn_raw_buffer_store_b8((u8)(b), d.out_rsrc, off_, 0, 0); \
+                                __builtin_amdgcn_raw_buffer_store_b8((u8)(b), d.out2_rsrc, off_, 0, 0); } while (0)
 // Flush skewed range [v0, v1) of the ring to HBM: full 16-B units as one 16-B store per lane, ragged head and
 // tail (first / last block of a stream only) as byte stores.  v1 - v0 <= BRX_FLUSH_BLOCK + 15.
 FI void flush_range(Dec &d, const Lds &s, u32 v0, u32 v1) {
@@ -692,18 +706,18 @@ FI void flush_range(Dec &d, const Lds &s, u32 v0, u32 v1) {
         typedef u32 u32x4 __attribute__((ext_vector_type(4)));
         u32x4 q = *(const u32x4 *)&s.ring[(u * 16u) & RMASK];
         u32 off = u < u1 ? u * 16u - d.a : 0xffffffffu;
-        __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0);
+        OUT_STORE128(q, off);
     }
     if (v0 & 15u) { // ragged head: bytes [v0, min(u0*16, v1))
         u32 e = u0 * 16u < v1 ? u0 * 16u : v1;
         u32 v = v0 + d.lane;
         u32 b = s.ring[v & RMASK];
-        __builtin_amdgcn_raw_buffer_store_b8((u8)b, d.out_rsrc, v < e ? v - d.a : 0xffffffffu, 0, 0);
+        OUT_STORE8(b, v < e ? v - d.a : 0xffffffffu);
     }
     if ((v1 & 15u) && u1 * 16u >= v0 && u1 >= u0) { // ragged tail: bytes [u1*16, v1)
         u32 v = u1 * 16u + d.lane;
         u32 b = s.ring[v & RMASK];
-        __builtin_amdgcn_raw_buffer_store_b8((u8)b, d.out_rsrc, v < v1 ? v - d.a : 0xffffffffu, 0, 0);
+        OUT_STORE8(b, v < v1 ? v - d.a : 0xffffffffu);
     }
     d.vfl = v1;
 }
@@ -788,7 +802,7 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
     const u32 step = 1024u % P;
     for (u32 k = 0; k < nblocks; k++) {
         const u32x4 q = *(const u32x4 *)&s.ring[(base + o) & RMASK];
-        __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, d.pos + 16u * d.lane, 0, 0);
+        OUT_STORE128(q, d.pos + 16u * d.lane);
         d.pos += 1024u;
         o += step;
         o = o >= P ? o - P : o;
@@ -816,10 +830,10 @@ FI void direct_far_copy(Dec &d, Lds &s, u32 de, u32 nblocks) {
         const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 1024u, 0, 0);
         const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 2048u, 0, 0);
         const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, src + 3072u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(q0, d.out_rsrc, dst, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(q1, d.out_rsrc, dst + 1024u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(q2, d.out_rsrc, dst + 2048u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(q3, d.out_rsrc, dst + 3072u, 0, 0);
+        OUT_STORE128(q0, dst);
+        OUT_STORE128(q1, dst + 1024u);
+        OUT_STORE128(q2, dst + 2048u);
+        OUT_STORE128(q3, dst + 3072u);
         d.pos += 4096u;
     }
     d.vfl = d.pos + d.a;
@@ -1626,6 +1640,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             d.bitend = 8ull * (mis + in_len);
             d.bitpos = 8ull * mis;
             d.out = a.out + o0;
+            d.mirror = a.out_mirror != nullptr ? a.out_mirror + o0 : nullptr;
             const u64 capacity = o1 >= o0 ? o1 - o0 : 0ull;
             d.cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
             d.pos = 0;

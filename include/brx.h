@@ -133,11 +133,16 @@ double brx_last_timing(brx_ctx *ctx, int which);
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
 int brx_synchronize(brx_ctx *ctx, void *hip_stream);
 
-/* Pinned (page-locked) host memory for the host-pointer path.  brx_decode_batch with host pointers cuts the batch
- * into chunks and pipelines input copy / decode / output copy on three HIP streams; with buffers from
- * brx_host_alloc (or hipHostMalloc / hipHostRegister) the copies are asynchronous DMA and overlap the kernels, with
- * pageable memory the HIP runtime stages them and the overlap is partial.  (Ingest shape of the reference's file
- * walker, src/main.rs:49-70: read files straight into such a buffer, decode, write out.) */
+/* Pinned (page-locked, device-mapped) host memory for the host-pointer path.  With buffers from brx_host_alloc (or
+ * hipHostMalloc / hipHostRegister with the mapped flag) brx_decode_batch makes no copies around the kernel: the kernel
+ * reads the compressed bytes in place (a wave stages its input 256 bytes ahead of its cursor, the PCIe round trip hides
+ * behind ~40 us of decoding) and stores every output byte to the host buffer itself while it decodes, next to the copy
+ * in HBM that serves as the stream's window -- the device-to-host transfer rides on the decode as 1 KiB writes.  The
+ * output pointer must sit at the 16-byte phase of its offsets (out + out_off[0] 16-byte aligned), else -- and with
+ * pageable memory -- the batch is staged: input copy, decode, output copy, in chunks on their own HIP streams from the
+ * second grid-full of streams on.  With the output stored in place only the stream's bytes are written; a staged copy
+ * brings a slot's slack along.  (Ingest shape of the reference's file walker, src/main.rs:49-70: read files straight
+ * into such a buffer, decode, write out -- brotli-rs_amd/host/brx_walk.cpp.) */
 void *brx_host_alloc(size_t bytes);
 void brx_host_free(void *p);
 

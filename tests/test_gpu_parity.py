@@ -542,6 +542,51 @@ def test_host_pipeline_with_pinned_buffers(ctx):
         brx.host_free(pin_out)
 
 
+def test_pinned_buffers_are_used_in_place(ctx):
+    """With pinned, mapped host buffers the kernel reads the compressed bytes in place and stores every output byte to the
+    host buffer itself while it decodes (BrxKernelArgs::out_mirror: no copies around the kernel).  A ragged batch of every
+    kind of stream -- fills, far copies, dictionary words, raw meta-blocks, empty streams, invalid streams (their prefix
+    must be on the host too) -- in slots at every 16-byte phase, against the same batch through pageable buffers; and an
+    output pointer off the 16-byte phase of the staging slots (falls back to the copy)."""
+    from brotli_rs_amd import brx
+    import craft
+    names = ["alice29.txt", "backward65536", "quickfox_repeated", "monkey", "empty", "x", "compressed_repeated",
+             "metablock_reset", "zeros", "quickfox"]
+    streams = [_read(nm + ".compressed") for nm in names] * 3
+    streams += [craft.farcopy_stream(3, 8192, 1 << 16)[0], bytes.fromhex("a103")]
+    bad = bytearray(_read("alice29.txt.compressed"))
+    bad[30000] ^= 0x40
+    streams.append(bytes(bad))
+    want = [oracle.decode(s, 0, cap=1 << 20) for s in streams]
+    caps = [len(w[1]) + 1 + (7 * i) % 23 for i, w in enumerate(want)]
+    n = len(streams)
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    in_off[1:] = np.cumsum([len(s) for s in streams])
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    out_off[1:] = np.cumsum(caps)
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    for shift in (0, 16, 8):  # 8: the host buffer sits at another 16-byte phase than the device slots -> copied back instead
+        pin_in = brx.host_alloc(len(blob) + 16)
+        pin_out = brx.host_alloc(int(out_off[-1]) + 64)
+        try:
+            pin_in[:len(blob)] = blob
+            pin_out[:] = 0xEE
+            status, out_len = ctx.decode_batch_host_raw(pin_in.ctypes.data, in_off, n, pin_out.ctypes.data + shift, out_off)
+            for i, w in enumerate(want):
+                assert int(status[i]) == w[0], (shift, i, int(status[i]), w[0])
+                o0 = shift + int(out_off[i])
+                if w[0] == 0:
+                    assert int(out_len[i]) == len(w[1]) and pin_out[o0:o0 + len(w[1])].tobytes() == w[1], (shift, i)
+                    if shift != 8:  # stored in place: nothing but the stream's bytes was written (a copied-back slot brings its slack along)
+                        assert (pin_out[o0 + len(w[1]):shift + int(out_off[i + 1])] == 0xEE).all(), (shift, i)
+                else:  # whatever prefix the decoder reports is what the oracle produced up to there
+                    k = int(out_len[i])
+                    assert pin_out[o0:o0 + k].tobytes() == w[1][:k], (shift, i)
+        finally:
+            brx.host_free(pin_in)
+            brx.host_free(pin_out)
+
+
 def test_bounded_memory_stream_of_70_MiB(ctx):
     """The Read facade in bounded mode: a 70 MiB stream (4.4 MiB compressed: chosen automatically,
     inputs >= 4 MiB) decoded slice by slice by the resumable kernel into a ~21 MiB sliding device window; the reader sees

@@ -762,6 +762,7 @@ def lds_u32(lds, off):
 def run_one(insts, index, rec, comp, expect, cmds, tables, args):
     """Emulate the loop from one dumped state; returns a dict of results / raises EmuError."""
     lds = rec["lds"]
+    lds[ST + 160:ST + 168] = 0  # st[40..41], the host mirror of the output slot: none here (dumps older than it hold noise)
     st = lambda k: lds_u32(lds, ST + 4 * k)
     mbw = lambda k: lds_u32(lds, MBW + 4 * k)
     in_words = st(0) | (st(1) << 32)

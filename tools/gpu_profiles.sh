@@ -12,27 +12,8 @@ for wl in $WLS; do
   timeout 600 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${TAG}_${wl}.json
 done
 echo "== sweep"; NS="1 256 1024 2048 4096 4352 8192 16384" bash tools/gpu_sweep.sh 2>/dev/null | tee $O/${TAG}_sweep.txt
-echo "== host path, pinned buffers (PCIe-inclusive)"
-timeout 300 python - <<'PY' 2>/dev/null | tee $O/${TAG}_pcie.txt
-import sys, time, numpy as np
-sys.path.insert(0, '.')
-from brotli_rs_amd import brx
-comp = open('tests/golden/data/alice29.txt.compressed','rb').read(); exp = open('tests/golden/data/alice29.txt','rb').read()
-n = 4096; cap = (len(exp) + 15) & ~15
-ctx = brx.Context(0)
-for kind in ('pinned', 'pageable'):
-    if kind == 'pinned':
-        a, b = brx.host_alloc(len(comp) * n), brx.host_alloc(cap * n)
-    else:
-        a, b = np.zeros(len(comp) * n, dtype=np.uint8), np.zeros(cap * n, dtype=np.uint8)
-    a[:] = np.frombuffer(comp * n, dtype=np.uint8)
-    io = np.arange(n + 1, dtype=np.uint64) * len(comp); oo = np.arange(n + 1, dtype=np.uint64) * cap
-    best = 1e9
-    for r in range(5):
-        t0 = time.perf_counter(); st, ln = ctx.decode_batch_host_raw(a.ctypes.data, io, n, b.ctypes.data, oo); best = min(best, time.perf_counter() - t0)
-    assert not st.any() and b[:len(exp)].tobytes() == exp
-    print("%s host buffers: 4096 x alice29, H2D + decode + D2H: %.2f ms wall, %.1f GB/s decompressed (PCIe-inclusive)" % (kind, best * 1e3, n * len(exp) / best / 1e9))
-PY
+echo "== host path (PCIe-inclusive)"
+( python tools/gpu_pcie.py 2>/dev/null; BRX_NO_MIRROR=1 python tools/gpu_pcie.py 2>/dev/null | head -1 ) | tee $O/${TAG}_pcie.txt
 cd /tmp && export TMPDIR=/tmp
 for wl in $WLS; do
   rm -rf /tmp/kt
