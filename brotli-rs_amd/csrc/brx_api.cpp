@@ -426,8 +426,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
     const size_t in_bytes = (size_t)(in_hi - in_lo), out_bytes = (size_t)(out_hi - out_lo);
     if ((in_bytes && !in) || (out_bytes && !out)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_decode_batch: NULL data");
     int rc;
-    if ((rc = grow(&c->st_in, &c->st_in_cap, in_bytes + 16))) return rc;
-    if ((rc = grow(&c->st_out, &c->st_out_cap, out_bytes + 16))) return rc;
+    if ((rc = grow(&c->st_out, &c->st_out_cap, out_bytes + 16))) return rc; // (always: the HBM slot is the stream's window)
     const size_t meta_words = 3 * (size_t)(n + 1);
     const size_t meta_bytes = meta_words * 8 + (size_t)n * 4 + (size_t)n * 4;
     if ((rc = grow((uint8_t **)&c->st_meta, &c->st_meta_cap, meta_bytes))) return rc;
@@ -489,6 +488,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
     // round trip hides behind that, 205 MB per 11 ms is a third of the link, and the batch starts decoding at once
     // instead of after its own copy.
     const uint8_t *in_dev = c->no_mirror ? nullptr : mapped(in + in_lo, in_bytes);
+    if (!in_dev && (rc = grow(&c->st_in, &c->st_in_cap, in_bytes + 16))) return rc;
     hipStream_t s0 = c->s_chunk[0];
     HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
     HIP_TRY(hipMemcpyAsync(d_in_off, hmeta.data(), hmeta.size() * 8, hipMemcpyHostToDevice, s0));
