@@ -337,6 +337,26 @@ def main():
             res["roofline"]["achieved_physical"] = round(traffic / (kavg * 1e-3) / 1e9, 1)
             res["roofline"]["frac_physical"] = round(traffic / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             res["roofline"]["physical_model"] = "PMC traffic (FETCH_SIZE + WRITE_SIZE)"
+        if cb and world == 1 and K == 1:
+            # informational, never part of `value`: the same batch from pinned HOST buffers to pinned host buffers through the
+            # C ABI's host-pointer path (the kernel reads the input and stores the output over PCIe while it decodes)
+            try:
+                hin, hout = brx.host_alloc(len(comp) * n), brx.host_alloc(cap * n)
+                hin[:] = np.frombuffer(comp * n, dtype=np.uint8)
+                io = np.arange(n + 1, dtype=np.uint64) * len(comp)
+                oo = np.arange(n + 1, dtype=np.uint64) * cap
+                best = 1e9
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    hst, hln = ctx.decode_batch_host_raw(hin.ctypes.data, io, n, hout.ctypes.data, oo)
+                    best = min(best, time.perf_counter() - t1)
+                okh = (not hst.any()) and hout[:len(expect)].tobytes() == expect and hout[(n - 1) * cap:(n - 1) * cap + len(expect)].tobytes() == expect
+                res["host_path_pcie_inclusive"] = {"ms": round(best * 1e3, 3), "MB_per_s": round(n * len(expect) / best / 1e6, 1),
+                                                   "bit_exact": bool(okh), "buffers": "pinned (brx_host_alloc), used in place"}
+                brx.host_free(hin)
+                brx.host_free(hout)
+            except Exception as e:
+                res["host_path_pcie_inclusive"] = {"error": repr(e)[:200]}
         if cb:
             res["config1"] = config1_monkey()
             res["cpu_baseline"] = cb
