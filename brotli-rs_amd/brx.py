@@ -56,6 +56,10 @@ def load_library():
     L.brx_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.POINTER(_Opts)]
+    L.brx_generate_batch.restype = ctypes.c_int
+    L.brx_generate_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                     ctypes.POINTER(_Opts)]
     L.brx_status_str.restype = ctypes.c_char_p
     L.brx_status_str.argtypes = [ctypes.c_int32]
     L.brx_last_error.restype = ctypes.c_char_p
@@ -81,7 +85,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
-                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded"]
+                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch"]
 
 
 def status_str(code: int) -> str:
@@ -150,6 +154,42 @@ class Context:
         if rc != 0:
             raise BrxError("brx_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
         return status[:n], out_len[:n]
+
+    # ---- stream generator (brx_generate_batch): inputs -> valid Brotli streams, made on the GPU ----------
+    @staticmethod
+    def generate_slot_bytes(n_bytes, metablock_bytes=65536):
+        """A slot size that always suffices for an input of n_bytes (brx.h)."""
+        return n_bytes + n_bytes // 8 + 256 * (n_bytes // metablock_bytes + 2)
+
+    def generate_batch(self, sources, metablock_bytes=65536):
+        """list of bytes -> list of Brotli streams (host buffers; the work happens on the device)."""
+        n = len(sources)
+        if n == 0:
+            return []
+        src_off = np.zeros(n + 1, dtype=np.uint64)
+        src_off[1:] = np.cumsum([len(x) for x in sources], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        out_off[1:] = np.cumsum([self.generate_slot_bytes(len(x), metablock_bytes) for x in sources], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(sources) or b"\0", dtype=np.uint8)
+        out = np.zeros(int(out_off[-1]), dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.uint64)
+        status = np.full(n, -1, dtype=np.int32)
+        opts = _Opts(MEM_HOST, 0, None)
+        rc = self._lib.brx_generate_batch(self._h, blob.ctypes.data, src_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
+                                          out_len.ctypes.data, status.ctypes.data, metablock_bytes, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_generate_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        assert not status.any(), status
+        return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
+
+    def generate_batch_device(self, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr, metablock_bytes=65536,
+                              hip_stream=None):
+        """Raw device pointers (e.g. torch tensors): nothing leaves the GPU."""
+        opts = _Opts(MEM_DEVICE, 0, hip_stream)
+        rc = self._lib.brx_generate_batch(self._h, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
+                                          metablock_bytes, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_generate_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
 
     # ---- device-memory batch (pointers are raw device addresses, e.g. torch tensor .data_ptr()) ------
     def decode_batch_device(self, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,

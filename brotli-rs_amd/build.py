@@ -9,10 +9,10 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_api.cpp"]
+SOURCES = ["brx_kernels.hip", "brx_gen.hip", "brx_api.cpp"]
 DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
-                  os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "build.py")]
+                  os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
 
 
 def _stale():

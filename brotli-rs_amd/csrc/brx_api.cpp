@@ -93,6 +93,8 @@ struct brx_ctx {
     std::string dump_path;
     // host-mode device staging (grown on demand)
     uint8_t *st_in = nullptr, *st_out = nullptr;
+    uint8_t *d_gen_header = nullptr, *st_gen = nullptr; // stream generator: the constant meta-block bits, hash tables + staging
+    size_t st_gen_cap = 0;
     uint64_t *st_meta = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_meta_cap = 0;
     // Read facade: streams created but not yet decoded (decoded together by the first read of any of them)
@@ -154,6 +156,8 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->st_in);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
+    (void)hipFree(c->d_gen_header);
+    (void)hipFree(c->st_gen);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_in)
@@ -578,6 +582,68 @@ extern "C" int brx_synchronize(brx_ctx *c, void *hip_stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t)hip_stream : c->stream));
     return BRX_SUCCESS;
+}
+
+// ---- stream generator (brx_gen.hip): n inputs -> n valid Brotli streams, made on the device ------------------------------
+void brx_launch_generate(const void *src, const uint64_t *src_off, uint32_t n, void *out, const uint64_t *out_off,
+                         uint64_t *out_len, int32_t *status, const void *header, uint32_t header_bits, uint32_t mb_bytes,
+                         uint32_t *hash, void *hip_stream);
+
+extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
+                                  const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
+                                  const brx_opts *opts) {
+    BRX_GUARD_BEGIN
+    if (!c) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: ctx is NULL");
+    if (n == 0) return BRX_SUCCESS;
+    if (!src_off || !out_off || !out_len || !status) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: NULL table");
+    if (metablock_bytes == 0) metablock_bytes = 65536;
+    if (metablock_bytes > (1u << 24)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: a meta-block holds at most 2^24 bytes");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t header_bits = (uint32_t)BRX_GEN_HEADER[0] | ((uint32_t)BRX_GEN_HEADER[1] << 8) | ((uint32_t)BRX_GEN_HEADER[2] << 16) |
+                                 ((uint32_t)BRX_GEN_HEADER[3] << 24);
+    if (!c->d_gen_header) {
+        HIP_TRY(hipMalloc(&c->d_gen_header, sizeof BRX_GEN_HEADER));
+        HIP_TRY(hipMemcpy(c->d_gen_header, BRX_GEN_HEADER, sizeof BRX_GEN_HEADER, hipMemcpyHostToDevice));
+    }
+    const uint32_t flags = opts ? opts->flags : 0u;
+    const size_t hash_bytes = (size_t)n * 2048u * 4u;
+    hipStream_t st = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
+    if (flags & BRX_MEM_DEVICE) {
+        int rc = grow(&c->st_gen, &c->st_gen_cap, hash_bytes);
+        if (rc) return rc;
+        brx_launch_generate(src, src_off, n, out, out_off, out_len, status, c->d_gen_header + 4, header_bits, metablock_bytes,
+                            (uint32_t *)c->st_gen, st);
+        HIP_TRY(hipGetLastError());
+        if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
+        return BRX_SUCCESS;
+    }
+    // host pointers: stage in, generate, stage out
+    for (uint32_t i = 0; i < n; i++)
+        if (src_off[i + 1] < src_off[i] || out_off[i + 1] < out_off[i])
+            return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: offsets must be non-decreasing");
+    const uint64_t s_lo = src_off[0], o_lo = out_off[0];
+    const size_t s_bytes = (size_t)(src_off[n] - s_lo), o_bytes = (size_t)(out_off[n] - o_lo), tab = ((size_t)n + 1) * 8;
+    if ((s_bytes && !src) || (o_bytes && !out)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: NULL data");
+    const size_t a_src = (hash_bytes + 255) & ~(size_t)255, a_out = (a_src + s_bytes + 255) & ~(size_t)255,
+                 a_tab = (a_out + o_bytes + 255) & ~(size_t)255, total = a_tab + 3 * tab + (size_t)n * 4 + 64;
+    int rc = grow(&c->st_gen, &c->st_gen_cap, total);
+    if (rc) return rc;
+    std::vector<uint64_t> h(2 * ((size_t)n + 1));
+    for (uint32_t i = 0; i <= n; i++) { h[i] = src_off[i] - s_lo; h[(size_t)n + 1 + i] = out_off[i] - o_lo; }
+    uint64_t *d_soff = (uint64_t *)(c->st_gen + a_tab), *d_ooff = d_soff + (n + 1), *d_len = d_ooff + (n + 1);
+    int32_t *d_st = (int32_t *)(d_len + (n + 1));
+    if (s_bytes) HIP_TRY(hipMemcpyAsync(c->st_gen + a_src, src + s_lo, s_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_soff, h.data(), 2 * tab, hipMemcpyHostToDevice, st));
+    brx_launch_generate(c->st_gen + a_src, d_soff, n, c->st_gen + a_out, d_ooff, d_len, d_st, c->d_gen_header + 4, header_bits,
+                        metablock_bytes, (uint32_t *)c->st_gen, st);
+    HIP_TRY(hipGetLastError());
+    if (o_bytes) HIP_TRY(hipMemcpyAsync(out + o_lo, c->st_gen + a_out, o_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return BRX_SUCCESS;
+    BRX_GUARD_END(BRX_ERR_OUT_OF_MEMORY, BRX_ERR_HIP)
 }
 
 extern "C" void *brx_host_alloc(size_t bytes) {

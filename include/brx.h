@@ -146,6 +146,23 @@ int brx_synchronize(brx_ctx *ctx, void *hip_stream);
 void *brx_host_alloc(size_t bytes);
 void brx_host_free(void *p);
 
+/* ---- Stream generator (the reference has no encoder, README.md:1) -------------------------------
+ * Makes n valid Brotli streams ON THE DEVICE from n inputs: a minimal encoder, one GPU thread per stream -- greedy LZ77
+ * over a 2048-entry hash table, the input cut into meta-blocks of `metablock_bytes` (0 = 65536, at most 2^24), every
+ * meta-block with one block type per category and three static complete prefix codes sent in complex form (literals
+ * 8 bits, insert&copy symbols 9/10 bits, distances 6 bits + extra; csrc/brx_gen.hip).  For batches of real, compressible
+ * streams of any size without committed fixtures and for differential fuzzing: every stream it makes decodes back to its
+ * input with brx_decode_batch and with any conforming decoder.
+ *   src / src_off   n inputs, concatenated (input i is src[src_off[i] .. src_off[i+1]), may be empty)
+ *   out / out_off   n output slots; a slot of  len + len / 8 + 256 * (len / metablock_bytes + 2)  bytes always suffices
+ *   out_len         n  compressed sizes
+ *   status          n  0, or 25 when the slot was too small (out_len then says how much was needed)
+ * Pointers are host memory (staged) or, with BRX_MEM_DEVICE in opts->flags, device memory (opts->hip_stream as for
+ * brx_decode_batch).  Returns BRX_SUCCESS or a BRX_ERR_* code. */
+int brx_generate_batch(brx_ctx *ctx, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
+                       const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
+                       const brx_opts *opts);
+
 /* ---- Read-shaped stream facade (one object = one stream, like one reference Decompressor) ----------
  * brx_stream_new copies the compressed bytes and queues the stream on its context.  The first brx_stream_read of
  * ANY queued stream decodes ALL streams queued on that context in one batch (N live Decompressors cost about one

@@ -195,6 +195,74 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_stream_generator_round_trip(ctx):
+    """brx_generate_batch (csrc/brx_gen.hip): streams made on the GPU -- text, random bytes, fills, far repeats, empty and
+    1-byte inputs, inputs around the meta-block size -- decode back to their inputs with the CPU oracle (both lookup modes
+    agree by construction of the suite) AND with the HIP decoder; text must actually shrink (the LZ77 parse works);
+    several meta-block sizes; the device-pointer form; a slot that is too small reports status 25 and the size needed."""
+    import torch
+    rng = random.Random(77)
+    alice = _read("alice29.txt")
+    sources = [alice, alice[:70000], alice[1000:1004], b"", b"x", b"ab" * 40000, bytes(70001), rng.randbytes(5000),
+               rng.randbytes(65536), alice[:65536], alice[:65537], alice[:65535], (alice[:3000] + rng.randbytes(200)) * 40,
+               _read("asyoulik.txt"), rng.randbytes(3) * 30000, bytes(range(256)) * 300]
+    for mb in (65536, 4096, 1 << 20, 1000):
+        streams = ctx.generate_batch(sources, metablock_bytes=mb)
+        for i, (src, s) in enumerate(zip(sources, streams)):
+            st, out = oracle.decode(s, 0, cap=len(src) + 64)
+            assert st == 0 and out == src, (mb, i, st, len(src), len(s))
+        outs, status, out_len = ctx.decode_batch(streams, [len(x) + (i % 13) for i, x in enumerate(sources)])
+        assert not status.any(), (mb, status)
+        assert all(o == x for o, x in zip(outs, sources)), mb
+        if mb >= 65536:
+            assert len(streams[0]) < 0.70 * len(alice), (mb, len(streams[0]))   # LZ77 alone on text  # (every meta-block carries its 104-byte code description)
+            assert len(streams[5]) < 2000 and len(streams[6]) < 2000             # fills collapse
+        assert len(streams[7]) <= ctx.generate_slot_bytes(5000, mb)              # random bytes: bounded expansion
+    # device pointers: 512 slices of text -> streams -> decoded, nothing leaves the GPU in between
+    n, piece = 512, 20000
+    srcs = [alice[(37 * k) % (len(alice) - piece):][:piece] for k in range(n)]
+    dev = torch.device("cuda", 0)
+    blob = torch.frombuffer(bytearray(b"".join(srcs)), dtype=torch.uint8).to(dev)
+    src_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * piece).contiguous()
+    slot = ctx.generate_slot_bytes(piece)
+    comp = torch.zeros(n * slot, dtype=torch.uint8, device=dev)
+    comp_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * slot).contiguous()
+    comp_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    gst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.generate_batch_device(blob.data_ptr(), src_off.data_ptr(), n, comp.data_ptr(), comp_off.data_ptr(), comp_len.data_ptr(),
+                              gst.data_ptr())
+    assert not gst.any().item()
+    # the slots have slack; the decoder wants stream i as in[in_off[i] .. in_off[i+1]): compact on the device (shard.compact)
+    from brotli_rs_amd import shard
+    comp, comp_off = shard.compact(comp, comp_off, comp_len)
+    cap = (piece + 15) & ~15
+    out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap).contiguous()
+    out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    dst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.decode_batch_device(comp.data_ptr(), comp_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(),
+                            dst.data_ptr())
+    ctx.synchronize()
+    assert not dst.any().item() and (out_len == piece).all().item()
+    got = out.cpu().numpy().reshape(n, cap)[:, :piece]
+    want = np.frombuffer(b"".join(srcs), dtype=np.uint8).reshape(n, piece)
+    assert (got == want).all()
+    assert float(comp_len.sum().item()) < 0.85 * n * piece
+    # too small a slot
+    L = ctx._lib
+    import ctypes as ct
+    from brotli_rs_amd import brx
+    src = np.frombuffer(rng.randbytes(4000), dtype=np.uint8)
+    so, oo = np.array([0, 4000], dtype=np.uint64), np.array([0, 1000], dtype=np.uint64)
+    ob, ol, stt = np.zeros(1000, dtype=np.uint8), np.zeros(1, dtype=np.uint64), np.full(1, -1, dtype=np.int32)
+    opts = brx._Opts(brx.MEM_HOST, 0, None)
+    rc = L.brx_generate_batch(ctx._h, src.ctypes.data, so.ctypes.data, 1, ob.ctypes.data, oo.ctypes.data, ol.ctypes.data,
+                              stt.ctypes.data, 65536, ct.byref(opts))
+    assert rc == 0 and int(stt[0]) == 25 and 4000 <= int(ol[0]) <= ctx.generate_slot_bytes(4000)
+
+
 def test_file_walker(ctx, tmp_path):
     """brx_walk (brotli-rs_amd/host/brx_walk.cpp): the reference's file walker (src/main.rs:49-70) over the reference's own
     data directory -- every *compressed file into one pinned buffer, one batch, outputs compared with the expected files
