@@ -16,6 +16,7 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 OPT_TIMING = 2
 OPT_ORDER = 4
+GEN_SWITCHES = 8
 
 OK = 0
 OUTPUT_TOO_SMALL = 25
@@ -161,8 +162,9 @@ class Context:
         """A slot size that always suffices for an input of n_bytes (brx.h)."""
         return n_bytes + n_bytes // 8 + 256 * (n_bytes // metablock_bytes + 2)
 
-    def generate_batch(self, sources, metablock_bytes=65536):
-        """list of bytes -> list of Brotli streams (host buffers; the work happens on the device)."""
+    def generate_batch(self, sources, metablock_bytes=65536, switches=False):
+        """list of bytes -> list of Brotli streams (host buffers; the work happens on the device).  switches: two literal
+        block types taking turns every 100 literals (BRX_GEN_SWITCHES)."""
         n = len(sources)
         if n == 0:
             return []
@@ -174,7 +176,7 @@ class Context:
         out = np.zeros(int(out_off[-1]), dtype=np.uint8)
         out_len = np.zeros(n, dtype=np.uint64)
         status = np.full(n, -1, dtype=np.int32)
-        opts = _Opts(MEM_HOST, 0, None)
+        opts = _Opts(MEM_HOST | (GEN_SWITCHES if switches else 0), 0, None)
         rc = self._lib.brx_generate_batch(self._h, blob.ctypes.data, src_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
                                           out_len.ctypes.data, status.ctypes.data, metablock_bytes, ctypes.byref(opts))
         if rc != 0:
@@ -183,9 +185,9 @@ class Context:
         return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
 
     def generate_batch_device(self, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr, metablock_bytes=65536,
-                              hip_stream=None):
+                              hip_stream=None, switches=False):
         """Raw device pointers (e.g. torch tensors): nothing leaves the GPU."""
-        opts = _Opts(MEM_DEVICE, 0, hip_stream)
+        opts = _Opts(MEM_DEVICE | (GEN_SWITCHES if switches else 0), 0, hip_stream)
         rc = self._lib.brx_generate_batch(self._h, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
                                           metablock_bytes, ctypes.byref(opts))
         if rc != 0:

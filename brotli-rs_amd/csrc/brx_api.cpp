@@ -587,7 +587,7 @@ extern "C" int brx_synchronize(brx_ctx *c, void *hip_stream) {
 // ---- stream generator (brx_gen.hip): n inputs -> n valid Brotli streams, made on the device ------------------------------
 void brx_launch_generate(const void *src, const uint64_t *src_off, uint32_t n, void *out, const uint64_t *out_off,
                          uint64_t *out_len, int32_t *status, const void *header, uint32_t header_bits, uint32_t mb_bytes,
-                         uint32_t *hash, void *hip_stream);
+                         uint32_t switches, uint32_t *hash, void *hip_stream);
 
 extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
                                   const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
@@ -600,20 +600,25 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     if (metablock_bytes > (1u << 24)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_generate_batch: a meta-block holds at most 2^24 bytes");
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t header_bits = (uint32_t)BRX_GEN_HEADER[0] | ((uint32_t)BRX_GEN_HEADER[1] << 8) | ((uint32_t)BRX_GEN_HEADER[2] << 16) |
-                                 ((uint32_t)BRX_GEN_HEADER[3] << 24);
+    const uint32_t flags = opts ? opts->flags : 0u;
+    // tables/gen_header.bin: record A (one literal block type), record B (two, switching): u32 bits + bits padded to 4 bytes
+    auto rd32 = [](const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    const uint32_t bits_a = rd32(BRX_GEN_HEADER);
+    const size_t rec_b = 4 + (((size_t)bits_a + 7) / 8 + 3) / 4 * 4;
+    const uint32_t switches = (flags & BRX_GEN_SWITCHES) ? 1u : 0u;
+    const uint32_t header_bits = switches ? rd32(BRX_GEN_HEADER + rec_b) : bits_a;
+    const size_t header_at = (switches ? rec_b : 0) + 4;
     if (!c->d_gen_header) {
         HIP_TRY(hipMalloc(&c->d_gen_header, sizeof BRX_GEN_HEADER));
         HIP_TRY(hipMemcpy(c->d_gen_header, BRX_GEN_HEADER, sizeof BRX_GEN_HEADER, hipMemcpyHostToDevice));
     }
-    const uint32_t flags = opts ? opts->flags : 0u;
     const size_t hash_bytes = (size_t)n * 2048u * 4u;
     hipStream_t st = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
     if (flags & BRX_MEM_DEVICE) {
         int rc = grow(&c->st_gen, &c->st_gen_cap, hash_bytes);
         if (rc) return rc;
-        brx_launch_generate(src, src_off, n, out, out_off, out_len, status, c->d_gen_header + 4, header_bits, metablock_bytes,
-                            (uint32_t *)c->st_gen, st);
+        brx_launch_generate(src, src_off, n, out, out_off, out_len, status, c->d_gen_header + header_at, header_bits, metablock_bytes,
+                            switches, (uint32_t *)c->st_gen, st);
         HIP_TRY(hipGetLastError());
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
         return BRX_SUCCESS;
@@ -635,8 +640,8 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     int32_t *d_st = (int32_t *)(d_len + (n + 1));
     if (s_bytes) HIP_TRY(hipMemcpyAsync(c->st_gen + a_src, src + s_lo, s_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_soff, h.data(), 2 * tab, hipMemcpyHostToDevice, st));
-    brx_launch_generate(c->st_gen + a_src, d_soff, n, c->st_gen + a_out, d_ooff, d_len, d_st, c->d_gen_header + 4, header_bits,
-                        metablock_bytes, (uint32_t *)c->st_gen, st);
+    brx_launch_generate(c->st_gen + a_src, d_soff, n, c->st_gen + a_out, d_ooff, d_len, d_st, c->d_gen_header + header_at, header_bits,
+                        metablock_bytes, switches, (uint32_t *)c->st_gen, st);
     HIP_TRY(hipGetLastError());
     if (o_bytes) HIP_TRY(hipMemcpyAsync(out + o_lo, c->st_gen + a_out, o_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost, st));

@@ -7,7 +7,8 @@
 // compressed with ONE block type per category, NPOSTFIX = NDIRECT = 0, one literal and one distance tree, and three
 // STATIC complete prefix codes transmitted in complex form (the constant 829 bits of tables/gen_header.bin,
 // tools/make_gen_header.py): literals 8 bits each, insert&copy symbols 9 bits (symbols 0..319) or 10 bits, distance
-// symbols 6 bits.  Commands come from a greedy LZ77 parse: a hash table of the last position of every 4-byte sequence
+// symbols 6 bits; optionally (BRX_GEN_SWITCHES) two literal block types that take turns every 100 literals -- the block-switch
+// commands of the format with one-symbol type and count codes, 4 bits per switch.  Commands come from a greedy LZ77 parse: a hash table of the last position of every 4-byte sequence
 // (2048 entries per stream), the match extended as far as it goes (<= 16 384 bytes, inside the meta-block), everything
 // between matches as the literals of the next command; explicit distances only (no ring codes, no dictionary).
 // So the compression is LZ77's alone (alice29: 65 % of the input), the entropy codes are flat -- enough to exercise every part of a
@@ -61,13 +62,18 @@ __device__ u32 code_of(const u32 *base, u32 v) {  // the largest code whose base
 
 // one command: `ins` literals starting at src[lit], then a copy of `cpy` bytes from `dist` back (dist = 0: the last command
 // of a meta-block, whose copy is never executed -- RFC 7932 section 9.3: the meta-block ends with its literals)
-__device__ void put_command(Writer &w, const u8 *src, u64 lit, u32 ins, u32 cpy, u32 dist) {
+// (lit_left: with block switches on, literals left in the current literal block; a switch = the 4 extra bits of the next count)
+__device__ void put_command(Writer &w, const u8 *src, u64 lit, u32 ins, u32 cpy, u32 dist, u32 &lit_left) {
     const u32 ic = code_of(K_INS_BASE, ins), cc = code_of(K_CPY_BASE, cpy);
     const u32 sym = 64u * K_CELL[ic >> 3][cc >> 3] + 8u * (ic & 7u) + (cc & 7u);
     if (sym < 320u) w.put(rev_bits(sym, 9), 9); else w.put(rev_bits(640u + (sym - 320u), 10), 10);
     w.put(ins - K_INS_BASE[ic], K_INS_EXTRA[ic]);
     w.put(cpy - K_CPY_BASE[cc], K_CPY_EXTRA[cc]);
-    for (u32 k = 0; k < ins; k++) w.put(rev_bits(src[lit + k], 8), 8);
+    for (u32 k = 0; k < ins; k++) {
+        if (lit_left == 0u) { w.put(3, 4); lit_left = 100u; }  // block type +1 (no bits), block count 97 + 3 (4 extra bits)
+        lit_left--;                                            // (without block switches lit_left starts at 2^32 - 1)
+        w.put(rev_bits(src[lit + k], 8), 8);
+    }
     if (dist) {  // explicit distance, NPOSTFIX = NDIRECT = 0 (RFC 7932 section 4)
         const u32 v = dist - 1u + 4u;
         const u32 nb = 30u - (u32)__clz(v);  // = bit length - 2
@@ -90,6 +96,7 @@ struct BrxGenArgs {
     const u8 *header;   // the constant bits of a compressed meta-block (tables/gen_header.bin without its length word)
     u32 header_bits;
     u32 mb_bytes;       // input bytes per meta-block (1 .. 2^24)
+    u32 switches;       // 1: the header is variant B (two literal block types taking turns every 100 literals)
     u32 *hash;          // n x BRX_GEN_HASH entries
 };
 
@@ -124,6 +131,7 @@ __global__ void brx_generate_kernel(BrxGenArgs a) {
             const u32 k = a.header_bits - b < 8u ? a.header_bits - b : 8u;
             w.put(a.header[b >> 3] & ((1u << k) - 1u), k);
         }
+        u32 lit_left = a.switches ? 100u : 0xffffffffu;
         u64 p = pos, lit = pos;
         while (p < end) {
             u32 best = 0, dist = 0;
@@ -140,14 +148,14 @@ __global__ void brx_generate_kernel(BrxGenArgs a) {
                 }
             }
             if (best) {
-                put_command(w, src, lit, (u32)(p - lit), best, dist);
+                put_command(w, src, lit, (u32)(p - lit), best, dist, lit_left);
                 p += best;
                 lit = p;
             } else {
                 p++;
             }
         }
-        if (lit < end) put_command(w, src, lit, (u32)(end - lit), 2, 0);  // trailing literals: the copy is never reached
+        if (lit < end) put_command(w, src, lit, (u32)(end - lit), 2, 0, lit_left);  // trailing literals: the copy is never reached
         pos = end;
     }
     w.finish();
@@ -157,10 +165,10 @@ __global__ void brx_generate_kernel(BrxGenArgs a) {
 
 void brx_launch_generate(const void *src, const uint64_t *src_off, uint32_t n, void *out, const uint64_t *out_off,
                          uint64_t *out_len, int32_t *status, const void *header, uint32_t header_bits, uint32_t mb_bytes,
-                         uint32_t *hash, void *hip_stream) {
+                         uint32_t switches, uint32_t *hash, void *hip_stream) {
     BrxGenArgs a;
     a.src = (const u8 *)src; a.src_off = src_off; a.n = n; a.out = (u8 *)out; a.out_off = out_off; a.out_len = out_len;
-    a.status = status; a.header = (const u8 *)header; a.header_bits = header_bits; a.mb_bytes = mb_bytes; a.hash = hash;
+    a.status = status; a.header = (const u8 *)header; a.header_bits = header_bits; a.mb_bytes = mb_bytes; a.switches = switches; a.hash = hash;
     // divergent, serial work per thread: small blocks so that the streams spread over all CUs
     hipLaunchKernelGGL(brx_generate_kernel, dim3((n + 31u) / 32u), dim3(32), 0, (hipStream_t)hip_stream, a);
 }

@@ -72,6 +72,7 @@ enum {
 #define BRX_MEM_HOST 0u   /* every pointer argument is host memory; the library stages through HBM */
 #define BRX_MEM_DEVICE 1u /* every pointer argument (data, offset tables, out_len, status) is device memory */
 #define BRX_OPT_TIMING 2u /* record HIP-event timings of the kernels of this call (brx_last_timing) */
+#define BRX_GEN_SWITCHES 8u /* brx_generate_batch only: two literal block types taking turns every 100 literals */
 #define BRX_OPT_ORDER 4u  /* BRX_MEM_DEVICE only: queue the longest compressed streams first (a ragged batch finishes when
                              its longest stream does).  Costs one synchronous read of the offset table; the host-pointer
                              path always orders.  The work queue itself is dynamic: a wave that finishes a stream takes the
@@ -158,7 +159,8 @@ void brx_host_free(void *p);
  *   out_len         n  compressed sizes
  *   status          n  0, or 25 when the slot was too small (out_len then says how much was needed)
  * Pointers are host memory (staged) or, with BRX_MEM_DEVICE in opts->flags, device memory (opts->hip_stream as for
- * brx_decode_batch).  Returns BRX_SUCCESS or a BRX_ERR_* code. */
+ * brx_decode_batch).  BRX_GEN_SWITCHES in opts->flags: every meta-block declares two literal block types (sharing the
+ * one literal tree) and switches between them every 100 literals -- the block-switch commands of the format, 4 bits each.  Returns BRX_SUCCESS or a BRX_ERR_* code. */
 int brx_generate_batch(brx_ctx *ctx, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
                        const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
                        const brx_opts *opts);

@@ -199,15 +199,19 @@ def test_stream_generator_round_trip(ctx):
     """brx_generate_batch (csrc/brx_gen.hip): streams made on the GPU -- text, random bytes, fills, far repeats, empty and
     1-byte inputs, inputs around the meta-block size -- decode back to their inputs with the CPU oracle (both lookup modes
     agree by construction of the suite) AND with the HIP decoder; text must actually shrink (the LZ77 parse works);
-    several meta-block sizes; the device-pointer form; a slot that is too small reports status 25 and the size needed."""
+    several meta-block sizes, with and without literal block switches; the device-pointer form; a slot that is too small reports status 25 and the size needed."""
     import torch
     rng = random.Random(77)
     alice = _read("alice29.txt")
     sources = [alice, alice[:70000], alice[1000:1004], b"", b"x", b"ab" * 40000, bytes(70001), rng.randbytes(5000),
                rng.randbytes(65536), alice[:65536], alice[:65537], alice[:65535], (alice[:3000] + rng.randbytes(200)) * 40,
                _read("asyoulik.txt"), rng.randbytes(3) * 30000, bytes(range(256)) * 300]
-    for mb in (65536, 4096, 1 << 20, 1000):
-        streams = ctx.generate_batch(sources, metablock_bytes=mb)
+    for mb, sw in ((65536, False), (4096, False), (1 << 20, False), (1000, False), (65536, True), (300, True), (1 << 20, True)):
+        streams = ctx.generate_batch(sources, metablock_bytes=mb, switches=sw)
+        if sw:  # the block-switch commands are really there: the oracle counts them
+            stats = oracle.decode(streams[0], want_stats=True)[2]
+            assert stats["meta_blocks"] == -(-len(alice) // mb), stats
+            assert stats["block_switches"] > 300 or mb < 65536, stats  # (~37 k literals, a switch every 100)
         for i, (src, s) in enumerate(zip(sources, streams)):
             st, out = oracle.decode(s, 0, cap=len(src) + 64)
             assert st == 0 and out == src, (mb, i, st, len(src), len(s))
