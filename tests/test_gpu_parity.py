@@ -267,6 +267,52 @@ def test_stream_generator_round_trip(ctx):
     assert rc == 0 and int(stt[0]) == 25 and 4000 <= int(ol[0]) <= ctx.generate_slot_bytes(4000)
 
 
+def test_generated_streams_differential_fuzz(ctx):
+    """Fixture-free differential fuzz (what the generator is for): 384 streams made on the GPU from edited text, random and
+    periodic data (meta-block sizes 300 .. 65536, with and without literal block switches), then corrupted -- bit flips,
+    truncation, bytes appended -- and decoded by the HIP path and the oracle: status and bytes must agree."""
+    rng = random.Random(4242)
+    alice, lcet = _read("alice29.txt"), _read("lcet10.txt")
+    streams = []
+    for mb, sw in ((65536, False), (300, True), (4096, True), (20000, False)):
+        sources = []
+        for k in range(96):
+            kind = k % 4
+            if kind == 0:
+                base = rng.choice((alice, lcet))
+                o = rng.randrange(len(base) - 40000)
+                d = bytearray(base[o:o + rng.randrange(100, 40000)])
+                for _ in range(rng.randrange(0, 30)):
+                    d[rng.randrange(len(d))] = rng.randrange(256)
+            elif kind == 1:
+                d = rng.randbytes(rng.randrange(1, 6000))
+            elif kind == 2:
+                unit = rng.randbytes(rng.choice((1, 2, 7, 64, 300, 5000)))
+                d = (unit * (1 + 30000 // len(unit)))[:rng.randrange(1, 30000)]
+            else:
+                d = b"".join(rng.choice((alice, lcet))[o:o + 120] for o in (rng.randrange(100000) for _ in range(rng.randrange(1, 120))))
+            sources.append(bytes(d))
+        made = ctx.generate_batch(sources, metablock_bytes=mb, switches=sw)
+        for src, s in zip(sources, made):
+            m = bytearray(s)
+            r = rng.random()
+            if r < 0.5:
+                for _ in range(rng.randrange(1, 4)):
+                    pos = rng.randrange(len(m) * 8)
+                    m[pos >> 3] ^= 1 << (pos & 7)
+            elif r < 0.75:
+                m = m[:rng.randrange(1, len(m) + 1)]
+            elif r < 0.85:
+                m += rng.randbytes(rng.randrange(1, 9))
+            streams.append(bytes(m))
+    cap = 1 << 18
+    want = [oracle.decode(s, 0, cap=cap) for s in streams]
+    outs, status, out_len = ctx.decode_batch(streams, cap)
+    bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if w[0] != st or (st == 0 and o != w[1])]
+    assert not bad, bad[:8]
+    assert sum(1 for w in want if w[0] == 0) > 40 and sum(1 for w in want if w[0] != 0) > 100
+
+
 def test_file_walker(ctx, tmp_path):
     """brx_walk (brotli-rs_amd/host/brx_walk.cpp): the reference's file walker (src/main.rs:49-70) over the reference's own
     data directory -- every *compressed file into one pinned buffer, one batch, outputs compared with the expected files
