@@ -612,14 +612,18 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
         HIP_TRY(hipMalloc(&c->d_gen_header, sizeof BRX_GEN_HEADER));
         HIP_TRY(hipMemcpy(c->d_gen_header, BRX_GEN_HEADER, sizeof BRX_GEN_HEADER, hipMemcpyHostToDevice));
     }
-    const size_t hash_bytes = (size_t)n * 2048u * 4u;
+    const uint32_t per_launch = 32768;  // streams per launch: bounds the hash tables (8 KiB per stream) at 256 MiB
+    const size_t hash_bytes = (size_t)std::min(n, per_launch) * 2048u * 4u;
     hipStream_t st = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
     if (flags & BRX_MEM_DEVICE) {
         int rc = grow(&c->st_gen, &c->st_gen_cap, hash_bytes);
         if (rc) return rc;
-        brx_launch_generate(src, src_off, n, out, out_off, out_len, status, c->d_gen_header + header_at, header_bits, metablock_bytes,
-                            switches, (uint32_t *)c->st_gen, st);
-        HIP_TRY(hipGetLastError());
+        for (uint32_t k = 0; k < n; k += per_launch) { // (same stream: the launches run one after the other and share the tables)
+            const uint32_t m = std::min(per_launch, n - k);
+            brx_launch_generate(src, src_off + k, m, out, out_off + k, out_len + k, status + k, c->d_gen_header + header_at, header_bits,
+                                metablock_bytes, switches, (uint32_t *)c->st_gen, st);
+            HIP_TRY(hipGetLastError());
+        }
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
         return BRX_SUCCESS;
     }
@@ -640,9 +644,12 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     int32_t *d_st = (int32_t *)(d_len + (n + 1));
     if (s_bytes) HIP_TRY(hipMemcpyAsync(c->st_gen + a_src, src + s_lo, s_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_soff, h.data(), 2 * tab, hipMemcpyHostToDevice, st));
-    brx_launch_generate(c->st_gen + a_src, d_soff, n, c->st_gen + a_out, d_ooff, d_len, d_st, c->d_gen_header + header_at, header_bits,
-                        metablock_bytes, switches, (uint32_t *)c->st_gen, st);
-    HIP_TRY(hipGetLastError());
+    for (uint32_t k = 0; k < n; k += per_launch) {
+        const uint32_t m = std::min(per_launch, n - k);
+        brx_launch_generate(c->st_gen + a_src, d_soff + k, m, c->st_gen + a_out, d_ooff + k, d_len + k, d_st + k,
+                            c->d_gen_header + header_at, header_bits, metablock_bytes, switches, (uint32_t *)c->st_gen, st);
+        HIP_TRY(hipGetLastError());
+    }
     if (o_bytes) HIP_TRY(hipMemcpyAsync(out + o_lo, c->st_gen + a_out, o_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -254,6 +254,11 @@ def test_stream_generator_round_trip(ctx):
     want = np.frombuffer(b"".join(srcs), dtype=np.uint8).reshape(n, piece)
     assert (got == want).all()
     assert float(comp_len.sum().item()) < 0.85 * n * piece
+    # more streams than one launch takes (32768): 40 000 tiny inputs
+    tiny = [bytes([k & 255, (k >> 8) & 255]) * (1 + k % 7) for k in range(40000)]
+    made = ctx.generate_batch(tiny)
+    outs, status, out_len = ctx.decode_batch(made, 32)
+    assert not status.any() and all(o == t for o, t in zip(outs, tiny))
     # too small a slot
     L = ctx._lib
     import ctypes as ct
