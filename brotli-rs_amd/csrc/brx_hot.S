@@ -85,6 +85,7 @@
 #define LBLEN s65
 #define IBLEN s66
 #define DBLEN s67
+#define PRIOW s60                // wave slot in the SIMD
 #define RUN s68                 // literals left in the current run, one behind
 #define NXT s[58:59]            // the next dword of the staged input (lane WL of chunk A), zero-extended
 #define NXTLO s58
@@ -414,6 +415,14 @@
 #endif
 
 // ======================================================================================================== entry
+    // Where the loop sits relative to the 32-byte instruction fetch windows is worth 2 % (measured: all 8 dword offsets, both
+    // builds; profiles/r02_alignment.txt): pin it -- 256-byte alignment, then the offset that measured best.
+    .p2align 8
+    s_nop 0
+    s_nop 0
+    s_nop 0
+    s_nop 0
+    s_getreg_b32 PRIOW, hwreg(HW_REG_HW_ID, 0, 4)       // this wave's slot in its SIMD (phase of the priority rotation, .Lspecial)
     s_waitcnt vmcnt(0) lgkmcnt(0)
     v_mov_b32 VZERO, 0
     v_mbcnt_lo_u32_b32 VLANE, -1, 0
@@ -1257,6 +1266,30 @@
     s_mov_b64 exec, XLOOP
     s_mov_b32 WL, 0
     WIN_ROLLED
+    // Issue priority by turns.  The arbiter of a SIMD serves its oldest wave first, and with the CU's scalar ALU saturated
+    // (16 streams per CU) that starves the youngest waves: the oldest streams finish in 8.1 ms, the youngest in 11.0, and
+    // a launch takes as long as its slowest wave.  Every 256 bytes of input a wave takes the next of the four priority
+    // levels, offset by its slot in the SIMD, so that over a stream every wave spends the same time at every level.
+    s_lshr_b32 T0, CBASE, 6
+    s_add_u32 T0, T0, PRIOW
+    s_and_b32 T0, T0, 3
+    s_cmp_lt_u32 T0, 2
+    s_cbranch_scc1 .Lprio_01
+    s_cmp_eq_u32 T0, 2
+    s_cbranch_scc1 .Lprio_2
+    s_setprio 3
+    s_branch .Lprio_done
+.Lprio_2:
+    s_setprio 2
+    s_branch .Lprio_done
+.Lprio_01:
+    s_cmp_eq_u32 T0, 0
+    s_cbranch_scc1 .Lprio_0
+    s_setprio 1
+    s_branch .Lprio_done
+.Lprio_0:
+    s_setprio 0
+.Lprio_done:
     s_sub_u32 T0, WSAFE, CBASE
     s_cselect_b32 T0, 0, T0
     s_min_u32 WLSTOP, T0, 64

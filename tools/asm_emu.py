@@ -122,6 +122,7 @@ def decode_program(prog):
                 else:
                     i.mods[m] = True
             core = _MODS.sub("", " " + args).strip()
+            core = re.sub(r"hwreg\([^)]*\)", "0", core)  # (s_getreg_b32: the register id does not matter here)
             toks = [t for t in re.split(r",\s*(?![A-Z0-9,]*\))", core) if t] if core else []  # (not inside gpr_idx(...))
             i.ops = [parse_operand(t) for t in toks]
             if i.op.startswith(("s_branch", "s_cbranch")):
@@ -337,6 +338,10 @@ class Wave:
                 if len(self.lg_q) > w["lgkmcnt"]:
                     self.cycles += (LAT["lds"] - 12) if self.lg_issue_cycle is None else max(0, LAT["lds"] - (self.cycles - self.lg_issue_cycle))
                 self.complete(self.lg_q, w["lgkmcnt"])
+        elif op == "s_setprio":
+            pass  # issue priority: no architectural effect
+        elif op == "s_getreg_b32":
+            self.sset(ops[0][1], 0)  # (HW_ID: wave slot 0)
         elif op == "s_nop":
             self.cycles += ops[0][1]
         # ---- SALU
@@ -952,7 +957,7 @@ def main():
              tot["bits"] / max(1, tot["commands"]), tot["cycles"] / max(1, tot["commands"])))
     cls = {"SALU": 0, "VALU": 0, "LDS": 0, "VMEM": 0, "SMEM": 0, "branch/wait": 0}
     for k, v in counts.items():
-        if k.startswith(("s_branch", "s_cbranch", "s_call", "s_setpc", "s_waitcnt", "s_nop")):
+        if k.startswith(("s_branch", "s_cbranch", "s_call", "s_setpc", "s_waitcnt", "s_nop", "s_setprio")):
             cls["branch/wait"] += v
         elif k.startswith("s_load"):
             cls["SMEM"] += v

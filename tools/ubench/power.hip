@@ -19,6 +19,8 @@ typedef unsigned int u32;
                      : "=s"(t0), "=s"(t1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) \
                      : "s"(buf) : "vcc", "scc", "memory", "s90", "s91", "s92", "s93", "v10", "v11");                         \
         if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = v0 + v1 + v2 + v3 + s0 + s1 + s2 + lds[5]; } \
+        if (threadIdx.x == 960 && blockIdx.x == 0) { out[2] = t1 - t0; out[3] = t1; }  /* the youngest wave of the workgroup */ \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[4] = t1; \
     }
 KERNEL(k_s, "s_add_u32 %6, %6, 1")
 KERNEL(k_s64, "s_lshr_b64 s[92:93], s[92:93], 1")
@@ -59,8 +61,8 @@ int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     int cus = p.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#define RUNN(K, IT, N, WHAT) for (int g : {1, cus}) { float ms = 0; u64 h[2]; for (int r = 0; r < 2; r++) { hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(g), dim3(1024), 0, 0, o, IT, (u32 *)o); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, o, 16, hipMemcpyDeviceToHost); } \
-      printf("%-44s %3d CU(s) x 16 waves: %7.2f ms = %5.2f instructions per CU per cycle (%d per pattern)\n", WHAT, g, ms, (double)(IT) * 64.0 * (N) * 16.0 / (ms * 2.4e6), N); }
+#define RUNN(K, IT, N, WHAT) for (int g : {1, cus}) { float ms = 0; u64 h[5]; for (int r = 0; r < 2; r++) { hipEventRecord(e0); hipLaunchKernelGGL(K, dim3(g), dim3(1024), 0, 0, o, IT, (u32 *)o); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h, o, 40, hipMemcpyDeviceToHost); } \
+      printf("%-44s %3d CU(s) x 16 waves: %7.2f ms = %5.2f instructions per CU per cycle (%d per pattern); s_memtime ticks in the oldest / youngest wave %.2f / %.2f M\n", WHAT, g, ms, (double)(IT) * 64.0 * (N) * 16.0 / (ms * 2.4e6), N, h[0] / 1e6, h[2] / 1e6); }
 #define RUN(K, IT, WHAT) RUNN(K, IT, 1, WHAT)
     RUN(k_s, 60000, "s_add chain");
     RUN(k_s64, 60000, "s_lshr_b64 chain");
