@@ -949,6 +949,18 @@
     s_branch .Lrf_back_\id
 .endm
 
+.macro LIT_RUN_FAST_STUB id, general_id
+.Lrf_stub_\id:
+    REFILL_CORE
+    s_cbranch_scc1 .Lrf_back_\id
+    s_mov_b32 INS, RUN
+    s_add_u32 LBLEN, LBLEN, RUN
+    s_sub_u32 POS, POS, RUN
+    s_mov_b32 RUN, 0
+    s_call_b64 LINKA, .Lspecial
+    s_branch .Lrf_back_\general_id
+.endm
+
 // ---- literals (reference parse_insert_literals :1286-1365)
 .Lhave_lits:
     s_sub_u32 MBLEFT, MBEND, POS
@@ -1015,19 +1027,16 @@
 // resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway), tree pair through the
 // VGPR index mode
 .Llit_r_start:
-    v_readfirstlane_b32 T4, VC                          // context id * 4 of the first literal
-    v_readfirstlane_b32 T5, VB4                         // p1's share as a later p2
-    s_lshr_b32 T4, T4, 2                                // (this loop works on the id itself)
-    s_lshr_b32 T5, T5, 2
+    v_lshrrev_b32 VT0, 2, VC                            // (this loop works on the context id itself, not id * 4)
+    v_lshrrev_b32 VT1, 2, VB4
+    s_nop 0
+    v_readfirstlane_b32 T4, VT0                         // context id of the first literal
+    v_readfirstlane_b32 T5, VT1                         // p1's share as a later p2
 // A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
 // LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
-    LIT_RUN_FAST .Llit_r_run
-    s_branch .Llit_r
-.Llit_r_run:
-    LIT_RUN_SETUP .Lflush_stub_lit_r
-.Llit_r:
+.macro LIT_R_BODY rid
     v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
-    LOOKUP2X 9
+    LOOKUP2X \rid
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
     v_and_b32 VT0, RMASK, VPA
@@ -1038,12 +1047,26 @@
     s_and_b32 T1, T1, MA2
     s_or_b32 T4, T1, T5                                 // context id of the next one
     s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
+.endm
+    LIT_RUN_FAST .Llit_r_run
+.Llit_rf:
+    LIT_R_BODY 10
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc0 .Llit_rf
+.Lafter_lits_fast:
+    s_mov_b32 PBASE, POS
+    s_cmp_eq_u32 POS, MBEND
+    s_cbranch_scc0 .Lno_lits
+    s_branch .Lexit
+.Llit_r_run:
+    LIT_RUN_SETUP .Lflush_stub_lit_r
+.Llit_r:
+    LIT_R_BODY 9
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit_r
-    s_cmp_lg_u32 INS, 0                                 // (a whole-insert run leaves nothing to check)
-    s_cbranch_scc0 .Lafter_lits
     LIT_RUN_END .Llit_r_run, .Lflush_stub_lit_r
     LIT_RUN_STUBS 9, .Llit_r_run, .Lflush_stub_lit_r
+    LIT_RUN_FAST_STUB 10, 9
 .Lafter_lits:
     s_mov_b32 INS, 0
     s_mov_b32 PBASE, POS                                // (nothing is pending here)
