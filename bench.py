@@ -35,6 +35,10 @@ WORKLOADS = {
     # the LZ77 back-reference on its own (north_star: ">= 40 % of HBM peak on the copy"): hand-assembled streams, 64 KiB of
     # raw bytes then non-overlapping copies from distance >= 64 KiB doubling the output to 1 MiB (tests/craft.py)
     "farcopy_1MiBx4096": (["farcopy_0", "farcopy_1", "farcopy_2", "farcopy_3"], 4096),
+    # the other Canterbury texts the reference holds (supplementary: bigger files, more trees per meta-block)
+    "asyoulikx4096": (["asyoulik.txt"], 4096),
+    "lcet10x4096": (["lcet10.txt"], 4096),
+    "plrabn12x4096": (["plrabn12.txt"], 4096),
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic

@@ -205,6 +205,10 @@ class Context:
     def last_timing_ms(self, which=1):
         return float(self._lib.brx_last_timing(self._h, which))
 
+    def last_wide_streams(self):
+        """Streams of the most recent launch that the wide-LDS kernel decoded (their tables spill the regular LDS)."""
+        return int(self._lib.brx_last_timing(self._h, 2))
+
     def synchronize(self, hip_stream=None):
         rc = self._lib.brx_synchronize(self._h, hip_stream)
         if rc != 0:

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_gen.hip", "brx_api.cpp"]
+SOURCES = ["brx_kernels.hip", "brx_kernels_big.hip", "brx_gen.hip", "brx_api.cpp"]
 DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
@@ -47,7 +47,9 @@ def _build_locked(verbose):
     if os.environ.get("BRX_NO_SPEC") == "1":
         prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
     # two builds of the loop (brx_hot.S, "Two builds of this file"): bit window in VGPRs (full chip) / in SGPRs (few waves per CU)
-    for name, defs, prefix in (("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_")):
+    # ... each for the regular and for the wide-LDS instance of the kernel (brx_kernels_big.hip: LDS offsets 10 KiB further up)
+    for name, defs, prefix in (("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_"),
+                               ("brx_hot_asm_big.h", ["-DBRX_BIG"], None), ("brx_hot_asm_sw_big.h", ["-DBRX_BIG", "-DBRX_WIN_SGPR"], ".LS_")):
         hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + defs + [os.path.join(CSRC, "brx_hot.S")]).decode()
         assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
         if prefix:

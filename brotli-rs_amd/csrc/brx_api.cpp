@@ -76,6 +76,12 @@ struct brx_ctx {
     uint32_t *d_iac = nullptr;
     uint32_t *d_counters = nullptr; // BRX_COUNTER_RING x 64 B
     uint64_t launch_seq = 0;
+    // streams whose tables spill the regular kernel's LDS are listed here by it and decoded by the wide kernel launched
+    // right behind (BrxKernelArgs::defer): BRX_COUNTER_RING lists of defer_cap stream indices, one per launch in flight
+    uint32_t *d_defer = nullptr;
+    size_t defer_cap = 0;
+    const uint32_t *last_counter = nullptr; // counter line of the most recent launch (brx_last_timing(ctx, 2))
+    bool no_defer = false; // bring-up / A-B (BRX_NO_DEFER=1): spilled meta-blocks stay in the regular kernel's C++ loop
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
     BrxSlabPool pool = {nullptr, nullptr, 0};
@@ -150,6 +156,7 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->d_xforms);
     (void)hipFree(c->d_iac);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_defer);
     (void)hipFree(c->d_pool);
     (void)hipFree(c->pool.bitmap);
     (void)hipFree(c->pool.slabs);
@@ -183,6 +190,7 @@ static int ctx_init(brx_ctx *c, int device) {
         c->debug_stats = getenv("BRX_DEBUG_STATS") != nullptr;
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
         c->no_order = getenv("BRX_NO_ORDER") != nullptr;
+        c->no_defer = getenv("BRX_NO_DEFER") != nullptr;
         c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
         if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
         if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
@@ -337,6 +345,23 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 
 // Streams per CU up to which a launch counts as sparse (profiles/r02_loop_build_sweep.txt).
 #define BRX_SW_WAVES_PER_CU 6u
+// Batches beyond this many streams keep their spilling streams in the regular kernel (the lists would be 64 x 4 B x n).
+#define BRX_DEFER_MAX_STREAMS (1u << 18)
+
+// Room for one list of n deferred stream indices per launch in flight (grown rarely: nobody may be using the old lists).
+static int ensure_defer(brx_ctx *c, uint32_t n) {
+    if (c->d_defer && c->defer_cap >= n) return BRX_SUCCESS;
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->d_defer);
+    c->d_defer = nullptr;
+    c->defer_cap = 0;
+    size_t cap = 4096;
+    while (cap < n) cap <<= 1;
+    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_COUNTER_RING);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e);
+    c->defer_cap = cap;
+    return BRX_SUCCESS;
+}
 
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
@@ -364,7 +389,16 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     // which build of the command loop (brx_hot.S): with at most BRX_SW_WAVES_PER_CU streams per CU the CU's scalar ALU has
     // room and the build with the shorter dependent chain wins; fuller CUs take the one that spares the scalar ALU
     a.loop_build = c->loop_build >= 0 ? (uint32_t)c->loop_build : (grid <= c->max_grid / 16u * BRX_SW_WAVES_PER_CU ? 1u : 0u);
-    a.work_counter = c->d_counters + (size_t)(c->launch_seq++ % BRX_COUNTER_RING) * 16u; // one 64-B line per launch
+    const size_t ring_slot = (size_t)(c->launch_seq++ % BRX_COUNTER_RING);
+    a.work_counter = c->d_counters + ring_slot * 16u; // one 64-B line per launch
+    // streams whose tables spill the regular LDS table memory go to the wide kernel (not in the resumable and bring-up modes)
+    a.defer = nullptr;
+    a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
+    if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && !c->debug_stats && n <= BRX_DEFER_MAX_STREAMS) {
+        int rc = ensure_defer(c, n);
+        if (rc) return rc;
+        a.defer = c->d_defer + ring_slot * c->defer_cap;
+    }
     a.debug = nullptr;
     unsigned long long *dbg = nullptr;
     if (c->debug_stats) {
@@ -379,12 +413,18 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 12, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
+    if (a.defer != nullptr) { // the wide kernel: 8 waves per CU; its waves leave at once when nothing was deferred
+        const unsigned big = c->max_grid / 2u;
+        brx_launch_decode_big(a, n < big ? n : big, st);
+        HIP_TRY(hipGetLastError());
+    }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));
+    c->last_counter = a.defer != nullptr ? a.work_counter : nullptr;
     c->any_launch = true;
     if (a.dump) { // bring-up: parked decoder states for tools/asm_emu.py
         (void)hipStreamSynchronize(st);
@@ -571,6 +611,14 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (which == 2) { // streams of the most recent launch that went to the wide-LDS kernel (waits for that launch)
+        if (!c->any_launch) return -1.0;
+        if (!c->last_counter) return 0.0;
+        uint32_t v = 0;
+        if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
+        if (hipMemcpy(&v, c->last_counter + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        return (double)v;
+    }
     if (!c->have_timing) return -1.0;
     float ms = 0.f;
     hipError_t e = which == 0 ? hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) : hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);

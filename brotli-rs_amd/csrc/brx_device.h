@@ -5,7 +5,15 @@
 // Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
 #define BRX_WAVE 64
 #define BRX_RING_BYTES 2048u     // LDS sliding-window ring: last 2 KiB of the stream's output
+// Two variants of the kernel (same source, brx_kernels.hip / brx_kernels_big.hip): the regular one with 10 KiB of LDS per
+// wave (16 streams per CU) and the wide one (-DBRX_BIG) with 20 KiB (8 streams per CU) for streams whose tables do not fit
+// the regular table memory (real text at high quality: lcet10.txt needs 2 208 words).  A regular wave that finds a
+// stream spilling hands it to the wide kernel, launched right behind on the same HIP stream (BrxKernelArgs::defer).
+#ifdef BRX_BIG
+#define BRX_TM_WORDS 4288u       // 17 152 B of table memory -> 20 KiB LDS per wave
+#else
 #define BRX_TM_WORDS 1728u       // LDS table memory (prefix-code tables, context maps): 6912 B -> 10 KiB LDS per wave
+#endif
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that
@@ -61,7 +69,11 @@ struct BrxKernelArgs {
     uint32_t n;
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
-    uint32_t *work_counter; // this launch's own counter (ring in brx_ctx), zeroed in-stream before the launch
+    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..2 zeroed in-stream before the launch:
+                            // [0] work counter of the regular kernel, [1] of the wide kernel, [2] streams deferred
+    uint32_t *defer;        // nullptr, or room for n stream indices: the regular kernel lists here the streams whose tables
+                            // spill its LDS table memory (and leaves them undecoded); the wide kernel decodes exactly those
+    uint32_t sw_threshold;  // wide kernel: up to this many deferred streams it runs the sparse-launch build of the loop
     const BrxSlabPool *pool; // spill slabs
     unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr
     uint32_t *dump;         // bring-up (BRX_DEBUG_DUMP, debug_stop 9): word 0 = records written, then records of
@@ -74,7 +86,12 @@ struct BrxKernelArgs {
     BrxDeviceTables t;
 };
 
+#ifdef BRX_BIG
+#define BRX_LDS_BYTES 20480u
+#else
 #define BRX_LDS_BYTES 10240u
+#endif
 #define BRX_DUMP_WORDS (16u + BRX_LDS_BYTES / 4u)
 
 void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
+void brx_launch_decode_big(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // the wide-LDS variant (args.defer set)

@@ -36,15 +36,22 @@
 // for all literal block types, every distance symbol fits its payload form, input < 2^28 bytes, pos + MLEN <= capacity.
 // tools/asm_emu.py runs this file instruction by instruction against LDS states dumped on the GPU and the oracle.
 
+// -DBRX_BIG: the wide-LDS instance of the kernel (brx_kernels_big.hip) -- 10 240 B more table memory, everything behind
+// it 10 240 B further up
+#ifdef BRX_BIG
+#define LDS_GROW 10240
+#else
+#define LDS_GROW 0
+#endif
 #define LDS_TM 2048
-#define LDS_ST 9728
-#define LDS_MBW 9920
+#define LDS_ST (9728+LDS_GROW)
+#define LDS_MBW (9920+LDS_GROW)
 #define RMASK 2047
 #define RING 2048
 // the code-length scratch area (Lds::lens, 768 B) is free during the command loop
-#define LDS_ITAB 8960   // byte -> context info (filled by prepare_fast_tables)
-#define LDS_SPARE 9216  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
-#define LDS_CMH 9472    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
+#define LDS_ITAB (8960+LDS_GROW)   // byte -> context info (filled by prepare_fast_tables)
+#define LDS_SPARE (9216+LDS_GROW)  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
+#define LDS_CMH (9472+LDS_GROW)    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
 #define SYMOFF 128      // symbol list of a tree: after its 32 header words
 // EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup + lane 16, which carries the symbol-list
 // address of a resident tree).  Everything uniform needs one lane; copies, flushes and input staging set their own mask.
@@ -195,7 +202,7 @@
 // distance symbol (<= 15); every literal, every extra-bit field > 0 and the distance symbol are followed by a check.
 // (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
 #ifdef BRX_PROF
-#define LDS_PAD 10112
+#define LDS_PAD (10112+LDS_GROW)
 .macro PROF_WAIT_VM
     s_waitcnt lgkmcnt(0)
     s_memtime s[16:17]

@@ -1202,7 +1202,11 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
 // shortest dependent chain wins.  BrxKernelArgs::loop_build picks one per launch.
 __device__ __noinline__ u32 asm_commands() {
     asm volatile(
+#ifdef BRX_BIG
+#include "_gen/brx_hot_asm_big.h"
+#else
 #include "_gen/brx_hot_asm.h"
+#endif
         :
         :
         : BRX_ASM_CLOBBERS);
@@ -1210,7 +1214,11 @@ __device__ __noinline__ u32 asm_commands() {
 }
 __device__ __noinline__ u32 asm_commands_sw() {
     asm volatile(
+#ifdef BRX_BIG
+#include "_gen/brx_hot_asm_sw_big.h"
+#else
 #include "_gen/brx_hot_asm_sw.h"
+#endif
         :
         :
         : BRX_ASM_CLOBBERS);
@@ -1615,18 +1623,44 @@ __device__ __noinline__ void seg_finish() {
 // The kernel itself is only a dispatcher: per stream it parks the initial state in LDS and then alternates
 // between the out-of-line segments.  Keeping it this small is what lets every segment have its own register
 // allocation (nothing but `a`, `sid` and &s is live across the calls).
-__global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a) {
+//
+// Two instances of this file: the regular kernel (10 KiB of LDS per wave, 16 waves per CU) and, with -DBRX_BIG
+// (brx_kernels_big.hip), the wide one (20 KiB, 8 waves per CU).  A stream whose meta-block tables spill the regular table
+// memory would run that meta-block in the C++ loop against tables in HBM (lcet10.txt: 8 x slower than its neighbours); with
+// a.defer set the regular kernel instead drops such a stream at the first spill, lists it, and the wide kernel -- launched
+// right behind on the same HIP stream, no host round trip -- decodes the listed streams from their start.
+#ifdef BRX_BIG
+#define BRX_KERNEL_NAME brx_decode_kernel_big
+#define BRX_WAVES_PER_SIMD 2
+#else
+#define BRX_KERNEL_NAME brx_decode_kernel
+#define BRX_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(BrxKernelArgs a) {
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
     if (a.debug_stop == 1u) return;
+#ifdef BRX_BIG
+    const u32 n_streams = rfl(a.defer != nullptr ? __builtin_nontemporal_load(&a.work_counter[2]) : 0u);
+    if (n_streams == 0u) return;
+    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold;
+    u32 *const counter = a.work_counter + 1;
+#else
+    const u32 n_streams = a.n;
     const bool sw_loop = a.loop_build != 0u;
+    u32 *const counter = a.work_counter;
+#endif
     for (;;) {
         // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
         // behind the lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63
         // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
-        u32 sid = rdl(atomicAdd(a.work_counter, lane == 0u ? 1u : 0u), 0);
-        if (sid >= a.n) break;
+        u32 sid = rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
+        if (sid >= n_streams) break;
+#ifdef BRX_BIG
+        sid = rfl(a.defer[sid]); // the streams the regular kernel left to this one
+#else
         if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
+#endif
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
         {
@@ -1665,6 +1699,7 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             }
             if (lane < 32u) s.pad[lane] = 0u;
         }
+#ifndef BRX_BIG
         if (a.resume != nullptr) {
             // ---- resumable mode: one stream decoded in slices against a sliding output window (brx_api.cpp, streaming
             // Read facade).  Pauses only between the out-of-line segments, where the whole state sits in LDS.
@@ -1727,12 +1762,20 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             }
             continue;
         }
+#endif
         const u32 prof_on = a.debug != nullptr ? 1u : 0u;
+        bool deferred = false;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
         u32 st = seg_frame();
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
             if (st) break;
+#ifndef BRX_BIG
+            if (a.defer != nullptr && get64(s, 20) != 0ull) { // this meta-block's tables spilled into a slab: a stream
+                deferred = true;                               // for the wide kernel
+                break;
+            }
+#endif
             if (a.debug_stop == 8u) { // bring-up: the C++ loop alone, whole meta-block per call
                 st = generic_commands(HC_WHOLE);
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
@@ -1780,6 +1823,13 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
             const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
             if (slab != nullptr) scratch_release(a.pool, slab);
         }
+#ifndef BRX_BIG
+        if (deferred) { // no status, no length: the wide kernel decodes the stream from its start (same bytes, same slots)
+            const u32 slot = rdl(atomicAdd(a.work_counter + 2, lane == 0u ? 1u : 0u), 0);
+            if (lane == 0u) a.defer[slot] = sid;
+            continue;
+        }
+#endif
         u32 pos = rfl(s.st[10]), needed = rfl(s.st[22]);
         if (prof_on && lane < 8u) a.debug[(size_t)sid * 10u + lane] = (u64)s.pad[2 * lane] | ((u64)s.pad[2 * lane + 1] << 32);
         if (prof_on && lane == 0u) {
@@ -1793,6 +1843,12 @@ __global__ __launch_bounds__(BRX_WAVE, 4) void brx_decode_kernel(BrxKernelArgs a
     }
 }
 
+#ifdef BRX_BIG
+void brx_launch_decode_big(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
+    hipLaunchKernelGGL(brx_decode_kernel_big, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
+}
+#else
 void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
     hipLaunchKernelGGL(brx_decode_kernel, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
 }
+#endif

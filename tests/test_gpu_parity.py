@@ -534,6 +534,48 @@ def test_both_builds_of_the_command_loop(build):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_no_defer_switch_keeps_spilled_meta_blocks_in_the_regular_kernel():
+    """BRX_NO_DEFER=1: streams whose tables spill the LDS table memory stay in the regular kernel (C++ loop against the
+    slab in HBM) instead of going to the wide-LDS kernel -- the path every stream took before, still bit-exact."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BRX_NO_DEFER="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
+    """lcet10.txt's tables (2 208 words) do not fit the regular kernel's 1 728 words of LDS table memory: the regular kernel
+    drops such a stream at the spill and lists it, the wide-LDS kernel launched behind it decodes it from the start.  A
+    mixed batch (spilling and fitting streams, reject vectors, empty outputs, unaligned slots) is bit-exact, the count
+    of handed-over streams is what the batch holds, and a batch without any hands over nothing."""
+    lcet = _read("lcet10.txt.compressed")
+    alice = _read("alice29.txt.compressed")
+    rest = [_read(e["stream"]) for e in MANIFEST]
+    streams = []
+    for i in range(70):
+        streams.append(lcet)
+        streams.append(alice if i % 3 else rest[i % len(rest)])
+    want = [oracle.decode(s_, 0, cap=1 << 20) for s_ in streams]
+    caps = [len(w[1]) + 1 + (i % 5) if w[0] == 0 else 1 << 17 for i, w in enumerate(want)]
+    want = [oracle.decode(s_, 0, cap=c_) for s_, c_ in zip(streams, caps)]
+    outs, status, out_len = ctx.decode_batch(streams, caps)
+    wide = ctx.last_wide_streams()
+    bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
+           if w[0] != st or (st == 0 and o != w[1])]
+    assert not bad, bad[:8]
+    assert 70 <= wide <= 70 + 12, wide  # every lcet10 (the few other spilling fixtures of data/ on top)
+    outs, status, out_len = ctx.decode_batch([alice] * 40, len(_read("alice29.txt")) + 16)
+    assert ctx.last_wide_streams() == 0
+    assert all(int(st) == 0 for st in status) and all(o == _read("alice29.txt") for o in outs)
+    # a spilling stream whose slot is too small: status 25 and the length needed so far, from whichever kernel meets it
+    outs, status, out_len = ctx.decode_batch([lcet, alice, lcet], [1000, 200000, 500000])
+    w0 = oracle.decode(lcet, 0, cap=1000)
+    assert [int(x) for x in status] == [25, 0, 0] and w0[0] == 25
+    assert outs[2] == _read("lcet10.txt")
+
+
 def test_farcopy_streams(ctx):
     """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
     streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
