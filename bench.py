@@ -39,6 +39,7 @@ WORKLOADS = {
     "asyoulikx4096": (["asyoulik.txt"], 4096),
     "lcet10x4096": (["lcet10.txt"], 4096),
     "plrabn12x4096": (["plrabn12.txt"], 4096),
+    "mapsdatazrhx4096": (["mapsdatazrh"], 4096),
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic

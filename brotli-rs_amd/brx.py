@@ -205,9 +205,10 @@ class Context:
     def last_timing_ms(self, which=1):
         return float(self._lib.brx_last_timing(self._h, which))
 
-    def last_wide_streams(self):
-        """Streams of the most recent launch that the wide-LDS kernel decoded (their tables spill the regular LDS)."""
-        return int(self._lib.brx_last_timing(self._h, 2))
+    def last_wide_streams(self, level=1):
+        """Streams of the most recent launch handed to the level-`level` (1..3) instance of the kernel: their tables spill
+        the LDS table memory of the levels below.  Level 1 = every stream that left the regular kernel."""
+        return int(self._lib.brx_last_timing(self._h, 1 + level))
 
     def synchronize(self, hip_stream=None):
         rc = self._lib.brx_synchronize(self._h, hip_stream)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_kernels_big.hip", "brx_gen.hip", "brx_api.cpp"]
+SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_gen.hip", "brx_api.cpp"]
 DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
@@ -47,9 +47,12 @@ def _build_locked(verbose):
     if os.environ.get("BRX_NO_SPEC") == "1":
         prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
     # two builds of the loop (brx_hot.S, "Two builds of this file"): bit window in VGPRs (full chip) / in SGPRs (few waves per CU)
-    # ... each for the regular and for the wide-LDS instance of the kernel (brx_kernels_big.hip: LDS offsets 10 KiB further up)
-    for name, defs, prefix in (("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_"),
-                               ("brx_hot_asm_big.h", ["-DBRX_BIG"], None), ("brx_hot_asm_sw_big.h", ["-DBRX_BIG", "-DBRX_WIN_SGPR"], ".LS_")):
+    # ... each for the four instances of the kernel (brx_device.h: the wider ones have their LDS offsets LDS_GROW further up)
+    variants = [("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_")]
+    for level, grow in ((1, 2560), (2, 10240), (3, 30720)):
+        variants += [("brx_hot_asm_l%d.h" % level, ["-DLDS_GROW=%d" % grow], None),
+                     ("brx_hot_asm_sw_l%d.h" % level, ["-DLDS_GROW=%d" % grow, "-DBRX_WIN_SGPR"], ".LS_")]
+    for name, defs, prefix in variants:
         hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + defs + [os.path.join(CSRC, "brx_hot.S")]).decode()
         assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
         if prefix:

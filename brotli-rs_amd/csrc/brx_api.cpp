@@ -357,7 +357,7 @@ static int ensure_defer(brx_ctx *c, uint32_t n) {
     c->defer_cap = 0;
     size_t cap = 4096;
     while (cap < n) cap <<= 1;
-    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_COUNTER_RING);
+    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * (BRX_LEVELS - 1) * BRX_COUNTER_RING);
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e);
     c->defer_cap = cap;
     return BRX_SUCCESS;
@@ -393,11 +393,13 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.work_counter = c->d_counters + ring_slot * 16u; // one 64-B line per launch
     // streams whose tables spill the regular LDS table memory go to the wide kernel (not in the resumable and bring-up modes)
     a.defer = nullptr;
+    a.defer_cap = 0;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
     if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && !c->debug_stats && n <= BRX_DEFER_MAX_STREAMS) {
         int rc = ensure_defer(c, n);
         if (rc) return rc;
-        a.defer = c->d_defer + ring_slot * c->defer_cap;
+        a.defer = c->d_defer + ring_slot * (BRX_LEVELS - 1) * c->defer_cap;
+        a.defer_cap = (uint32_t)c->defer_cap;
     }
     a.debug = nullptr;
     unsigned long long *dbg = nullptr;
@@ -413,13 +415,15 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 12, st));
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 32, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
-    if (a.defer != nullptr) { // the wide kernel: 8 waves per CU; its waves leave at once when nothing was deferred
-        const unsigned big = c->max_grid / 2u;
-        brx_launch_decode_big(a, n < big ? n : big, st);
+    if (a.defer != nullptr) { // the wider kernels (12 / 8 / 4 waves per CU): their waves leave at once when nothing was listed
+        const unsigned per_cu = c->max_grid / 16u;
+        brx_launch_decode_l1(a, std::min(n, per_cu * 12u), st);
+        brx_launch_decode_l2(a, std::min(n, per_cu * 8u), st);
+        brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
         HIP_TRY(hipGetLastError());
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -611,13 +615,13 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (which == 2) { // streams of the most recent launch that went to the wide-LDS kernel (waits for that launch)
+    if (which >= 2 && which <= 4) { // streams of the most recent launch listed for level which - 1 (waits for that launch)
         if (!c->any_launch) return -1.0;
         if (!c->last_counter) return 0.0;
         uint32_t v = 0;
         if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
-        if (hipMemcpy(&v, c->last_counter + 2, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
-        return (double)v;
+        if (hipMemcpy(&v, c->last_counter + 3 + which, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        return (double)v; // every stream that left level 0 (levels 2 and 3 take theirs out of these)
     }
     if (!c->have_timing) return -1.0;
     float ms = 0.f;

@@ -5,15 +5,31 @@
 // Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
 #define BRX_WAVE 64
 #define BRX_RING_BYTES 2048u     // LDS sliding-window ring: last 2 KiB of the stream's output
-// Two variants of the kernel (same source, brx_kernels.hip / brx_kernels_big.hip): the regular one with 10 KiB of LDS per
-// wave (16 streams per CU) and the wide one (-DBRX_BIG) with 20 KiB (8 streams per CU) for streams whose tables do not fit
-// the regular table memory (real text at high quality: lcet10.txt needs 2 208 words).  A regular wave that finds a
-// stream spilling hands it to the wide kernel, launched right behind on the same HIP stream (BrxKernelArgs::defer).
-#ifdef BRX_BIG
-#define BRX_TM_WORDS 4288u       // 17 152 B of table memory -> 20 KiB LDS per wave
-#else
-#define BRX_TM_WORDS 1728u       // LDS table memory (prefix-code tables, context maps): 6912 B -> 10 KiB LDS per wave
+// Four instances of the kernel, one source (brx_kernels.hip; brx_kernels_l1/l2/l3.hip set BRX_LEVEL): the regular one with
+// 10 KiB of LDS per wave (16 streams per CU) and three wider ones for streams whose meta-block tables do not fit its table
+// memory (real text at high quality: lcet10.txt needs 2 208 words, 800 KB of text at quality 11 ~5 000):
+//   level   LDS per wave   table memory          streams per CU
+//     0       10 240 B      1 728 words            16
+//     1       12 800 B      2 368 words            12
+//     2       20 480 B      4 288 words             8
+//     3       40 960 B      9 408 words             4
+// (sizes are multiples of 1 280 B so that the waves of a CU fill its 160 KiB whatever the allocation granule.)  A wave that
+// finds a stream spilling its level's table memory drops it and lists it for the next level; the four kernels are
+// launched back to back on one HIP stream, no host round trip (BrxKernelArgs::defer).  Beyond level 3: the spill slabs.
+#ifndef BRX_LEVEL
+#define BRX_LEVEL 0
 #endif
+#define BRX_LEVELS 4
+#if BRX_LEVEL == 0
+#define BRX_LDS_GROW 0u
+#elif BRX_LEVEL == 1
+#define BRX_LDS_GROW 2560u
+#elif BRX_LEVEL == 2
+#define BRX_LDS_GROW 10240u
+#else
+#define BRX_LDS_GROW 30720u
+#endif
+#define BRX_TM_WORDS (1728u + BRX_LDS_GROW / 4u) // LDS table memory (prefix-code tables, context maps): 6 912 B at level 0
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that
@@ -69,11 +85,13 @@ struct BrxKernelArgs {
     uint32_t n;
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
-    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..2 zeroed in-stream before the launch:
-                            // [0] work counter of the regular kernel, [1] of the wide kernel, [2] streams deferred
-    uint32_t *defer;        // nullptr, or room for n stream indices: the regular kernel lists here the streams whose tables
-                            // spill its LDS table memory (and leaves them undecoded); the wide kernel decodes exactly those
-    uint32_t sw_threshold;  // wide kernel: up to this many deferred streams it runs the sparse-launch build of the loop
+    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..7 zeroed in-stream before the launch:
+                            // [k] work counter of the level-k kernel, [4 + k] streams listed for level k (k = 1..3)
+    uint32_t *defer;        // nullptr, or 3 lists of defer_cap stream indices (list of level k at (k - 1) * defer_cap): a
+                            // kernel lists for the next level the streams whose tables spill its LDS table memory (and
+                            // leaves them undecoded); the level-k kernel decodes exactly the streams of its list
+    uint32_t defer_cap;
+    uint32_t sw_threshold;  // wider kernels: up to this many listed streams they run the sparse-launch build of the loop
     const BrxSlabPool *pool; // spill slabs
     unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr
     uint32_t *dump;         // bring-up (BRX_DEBUG_DUMP, debug_stop 9): word 0 = records written, then records of
@@ -86,12 +104,10 @@ struct BrxKernelArgs {
     BrxDeviceTables t;
 };
 
-#ifdef BRX_BIG
-#define BRX_LDS_BYTES 20480u
-#else
-#define BRX_LDS_BYTES 10240u
-#endif
+#define BRX_LDS_BYTES (10240u + BRX_LDS_GROW)
 #define BRX_DUMP_WORDS (16u + BRX_LDS_BYTES / 4u)
 
 void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
-void brx_launch_decode_big(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // the wide-LDS variant (args.defer set)
+void brx_launch_decode_l1(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // the wider instances (args.defer set)
+void brx_launch_decode_l2(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
+void brx_launch_decode_l3(const BrxKernelArgs &args, unsigned grid, void *hip_stream);

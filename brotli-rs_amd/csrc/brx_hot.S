@@ -36,11 +36,9 @@
 // for all literal block types, every distance symbol fits its payload form, input < 2^28 bytes, pos + MLEN <= capacity.
 // tools/asm_emu.py runs this file instruction by instruction against LDS states dumped on the GPU and the oracle.
 
-// -DBRX_BIG: the wide-LDS instance of the kernel (brx_kernels_big.hip) -- 10 240 B more table memory, everything behind
-// it 10 240 B further up
-#ifdef BRX_BIG
-#define LDS_GROW 10240
-#else
+// -DLDS_GROW=bytes: the wider instances of the kernel (brx_kernels_l1/l2/l3.hip, BRX_LDS_GROW of brx_device.h) -- that much
+// more table memory, everything behind it that much further up
+#ifndef LDS_GROW
 #define LDS_GROW 0
 #endif
 #define LDS_TM 2048

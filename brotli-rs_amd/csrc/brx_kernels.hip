@@ -1202,10 +1202,14 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
 // shortest dependent chain wins.  BrxKernelArgs::loop_build picks one per launch.
 __device__ __noinline__ u32 asm_commands() {
     asm volatile(
-#ifdef BRX_BIG
-#include "_gen/brx_hot_asm_big.h"
-#else
+#if BRX_LEVEL == 0
 #include "_gen/brx_hot_asm.h"
+#elif BRX_LEVEL == 1
+#include "_gen/brx_hot_asm_l1.h"
+#elif BRX_LEVEL == 2
+#include "_gen/brx_hot_asm_l2.h"
+#else
+#include "_gen/brx_hot_asm_l3.h"
 #endif
         :
         :
@@ -1214,10 +1218,14 @@ __device__ __noinline__ u32 asm_commands() {
 }
 __device__ __noinline__ u32 asm_commands_sw() {
     asm volatile(
-#ifdef BRX_BIG
-#include "_gen/brx_hot_asm_sw_big.h"
-#else
+#if BRX_LEVEL == 0
 #include "_gen/brx_hot_asm_sw.h"
+#elif BRX_LEVEL == 1
+#include "_gen/brx_hot_asm_sw_l1.h"
+#elif BRX_LEVEL == 2
+#include "_gen/brx_hot_asm_sw_l2.h"
+#else
+#include "_gen/brx_hot_asm_sw_l3.h"
 #endif
         :
         :
@@ -1624,31 +1632,42 @@ __device__ __noinline__ void seg_finish() {
 // between the out-of-line segments.  Keeping it this small is what lets every segment have its own register
 // allocation (nothing but `a`, `sid` and &s is live across the calls).
 //
-// Two instances of this file: the regular kernel (10 KiB of LDS per wave, 16 waves per CU) and, with -DBRX_BIG
-// (brx_kernels_big.hip), the wide one (20 KiB, 8 waves per CU).  A stream whose meta-block tables spill the regular table
-// memory would run that meta-block in the C++ loop against tables in HBM (lcet10.txt: 8 x slower than its neighbours); with
-// a.defer set the regular kernel instead drops such a stream at the first spill, lists it, and the wide kernel -- launched
+// Four instances of this file (BRX_LEVEL, brx_device.h): the regular kernel (10 KiB of LDS per wave, 16 waves per CU) and
+// three wider ones (12.5 / 20 / 40 KiB: 12 / 8 / 4 waves per CU).  A stream whose meta-block tables spill the table memory
+// would run that meta-block in the C++ loop against tables in HBM (lcet10.txt: 8 x slower than its neighbours); with a.defer
+// set a kernel instead drops such a stream at the first spill and lists it for the next level, whose kernel -- launched
 // right behind on the same HIP stream, no host round trip -- decodes the listed streams from their start.
-#ifdef BRX_BIG
-#define BRX_KERNEL_NAME brx_decode_kernel_big
+#if BRX_LEVEL == 0
+#define BRX_KERNEL_NAME brx_decode_kernel
+#define BRX_LAUNCH_NAME brx_launch_decode
+#define BRX_WAVES_PER_SIMD 4
+#elif BRX_LEVEL == 1
+#define BRX_KERNEL_NAME brx_decode_kernel_l1
+#define BRX_LAUNCH_NAME brx_launch_decode_l1
+#define BRX_WAVES_PER_SIMD 3
+#elif BRX_LEVEL == 2
+#define BRX_KERNEL_NAME brx_decode_kernel_l2
+#define BRX_LAUNCH_NAME brx_launch_decode_l2
 #define BRX_WAVES_PER_SIMD 2
 #else
-#define BRX_KERNEL_NAME brx_decode_kernel
-#define BRX_WAVES_PER_SIMD 4
+#define BRX_KERNEL_NAME brx_decode_kernel_l3
+#define BRX_LAUNCH_NAME brx_launch_decode_l3
+#define BRX_WAVES_PER_SIMD 1
 #endif
 __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(BrxKernelArgs a) {
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
     if (a.debug_stop == 1u) return;
-#ifdef BRX_BIG
-    const u32 n_streams = rfl(a.defer != nullptr ? __builtin_nontemporal_load(&a.work_counter[2]) : 0u);
+    u32 *const counter = a.work_counter + BRX_LEVEL;
+#if BRX_LEVEL > 0
+    const u32 n_streams = rfl(a.defer != nullptr ? __builtin_nontemporal_load(&a.work_counter[4 + BRX_LEVEL]) : 0u);
     if (n_streams == 0u) return;
-    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold;
-    u32 *const counter = a.work_counter + 1;
+    const u32 *const my_list = a.defer + (size_t)(BRX_LEVEL - 1) * a.defer_cap;
+    // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
+    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
 #else
     const u32 n_streams = a.n;
     const bool sw_loop = a.loop_build != 0u;
-    u32 *const counter = a.work_counter;
 #endif
     for (;;) {
         // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
@@ -1656,8 +1675,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
         u32 sid = rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
         if (sid >= n_streams) break;
-#ifdef BRX_BIG
-        sid = rfl(a.defer[sid]); // the streams the regular kernel left to this one
+#if BRX_LEVEL > 0
+        sid = rfl(my_list[sid]); // the streams the level below left to this one
 #else
         if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
 #endif
@@ -1699,7 +1718,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             }
             if (lane < 32u) s.pad[lane] = 0u;
         }
-#ifndef BRX_BIG
+#if BRX_LEVEL == 0
         if (a.resume != nullptr) {
             // ---- resumable mode: one stream decoded in slices against a sliding output window (brx_api.cpp, streaming
             // Read facade).  Pauses only between the out-of-line segments, where the whole state sits in LDS.
@@ -1770,9 +1789,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
             if (st) break;
-#ifndef BRX_BIG
+#if BRX_LEVEL < BRX_LEVELS - 1
             if (a.defer != nullptr && get64(s, 20) != 0ull) { // this meta-block's tables spilled into a slab: a stream
-                deferred = true;                               // for the wide kernel
+                deferred = true;                               // for the next level
                 break;
             }
 #endif
@@ -1823,10 +1842,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
             if (slab != nullptr) scratch_release(a.pool, slab);
         }
-#ifndef BRX_BIG
-        if (deferred) { // no status, no length: the wide kernel decodes the stream from its start (same bytes, same slots)
-            const u32 slot = rdl(atomicAdd(a.work_counter + 2, lane == 0u ? 1u : 0u), 0);
-            if (lane == 0u) a.defer[slot] = sid;
+#if BRX_LEVEL < BRX_LEVELS - 1
+        if (deferred) { // no status, no length: the next level decodes the stream from its start (same bytes, same slots)
+            const u32 slot = rdl(atomicAdd(a.work_counter + 5 + BRX_LEVEL, lane == 0u ? 1u : 0u), 0);
+            if (lane == 0u) a.defer[(size_t)BRX_LEVEL * a.defer_cap + slot] = sid;
             continue;
         }
 #endif
@@ -1843,12 +1862,6 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     }
 }
 
-#ifdef BRX_BIG
-void brx_launch_decode_big(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
-    hipLaunchKernelGGL(brx_decode_kernel_big, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
+void BRX_LAUNCH_NAME(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
+    hipLaunchKernelGGL(BRX_KERNEL_NAME, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
 }
-#else
-void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
-    hipLaunchKernelGGL(brx_decode_kernel, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
-}
-#endif

@@ -129,9 +129,10 @@ const char *brx_last_error(void);
 
 /* Timing of the most recent brx_decode_batch call made with BRX_OPT_TIMING (milliseconds, HIP events on
  * the launch stream).  which: 0 = whole device section, 1 = decode kernels. Returns <0 if unavailable.
- * which = 2 (no BRX_OPT_TIMING needed; waits for the most recent launch): how many streams of that launch were decoded
- * by the wide-LDS instance of the kernel -- streams whose prefix-code tables do not fit the regular 6 912 B of LDS
- * table memory are handed over on the device to a second kernel with 17 152 B (8 instead of 16 streams per CU). */
+ * which = 2, 3, 4 (no BRX_OPT_TIMING needed; waits for the most recent launch): how many streams of that launch were
+ * handed to the level-1, -2, -3 instance of the kernel.  Streams whose prefix-code tables do not fit the regular 6 912 B
+ * of LDS table memory are handed over on the device to kernels with 9 472 / 17 152 / 37 632 B of it (12 / 8 / 4 instead
+ * of 16 streams per CU), launched behind the regular one; which = 2 counts every stream that left the regular kernel. */
 double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */

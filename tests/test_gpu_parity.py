@@ -557,6 +557,7 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     for i in range(70):
         streams.append(lcet)
         streams.append(alice if i % 3 else rest[i % len(rest)])
+    streams += [_read("mapsdatazrh.compressed")] * 3  # 4 094 words of tables: more than level 1 holds
     want = [oracle.decode(s_, 0, cap=1 << 20) for s_ in streams]
     caps = [len(w[1]) + 1 + (i % 5) if w[0] == 0 else 1 << 17 for i, w in enumerate(want)]
     want = [oracle.decode(s_, 0, cap=c_) for s_, c_ in zip(streams, caps)]
@@ -565,7 +566,8 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
            if w[0] != st or (st == 0 and o != w[1])]
     assert not bad, bad[:8]
-    assert 70 <= wide <= 70 + 12, wide  # every lcet10 (the few other spilling fixtures of data/ on top)
+    assert 73 <= wide <= 73 + 12, wide  # every lcet10 and mapsdatazrh (the few other spilling fixtures of data/ on top)
+    assert 3 <= ctx.last_wide_streams(2) <= 3 + 12 and ctx.last_wide_streams(3) <= 12
     outs, status, out_len = ctx.decode_batch([alice] * 40, len(_read("alice29.txt")) + 16)
     assert ctx.last_wide_streams() == 0
     assert all(int(st) == 0 for st in status) and all(o == _read("alice29.txt") for o in outs)

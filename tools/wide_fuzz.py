@@ -44,7 +44,7 @@ for r in range(rounds):
         datas.append(data)
     caps = [len(x) + rng.randrange(0, 40) for x in datas]
     outs, status, out_len = ctx.decode_batch(streams, caps)
-    wide = ctx.last_wide_streams()
+    wide = [ctx.last_wide_streams(k) for k in (1, 2, 3)]
     for i, (d, o, st) in enumerate(zip(datas, outs, status)):
         if st != 0 or o != d:
             bad += 1
@@ -60,12 +60,12 @@ for r in range(rounds):
         cs.append(bytes(s))
     exp = [oracle_py.decode(s, cap=1 << 21) for s in cs]
     outs, status, out_len = ctx.decode_batch(cs, [1 << 21] * len(cs))
-    wide2 = ctx.last_wide_streams()
+    wide2 = [ctx.last_wide_streams(k) for k in (1, 2, 3)]
     for i, (e, o, st) in enumerate(zip(exp, outs, status)):
         if int(st) != e[0] or (e[0] == 0 and o != e[1]):
             bad += 1
             print("MISMATCH corrupted stream", r, i, int(st), e[0], cs[i][:24].hex())
-    print("round", r, "done: wide kernel took", wide, "of", len(streams), "valid and", wide2, "of", len(cs),
+    print("round", r, "done: levels 1/2/3 were handed", wide, "of", len(streams), "valid and", wide2, "of", len(cs),
           "corrupted streams; mismatches so far", bad, flush=True)
 ctx.close()
 sys.exit(1 if bad else 0)
