@@ -395,7 +395,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.defer = nullptr;
     a.defer_cap = 0;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
-    if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && !c->debug_stats && n <= BRX_DEFER_MAX_STREAMS) {
+    if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS) {
         int rc = ensure_defer(c, n);
         if (rc) return rc;
         a.defer = c->d_defer + ring_slot * (BRX_LEVELS - 1) * c->defer_cap;

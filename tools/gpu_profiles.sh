@@ -7,7 +7,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$GRAFT_REPO_ROOT; TAG=${TAG:-r02}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-WLS="alice29x4096 config5_1MiBx1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192 compressed_repeatedx4096"
+WLS="alice29x4096 config5_1MiBx1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192 compressed_repeatedx4096 lcet10x4096"
 for wl in $WLS; do
   timeout 600 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${TAG}_${wl}.json
 done
@@ -30,11 +30,12 @@ for wl in alice29x4096 config5_1MiBx1024 farcopy_1MiBx4096 backward65536x4096 qu
 import csv,sys,glob,json,os
 wl,tag=sys.argv[1:3]; out={"workload":wl}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
-    vals=[]
+    tot=0.0; launches=0   # one launch = the regular kernel + the three wider instances behind it (brx_decode_kernel_l1..3)
     for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv"%c, recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'brx_decode' in r['Kernel_Name'] and r['Counter_Name']==c: vals.append(float(r['Counter_Value']))
-    out[c+"_per_dispatch_raw"]=vals
+            if 'brx_decode' in r['Kernel_Name'] and r['Counter_Name']==c:
+                tot+=float(r['Counter_Value']); launches+=r['Kernel_Name'].startswith('brx_decode_kernel(')
+    out[c+"_per_dispatch_raw"]=[tot/launches] if launches else []
 json.dump(out, open(os.environ['GRAFT_REPO_ROOT']+"/gpurun_out/traffic_%s_%s.json"%(tag,wl),"w"))
 print(wl, {k:(sum(v)/max(1,len(v)) if isinstance(v,list) else v) for k,v in out.items()})
 PY
@@ -48,8 +49,8 @@ import csv,glob,collections
 agg=collections.defaultdict(float); n=collections.defaultdict(int)
 for f in glob.glob("/tmp/pmc_out/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'brx' in r['Kernel_Name']:
-            agg[r['Counter_Name']]+=float(r['Counter_Value']); n[r['Counter_Name']]+=1
+        if 'brx' in r['Kernel_Name']:  # per launch: the regular kernel + the (here idle) wider instances behind it
+            agg[r['Counter_Name']]+=float(r['Counter_Value']); n[r['Counter_Name']]+=r['Kernel_Name'].startswith('brx_decode_kernel(')
 for k in sorted(agg): print("%-24s %18.0f per dispatch"%(k,agg[k]/n[k]))
 PY
 done
