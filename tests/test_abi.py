@@ -24,6 +24,9 @@ def test_library_builds_for_gfx950():
     blob = open(path, "rb").read()
     assert b"gfx950" in blob  # the code object targets MI355X
     assert b"brx_decode_kernel" in blob
+    # the three wider-LDS instances of the kernel (brx_device.h, BRX_LEVEL) travel in the same library
+    for k in (1, 2, 3):
+        assert b"brx_decode_kernel_l%d" % k in blob
 
 
 def test_every_declared_symbol_is_exported():
