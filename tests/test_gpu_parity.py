@@ -608,13 +608,15 @@ def test_farcopy_streams(ctx):
 
 
 def test_two_overlapping_device_batches_on_two_hip_streams(ctx):
-    """Two BRX_MEM_DEVICE calls on one context, enqueued back to back on two HIP streams without a host sync in
-    between: each launch has its own work counter, spill slabs are claimed by the waves from the shared pool
-    (metablock_reset spills its tables to HBM), the results must be those of the oracle."""
+    """Three BRX_MEM_DEVICE calls on one context, enqueued back to back on three HIP streams without a host sync in
+    between: each launch has its own work counters and hand-over lists, spill slabs are claimed by the waves from the
+    shared pool, the results must be those of the oracle."""
     import torch
     dev = torch.device("cuda:0")
     jobs = []
-    for name, n in (("alice29.txt", 700), ("metablock_reset", 96)):
+    # metablock_reset and lcet10 spill the regular table memory: both batches hand streams to the wider kernel instances,
+    # each through its own lists, while the kernels of the other batches run
+    for name, n in (("alice29.txt", 700), ("metablock_reset", 96), ("lcet10.txt", 120)):
         comp, exp = _read(name + ".compressed"), _read(name)
         cap = (len(exp) + 15) & ~15
         blob = torch.frombuffer(bytearray(comp * n), dtype=torch.uint8).to(dev)
