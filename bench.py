@@ -40,6 +40,10 @@ WORKLOADS = {
     "lcet10x4096": (["lcet10.txt"], 4096),
     "plrabn12x4096": (["plrabn12.txt"], 4096),
     "mapsdatazrhx4096": (["mapsdatazrh"], 4096),
+    # small streams (a launch of many short messages): 47 / 69 / 425 compressed bytes
+    "quickfoxx16384": (["quickfox"], 16384),
+    "ukkonooax16384": (["ukkonooa"], 16384),
+    "monkeyx16384": (["monkey"], 16384),
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic

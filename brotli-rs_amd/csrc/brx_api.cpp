@@ -81,6 +81,7 @@ struct brx_ctx {
     uint32_t *d_defer = nullptr;
     size_t defer_cap = 0;
     const uint32_t *last_counter = nullptr; // counter line of the most recent launch (brx_last_timing(ctx, 2))
+    uint32_t tiny_bytes = BRX_TINY_STREAM_BYTES; // bring-up / A-B: BRX_TINY_BYTES
     bool no_defer = false; // bring-up / A-B (BRX_NO_DEFER=1): spilled meta-blocks stay in the regular kernel's C++ loop
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
@@ -191,6 +192,7 @@ static int ctx_init(brx_ctx *c, int device) {
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
         c->no_order = getenv("BRX_NO_ORDER") != nullptr;
         c->no_defer = getenv("BRX_NO_DEFER") != nullptr;
+        if ((e = getenv("BRX_TINY_BYTES")) != nullptr) c->tiny_bytes = (uint32_t)atoi(e);
         c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
         if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
         if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
@@ -392,6 +394,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     const size_t ring_slot = (size_t)(c->launch_seq++ % BRX_COUNTER_RING);
     a.work_counter = c->d_counters + ring_slot * 16u; // one 64-B line per launch
     // streams whose tables spill the regular LDS table memory go to the wide kernel (not in the resumable and bring-up modes)
+    a.tiny_bytes = c->tiny_bytes;
     a.defer = nullptr;
     a.defer_cap = 0;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;

@@ -31,6 +31,7 @@
 #endif
 #define BRX_TM_WORDS (1728u + BRX_LDS_GROW / 4u) // LDS table memory (prefix-code tables, context maps): 6 912 B at level 0
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
+#define BRX_TINY_STREAM_BYTES 128u // compressed streams up to this size run their commands in the C++ loop alone
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that
                                  // is still in flight lands before a flush, so no lag is needed)
@@ -91,6 +92,7 @@ struct BrxKernelArgs {
                             // kernel lists for the next level the streams whose tables spill its LDS table memory (and
                             // leaves them undecoded); the level-k kernel decodes exactly the streams of its list
     uint32_t defer_cap;
+    uint32_t tiny_bytes;    // compressed streams up to this size run their commands in the C++ loop alone (BRX_TINY_STREAM_BYTES)
     uint32_t sw_threshold;  // wider kernels: up to this many listed streams they run the sparse-launch build of the loop
     const BrxSlabPool *pool; // spill slabs
     unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr

@@ -1783,6 +1783,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         }
 #endif
         const u32 prof_on = a.debug != nullptr ? 1u : 0u;
+        const bool tiny = i1 - i0 <= (u64)a.tiny_bytes || i1 < i0;
         bool deferred = false;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
         u32 st = seg_frame();
@@ -1795,7 +1796,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 break;
             }
 #endif
-            if (a.debug_stop == 8u) { // bring-up: the C++ loop alone, whole meta-block per call
+            if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u)) {
+                // the C++ loop alone, whole meta-block per call: a bring-up mode, and the way of streams of a few dozen
+                // bytes (a handful of commands, e.g. the RLE-like fills of BASELINE configs 3 / 4): preparing the
+                // assembly loop's tables and handing over at every long copy costs more than it saves there
                 st = generic_commands(HC_WHOLE);
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
                 st = generic_commands(HC_START);

@@ -545,6 +545,17 @@ def test_no_defer_switch_keeps_spilled_meta_blocks_in_the_regular_kernel():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_tiny_streams_through_the_assembly_loop_too():
+    """Streams of <= 128 compressed bytes run their commands in the C++ loop alone (brx_device.h, BRX_TINY_STREAM_BYTES);
+    BRX_TINY_BYTES=0 sends them through the assembly loop like every other stream -- same parity subset, fresh process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BRX_TINY_BYTES="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     """lcet10.txt's tables (2 208 words) do not fit the regular kernel's 1 728 words of LDS table memory: the regular kernel
     drops such a stream at the spill and lists it, the wide-LDS kernel launched behind it decodes it from the start.  A
