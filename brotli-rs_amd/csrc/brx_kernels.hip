@@ -1669,11 +1669,24 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     const u32 n_streams = a.n;
     const bool sw_loop = a.loop_build != 0u;
 #endif
+    // Work queue.  A wave's FIRST stream is its workgroup index, no atomic: 4096 waves adding to one address from eight
+    // XCDs serialise at ~13 ns each (4096 EMPTY streams took 106 us that way, most of what config 3 took).  Later streams
+    // come from the counter (queue slot = grid size + ticket).  Measured and dropped: a plain device-scope load of the
+    // counter before the add (the contended line serves loads no faster), several slots per add after a tiny stream
+    // (with 2 x grid streams a quarter of the waves then does the whole second round).
+    bool first = true;
     for (;;) {
-        // Work queue.  Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right
-        // behind the lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63
-        // around both across the back edge -- they then spin in their own loop and never meet lane 0 again.
-        u32 sid = rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
+        u32 sid;
+        if (first) {
+            first = false;
+            sid = blockIdx.x;
+        } else {
+            if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
+            // Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right behind the
+            // lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63 around both
+            // across the back edge -- they then spin in their own loop and never meet lane 0 again.
+            sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
+        }
         if (sid >= n_streams) break;
 #if BRX_LEVEL > 0
         sid = rfl(my_list[sid]); // the streams the level below left to this one
