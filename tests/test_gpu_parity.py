@@ -121,6 +121,22 @@ def test_replicated_batch_matches_oracle(ctx):
         assert o == ref[n]
 
 
+def test_more_streams_than_waves_go_through_the_ticket_queue(ctx):
+    """A wave's first stream is its workgroup index; every further one is a ticket from the launch's counter.  11 000 short
+    streams of seven kinds (more than the 4096 waves of a full grid, in every chunk of the host path) plus a long one every
+    500: every output bit-exact, every status 0."""
+    names = ["quickfox_repeated", "backward65536", "x", "10x10y", "quickfox", "ukkonooa", "monkey"]
+    ref = {n: _read(n) for n in names + ["alice29.txt"]}
+    streams, exp = [], []
+    for i in range(11000):
+        n = "alice29.txt" if i % 500 == 499 else names[i % 7]
+        streams.append(_read(n + ".compressed"))
+        exp.append(n)
+    outs, status, out_len = ctx.decode_batch(streams, [len(ref[n]) + (i % 3) for i, n in enumerate(exp)])
+    assert not status.any()
+    assert all(o == ref[n] for o, n in zip(outs, exp))
+
+
 def test_differential_fuzz_against_oracle(ctx):
     """The reference's own practice (AFL) transplanted: bit-flipped / truncated fixtures, HIP path vs oracle:
     same status for every stream and same bytes whenever the status is 0."""
