@@ -808,6 +808,20 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
         o = o >= P ? o - P : o;
     }
     d.vfl = d.pos + d.a;
+    // Re-seed the ring with the last 2 KiB of the output = the last two blocks of the fill: their units are still in LDS
+    // (the period), so no store has to be waited for and nothing is read back from HBM.  Both blocks are read before the
+    // first is written: the writes cover the whole ring, the period included.
+    static_assert(BRX_RING_BYTES == 2048u, "periodic_fill re-seeds two 1 KiB blocks");
+    if (nblocks >= 2u) {
+        const u32 o1 = o >= step ? o - step : o + P - step;    // unit of block nblocks - 1
+        const u32 o0 = o1 >= step ? o1 - step : o1 + P - step; // unit of block nblocks - 2
+        const u32x4 q0 = *(const u32x4 *)&s.ring[(base + o0) & RMASK];
+        const u32x4 q1 = *(const u32x4 *)&s.ring[(base + o1) & RMASK];
+        const u32 off = d.pos - BRX_RING_BYTES + 16u * d.lane;
+        *(u32x4 *)&s.ring[(off + d.a) & RMASK] = q0;
+        *(u32x4 *)&s.ring[(off + 1024u + d.a) & RMASK] = q1;
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the stores are done before their bytes are read back
     for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) {
         const u32 off = d.pos - BRX_RING_BYTES + 1024u * j + 16u * d.lane;
