@@ -794,7 +794,7 @@ FI void bulk_copy_1k(Dec &d, Lds &s, u32 de) {
 // <= 1 KiB) ending at a 16-byte aligned cursor, every further 1 KiB block is 64 aligned 16-byte units of that period:
 // lane l reads its unit from the ring and stores it STRAIGHT to HBM -- no ring write, no flush read: one LDS read and
 // one 16 B/lane buffer store per KiB and wave (configs 3/4 of BASELINE.json run at the HBM write rate this way).
-// Afterwards the ring is re-seeded with the last 4 KiB of the output, read back from HBM.
+// Afterwards the ring is re-seeded with the last 2 KiB of the output: the fill's last two blocks, again from the period in LDS.
 FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
     flush_range(d, s, d.vfl, d.pos + d.a);                 // everything up to the cursor is in HBM now
     const u32 base = d.pos - P + d.a;                      // skewed ring coordinate of the period's first byte
