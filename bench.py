@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- decompressed MB/s of the batched Brotli decode hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher around it: starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+
+--gpus N with fewer than N visible GPUs, or under a launcher whose WORLD_SIZE differs from N, exits non-zero without a line.
 
 A "step" = one pass of the hot path (brx_decode_batch through the C ABI) over one batch of synthetic input
 already resident in HBM.  Workload at every N: BASELINE.json configs[1], "4096 x data/alice29.txt.compressed"
 PER GPU (weak scaling: independent streams shard across ranks with no data-path collective; the RCCL
 scatter/gather of SURVEY 8e lives in brotli-rs_amd/shard.py and is never inside `value`).  Prints ONE JSON line on
-rank 0.
+rank 0; next to `value` it carries `strong` (the same 4096-stream batch split over the N GPUs), `kernel_ms_per_rank`, and at
+N = 1 `copy_path` (the LZ77 copy path against the physical HBM roofline: far copies and the two fills of configs 3 / 4).
 """
 import argparse
 import json
@@ -22,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GOLD = os.path.join(ROOT, "tests", "golden", "data")
+STUB = os.environ.get("BRX_BENCH_STUB") == "1"  # CPU test of the launcher path only (tests/test_bench_launch.py)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 C5 = os.path.join(ROOT, "tests", "golden", "config5")
@@ -155,6 +159,128 @@ def libbrotlidec_rate(comp, expect, seconds=3.0):
         return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 and hand its exit code back.  Fewer than N visible devices is an error -- never an
+    N=1 number under an N-GPU label.  (BRX_BENCH_STUB=1: the CPU test of this launcher -- gloo, no GPU, a stand-in decode.)"""
+    import subprocess
+    if not STUB:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to print a number\n" % (args.gpus, have))
+            sys.exit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Batch:
+    """One synthetic batch resident on the device: stream i = fixture i mod K, each in its own region of the input blob,
+    distinct 16-byte aligned output slots."""
+
+    def __init__(self, torch, np, dev, fx, n):
+        self.fx, self.n, self.K = fx, n, len(fx)
+        K = self.K
+        self.cap = (max(len(e) for _, e in fx) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
+        self.lens = np.array([len(fx[i % K][0]) for i in range(n)], dtype=np.int64)
+        in_off_h = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(self.lens, out=in_off_h[1:])
+        if K == 1:
+            one = torch.frombuffer(bytearray(fx[0][0]), dtype=torch.uint8).to(dev)
+            self.blob = one.repeat(n).contiguous()
+        else:
+            parts = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev) for c, _ in fx]
+            self.blob = torch.cat([parts[i % K] for i in range(n)]).contiguous()
+        self.in_off = torch.from_numpy(in_off_h).to(dev)
+        self.out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * self.cap).contiguous()
+        self.out = torch.empty(n * self.cap, dtype=torch.uint8, device=dev)
+        self.out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        self.out_bytes = sum(len(fx[i % K][1]) for i in range(n))
+
+    def step(self, ctx, timing=False):
+        if STUB:  # (launcher test only) stand-in for the decode: the expected bytes into every slot
+            import torch
+            for k, (_, e) in enumerate(self.fx):
+                want = torch.frombuffer(bytearray(e), dtype=torch.uint8)
+                self.out.view(self.n, self.cap)[k::self.K, :len(e)] = want
+                self.out_len[k::self.K] = len(e)
+            self.status.zero_()
+            return
+        ctx.decode_batch_device(self.blob.data_ptr(), self.in_off.data_ptr(), self.n, self.out.data_ptr(), self.out_off.data_ptr(),
+                                self.out_len.data_ptr(), self.status.data_ptr(), timing=timing)
+
+    def verify(self, torch):
+        """status, lengths, and every stream's bytes (checksum of checksums by equality)"""
+        ok = bool((self.status == 0).all().item())
+        for k, (_, e) in enumerate(self.fx):
+            want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(self.out.device)
+            ok = ok and bool((self.out_len[k::self.K] == len(e)).all().item())
+            got = self.out.view(self.n, self.cap)[k::self.K, :len(e)]
+            ok = ok and bool((got == want.unsqueeze(0)).all().item())
+        return ok
+
+    def byte_model(self, which):
+        """bytes of one launch: 'alg' (in + out + window-copy bytes read + dictionary bytes read), 'rw' (physical:
+        in + out + every copied byte read from HBM) or 'w' (physical: in + out; the fill's source period stays in LDS)"""
+        import oracle_py
+        per = []
+        for c, e in self.fx:
+            st = oracle_py.decode(c, want_stats=True)[2]
+            per.append(len(c) + len(e) + {"alg": st["copy_bytes"] + st["dict_bytes"], "rw": st["copy_bytes"], "w": 0}[which])
+        return sum(per[i % self.K] for i in range(self.n))
+
+
+def timed_pass(ctx, batch, steps, warmup, barrier):
+    """W untimed steps, barrier + synchronize, exactly K timed steps (HIP events around each kernel, on the stream it is
+    launched on), barrier + synchronize.  Returns (wall seconds, kernel ms of every step)."""
+    for _ in range(warmup):
+        batch.step(ctx)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.step(ctx, timing=True)
+        kernel_ms.append(0.0 if STUB else ctx.last_timing_ms(1))
+    barrier()
+    return time.perf_counter() - t0, kernel_ms
+
+
+def copy_path(torch, np, dev, ctx, barrier, steps=5):
+    """The LZ77 copy path in the driver-run line (north_star: the copy at >= 40 % of HBM peak): three short runs with the
+    PHYSICAL bytes known by construction -- far copies HBM -> registers -> HBM (every copied byte read once), and the two
+    fills of BASELINE configs[2] / configs[3] (in + out only)."""
+    res = {}
+    for name in ("farcopy_1MiBx4096", "backward65536x4096", "quickfox_repeatedx8192"):
+        fixtures, n = WORKLOADS[name]
+        b = Batch(torch, np, dev, [load_fixture(f) for f in fixtures], n)
+        dt, kms = timed_pass(ctx, b, steps, 2, barrier)
+        ok = b.verify(torch)
+        kavg = sum(kms) / len(kms)
+        phys = b.byte_model(PHYSICAL_MODEL[name])
+        res[name] = {"kernel_ms_avg": round(kavg, 4), "steps": steps, "physical_bytes_per_launch": phys,
+                     "achieved_physical_GBs": round(phys / (kavg * 1e-3) / 1e9, 1),
+                     "frac_physical": round(phys / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "decompressed_MB_per_s": round(b.out_bytes * steps / dt / 1e6, 1),
+                     "physical_model": PHYSICAL_MODEL[name], "bit_exact": ok}
+        del b
+        torch.cuda.empty_cache()
+    res["frac_physical"] = res["farcopy_1MiBx4096"]["frac_physical"]
+    res["note"] = ("physical_model rw = input read + output written + every copied byte read from HBM; w = input read + output "
+                   "written (periodic fill, source period in LDS); peak %.0f GB/s" % HBM_PEAK_GBS)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,10 +289,14 @@ def main():
     ap.add_argument("--workload", default="alice29x4096", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-path", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also time the ragged gather of the outputs to rank 0 (N>1: always)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
 
     import numpy as np
     import torch
@@ -175,16 +305,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the line would carry the wrong n_gpus\n" % (args.gpus, world))
+        sys.exit(3)
+    if STUB:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
     else:
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, torch.cuda.device_count()))
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=dev)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
 
-    from brotli_rs_amd import brx
-    ctx = brx.Context(local_rank)
+    ctx = None
+    if not STUB:
+        from brotli_rs_amd import brx
+        ctx = brx.Context(local_rank)
 
     fixtures, n = WORKLOADS[args.workload]
     if args.streams:
@@ -192,67 +336,54 @@ def main():
     fx = [load_fixture(f) for f in fixtures]
     K = len(fx)
     comp, expect = fx[0]
-    cap = (max(len(e) for _, e in fx) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
-
-    # synthetic batch: stream i = fixture i mod K, each in its own HBM region, distinct output regions
-    lens = np.array([len(fx[i % K][0]) for i in range(n)], dtype=np.int64)
-    in_off_h = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(lens, out=in_off_h[1:])
-    if K == 1:
-        one = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
-        blob = one.repeat(n).contiguous()
-    else:
-        parts = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev) for c, _ in fx]
-        blob = torch.cat([parts[i % K] for i in range(n)]).contiguous()
-    in_off = torch.from_numpy(in_off_h).to(dev)
-    out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap).contiguous()
-    out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
-    out_len = torch.zeros(n, dtype=torch.int64, device=dev)
-    status = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-
-    def step(timing=False):
-        ctx.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
-                                out_len.data_ptr(), status.data_ptr(), timing=timing)
+    batch = Batch(torch, np, dev, fx, n)
+    if not STUB:
+        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        if not STUB:
+            ctx.synchronize()
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timing=True)  # HIP events around the kernel, on the stream it is launched on
-        kernel_ms.append(ctx.last_timing_ms(1))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def all_ranks(x):
+        if world == 1:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        return [float(v.item()) for v in ts]
+
+    dt, kernel_ms = timed_pass(ctx, batch, args.steps, args.warmup, barrier)
+    dt = max_over_ranks(dt)
+    kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
+    kavg_ranks = all_ranks(kavg)
 
     # The RCCL exchange around the decode, timed on its own AFTER the timed region -- never part of `value`:
     # compaction of the capacity slots + grouped send/recv of the ragged outputs to rank 0 (brotli-rs_amd/shard.py).
     gather_info = None
-    if world > 1 or args.gather:
+    if (world > 1 or args.gather) and not STUB:
         try:
             from brotli_rs_amd import shard
             if world == 1 and not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
                 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-            produced = torch.where(status == 0, out_len, torch.zeros_like(out_len))
+            produced = torch.where(batch.status == 0, batch.out_len, torch.zeros_like(batch.out_len))
             times = []
             for _ in range(3):
                 barrier()
                 tg = time.perf_counter()
-                cdata, coffs = shard.compact(out, out_off, produced)
-                full, offs_all, st_all = shard.gather_ragged(cdata, coffs, status, n * world, dst=0, device=dev)
+                cdata, coffs = shard.compact(batch.out, batch.out_off, produced, ctx=ctx)
+                full, offs_all, st_all = shard.gather_ragged(cdata, coffs, batch.status, n * world, dst=0, device=dev)
                 torch.cuda.synchronize()
                 if world > 1:
                     dist.barrier()
@@ -260,26 +391,34 @@ def main():
             g = min(times)
             gather_info = {"ms": round(g * 1e3, 3), "bytes_at_root": int(full.numel()) if full is not None else None,
                            "what": "device-side compaction + grouped send/recv of the ragged outputs to rank 0 (best of 3)"}
-            del full
+            del full, cdata
         except Exception as e:  # the gather must never take the decode measurement down with it
             gather_info = {"error": repr(e)[:200]}
 
-    # parity on the timed output: status, lengths, and every stream's bytes (checksum of checksums by equality)
-    ok = True
-    if args.verify:
-        ok = bool((status == 0).all().item())
-        for k, (_, e) in enumerate(fx):
-            want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(dev)
-            ok = ok and bool((out_len[k::K] == len(e)).all().item())
-            got = out.view(n, cap)[k::K, :len(e)]
-            ok = ok and bool((got == want.unsqueeze(0)).all().item())
+    # parity on the timed output
+    ok = batch.verify(torch) if args.verify else True
+
+    # Strong scaling, the metric as BASELINE.json words it ("a 4096-stream batch at 1/2/4/8 GPUs"): the SAME total batch
+    # split over the ranks, n / N streams per GPU.  At N = 1 it is the weak figure.  Never `value`.
+    strong = None
+    if world > 1:
+        ns = max(n // world, 1)
+        sb = Batch(torch, np, dev, fx, ns)
+        sdt, skms = timed_pass(ctx, sb, args.steps, 1, barrier)
+        sdt = max_over_ranks(sdt)
+        ok = ok and (sb.verify(torch) if args.verify else True)
+        strong = {"streams_total": ns * world, "streams_per_gpu": ns, "ms_per_step": round(sdt / args.steps * 1e3, 4),
+                  "value": round(float(sb.out_bytes) * world * args.steps / sdt / 1e6, 1), "unit": "MB/s",
+                  "kernel_ms_per_rank": [round(v, 4) for v in all_ranks(sum(skms) / len(skms))]}
+        del sb
     if world > 1:
         f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
 
     if rank == 0:
-        out_bytes_gpu = sum(len(fx[i % K][1]) for i in range(n))
+        out_bytes_gpu = batch.out_bytes
+        lens = batch.lens
         total_out = float(out_bytes_gpu) * world
         ms_per_step = dt / args.steps * 1e3
         value = total_out * args.steps / dt / 1e6
@@ -291,24 +430,38 @@ def main():
                           "streams_per_gpu": n,
                           "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
-               "bit_exact": ok}
+               "bit_exact": ok, "kernel_ms_per_rank": [round(v, 4) for v in kavg_ranks]}
+        if STUB:
+            res["stub"] = "BRX_BENCH_STUB=1: launcher test on CPU, the decode is a stand-in -- `value` means nothing"
+            res["data"] = "STUB"
+        if strong is None:
+            strong = {"streams_total": n, "streams_per_gpu": n, "ms_per_step": round(ms_per_step, 4), "value": round(value, 1),
+                      "unit": "MB/s", "note": "N = 1: the strong-scaling batch is the weak one"}
+        strong["what"] = ("the SAME %d-stream batch split over N GPUs (BASELINE.json's metric as worded).  One wavefront decodes one stream, so "
+                          "a GPU's time is bounded below by ONE stream alone (profiles/r03_sweep.txt: 256 .. 4096 x alice29 take 7.6 .. 10 ms): "
+                          "N GPUs buy at most that ratio on a 4096-stream batch; throughput scales with N only at >= 4096 streams per GPU "
+                          "(`value`, weak)" % strong["streams_total"])
+        res["strong"] = strong
         if gather_info:
             if "ms" in gather_info:
                 gather_info["decode_plus_gather_MB_per_s"] = round(total_out / (dt / args.steps + gather_info["ms"] * 1e-3) / 1e6, 1)
             res["gather"] = gather_info
+        if STUB:
+            print(json.dumps(res), flush=True)
+    if STUB:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 2)
+
+    if rank == 0:
         import oracle_py
         cb = None
         if not args.no_cpu_baseline:
             cb, _ = cpu_baseline(comp, expect, args.cpu_seconds)
         # ALGORITHMIC bytes per stream: compressed in + decompressed out + window-copy bytes read +
         # dictionary bytes read; per launch = summed over the streams of one GPU.
-        algs = []
-        for c, e in fx:
-            st = oracle_py.decode(c, want_stats=True)[2]
-            algs.append(len(c) + len(e) + st["copy_bytes"] + st["dict_bytes"])
-        alg_launch = sum(algs[i % K] for i in range(n))
+        alg_launch = batch.byte_model("alg")
         kms = sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else float("nan")
-        kavg = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg_launch / (kavg * 1e-3) / 1e9
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected by
         # tools/gpu_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command) and
@@ -332,11 +485,7 @@ def main():
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
         model = PHYSICAL_MODEL.get(args.workload)
         if model:  # physical HBM bytes known by construction ("report both")
-            phys = []
-            for c, e in fx:
-                st = oracle_py.decode(c, want_stats=True)[2]
-                phys.append(len(c) + len(e) + (st["copy_bytes"] if model == "rw" else 0))
-            phys_launch = sum(phys[i % K] for i in range(n))
+            phys_launch = batch.byte_model(model)
             res["roofline"]["physical_bytes_per_launch"] = phys_launch
             res["roofline"]["achieved_physical"] = round(phys_launch / (kavg * 1e-3) / 1e9, 1)
             res["roofline"]["frac_physical"] = round(phys_launch / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -346,10 +495,19 @@ def main():
             res["roofline"]["achieved_physical"] = round(traffic / (kavg * 1e-3) / 1e9, 1)
             res["roofline"]["frac_physical"] = round(traffic / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             res["roofline"]["physical_model"] = "PMC traffic (FETCH_SIZE + WRITE_SIZE)"
+    del batch
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if not args.no_copy_path and world == 1:
+            try:
+                res["copy_path"] = copy_path(torch, np, dev, ctx, barrier)
+            except Exception as e:  # never takes the headline down with it
+                res["copy_path"] = {"error": repr(e)[:200]}
         if cb and world == 1 and K == 1:
             # informational, never part of `value`: the same batch from pinned HOST buffers to pinned host buffers through the
             # C ABI's host-pointer path (the kernel reads the input and stores the output over PCIe while it decodes)
             try:
+                cap = (len(expect) + 15) & ~15
                 hin, hout = brx.host_alloc(len(comp) * n), brx.host_alloc(cap * n)
                 hin[:] = np.frombuffer(comp * n, dtype=np.uint8)
                 io = np.arange(n + 1, dtype=np.uint64) * len(comp)
@@ -382,9 +540,9 @@ def main():
             except Exception:
                 pass
     ctx.close()
-    if dist.is_initialized():
+    used_rccl = dist.is_initialized()
+    if used_rccl:
         dist.destroy_process_group()  # (RCCL prints its library path to stdout around here: the JSON line goes last)
-    used_rccl = "gather_info" in dir() and (world > 1 or args.gather)
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(res), flush=True)

@@ -61,6 +61,9 @@ def load_library():
     L.brx_generate_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                      ctypes.POINTER(_Opts)]
+    L.brx_compact_batch.restype = ctypes.c_int
+    L.brx_compact_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
     L.brx_status_str.restype = ctypes.c_char_p
     L.brx_status_str.argtypes = [ctypes.c_int32]
     L.brx_last_error.restype = ctypes.c_char_p
@@ -86,7 +89,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
-                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch"]
+                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch"]
 
 
 def status_str(code: int) -> str:
@@ -202,6 +205,12 @@ class Context:
         if rc != 0:
             raise BrxError("brx_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
 
+    def compact_batch_device(self, out_ptr, out_off_ptr, len_ptr, n, dst_ptr, dst_off_ptr, total, hip_stream=None):
+        """dst[dst_off[i] ..] = out[out_off[i] .. + len[i]) for the n streams of a decoded batch (device pointers)."""
+        rc = self._lib.brx_compact_batch(self._h, out_ptr, out_off_ptr, len_ptr, n, dst_ptr, dst_off_ptr, total, hip_stream)
+        if rc != 0:
+            raise BrxError("brx_compact_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+
     def last_timing_ms(self, which=1):
         return float(self._lib.brx_last_timing(self._h, which))
 
@@ -264,8 +273,9 @@ class Decompressor(io.RawIOBase):
     Semantics of `read` follow the reference's `impl Read` (src/lib.rs:2173-2193): n > 0 bytes, b"" at end of
     stream forever after, and an error carrying the reference's description string for invalid input --
     raised as ValueError here (the reference returns io::ErrorKind::InvalidData).  Differences, documented
-    in INTEGRATION.md: the inner reader is drained eagerly on the first read, and nothing is delivered for a
-    stream that fails (the reference delivers an unspecified prefix).
+    in INTEGRATION.md: the inner reader is drained eagerly on the first read; a stream that fails serves the bytes
+    decoded before the error first and raises afterwards (the reference delivers a prefix too).  The object
+    keeps its context alive; should the context be closed explicitly first, later reads raise BrxError.
     """
 
     def __init__(self, reader, ctx: Context = None):
@@ -283,8 +293,8 @@ class Decompressor(io.RawIOBase):
         stream then decodes all of them in one batch (many live Decompressors cost about one batch)."""
         if self._stream is None:
             data = self._reader.read() if hasattr(self._reader, "read") else bytes(self._reader)
-            ctx = self._ctx or default_context()
-            self._stream = self._lib.brx_stream_new(ctx._h, data, len(data))
+            self._ctx = self._ctx or default_context()  # (held: the context must outlive the stream object)
+            self._stream = self._lib.brx_stream_new(self._ctx._h, data, len(data))
             if not self._stream:
                 raise BrxError("brx_stream_new failed")
         return self

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_gen.hip", "brx_api.cpp"]
+SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
 DEPS = SOURCES + ["brx_device.h", "brx_hot.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
@@ -63,6 +63,8 @@ def _build_locked(verbose):
             f.write("// generated from brx_hot.S by build.py -- do not edit\n")
             f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
+    if os.environ.get("BRX_BRINGUP") == "1" or os.environ.get("BRX_PROF") == "1":
+        cmd.append("-DBRX_BRINGUP")  # bring-up: BRX_DEBUG_STATS / BRX_DEBUG_STOP=9 + BRX_DEBUG_DUMP (tools/gpu_dumps.sh, tools/span_stats.py)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
     cmd += ["-o", tmp]

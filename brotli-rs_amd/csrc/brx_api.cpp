@@ -80,6 +80,10 @@ struct brx_ctx {
     // right behind (BrxKernelArgs::defer): BRX_COUNTER_RING lists of defer_cap stream indices, one per launch in flight
     uint32_t *d_defer = nullptr;
     size_t defer_cap = 0;
+    // BRX_OPT_ORDER on the device path: the queue order of a launch lives in that launch's own slot of a ring (like its work
+    // counter and its defer lists), so overlapping calls on different HIP streams never share one
+    uint32_t *d_order = nullptr;
+    size_t order_cap = 0;
     const uint32_t *last_counter = nullptr; // counter line of the most recent launch (brx_last_timing(ctx, 2))
     uint32_t tiny_bytes = BRX_TINY_STREAM_BYTES; // bring-up / A-B: BRX_TINY_BYTES
     bool no_defer = false; // bring-up / A-B (BRX_NO_DEFER=1): spilled meta-blocks stay in the regular kernel's C++ loop
@@ -106,6 +110,8 @@ struct brx_ctx {
     size_t st_in_cap = 0, st_out_cap = 0, st_meta_cap = 0;
     // Read facade: streams created but not yet decoded (decoded together by the first read of any of them)
     std::vector<brx_stream *> pending;
+    // every live stream object of this context, bounded ones included: brx_ctx_destroy detaches them all
+    std::vector<brx_stream *> live;
 };
 
 extern "C" const char *brx_last_error(void) { return g_err.c_str(); }
@@ -158,6 +164,7 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->d_iac);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_defer);
+    (void)hipFree(c->d_order);
     (void)hipFree(c->d_pool);
     (void)hipFree(c->pool.bitmap);
     (void)hipFree(c->pool.slabs);
@@ -300,9 +307,10 @@ extern "C" void brx_ctx_destroy(brx_ctx *c) {
         std::vector<brx_stream *> orphans;
         {
             std::lock_guard<std::mutex> lk(c->mu);
-            orphans.swap(c->pending);
+            orphans.swap(c->live);
+            c->pending.clear();
         }
-        for (brx_stream *s : orphans) stream_detach(s);
+        for (brx_stream *s : orphans) stream_detach(s); // (bounded streams too: their device buffers go with the context)
     } catch (...) {
     }
     ctx_release(c);
@@ -365,6 +373,21 @@ static int ensure_defer(brx_ctx *c, uint32_t n) {
     return BRX_SUCCESS;
 }
 
+// Room for one queue order of n stream indices per launch in flight (BRX_OPT_ORDER, device path).
+static int ensure_order(brx_ctx *c, uint32_t n) {
+    if (c->d_order && c->order_cap >= n) return BRX_SUCCESS;
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->d_order);
+    c->d_order = nullptr;
+    c->order_cap = 0;
+    size_t cap = 4096;
+    while (cap < n) cap <<= 1;
+    hipError_t e = hipMalloc(&c->d_order, cap * 4u * BRX_COUNTER_RING);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "queue-order allocation failed", e);
+    c->order_cap = cap;
+    return BRX_SUCCESS;
+}
+
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
                   const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr,
@@ -405,15 +428,17 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         a.defer_cap = (uint32_t)c->defer_cap;
     }
     a.debug = nullptr;
+    a.dump = nullptr;
+    a.dump_interval = c->dump_interval;
+    a.dump_max = c->dump_max;
+#ifdef BRX_BRINGUP // (build.py with BRX_BRINGUP=1: per-stream statistics, LDS dumps for tools/asm_emu.py)
     unsigned long long *dbg = nullptr;
     if (c->debug_stats) {
         if (hipMalloc(&dbg, (size_t)n * 80) == hipSuccess) { (void)hipMemset(dbg, 0, (size_t)n * 80); a.debug = dbg; }
     }
-    a.dump = nullptr;
-    a.dump_interval = c->dump_interval;
-    a.dump_max = c->dump_max;
     const size_t dump_bytes = (16u + (size_t)c->dump_max * BRX_DUMP_WORDS) * 4u;
     if (c->dump_max && c->debug_stop == 9u && hipMalloc(&a.dump, dump_bytes) == hipSuccess) (void)hipMemset(a.dump, 0, 64);
+#endif
     a.t.dict = c->d_dict;
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
@@ -433,6 +458,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     HIP_TRY(hipEventRecord(c->ev_last, st));
     c->last_counter = a.defer != nullptr ? a.work_counter : nullptr;
     c->any_launch = true;
+#ifdef BRX_BRINGUP
     if (a.dump) { // bring-up: parked decoder states for tools/asm_emu.py
         (void)hipStreamSynchronize(st);
         std::vector<uint32_t> h(dump_bytes / 4u);
@@ -460,6 +486,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         }
         (void)hipFree(dbg);
     }
+#endif
     return BRX_SUCCESS;
 }
 
@@ -587,11 +614,12 @@ static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in
             std::vector<uint32_t> order(n);
             std::iota(order.begin(), order.end(), 0u);
             std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h[x + 1] - h[x] > h[y + 1] - h[y]; });
-            int rc0 = grow((uint8_t **)&c->st_meta, &c->st_meta_cap, (size_t)n * 4);
+            int rc0 = ensure_order(c, n);
             if (rc0) return rc0;
-            HIP_TRY(hipMemcpyAsync(c->st_meta, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+            uint32_t *slot = c->d_order + (size_t)(c->launch_seq % BRX_COUNTER_RING) * c->order_cap; // the slot launch() takes next
+            HIP_TRY(hipMemcpyAsync(slot, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st)); // (`order` is a local)
-            d_order = (const uint32_t *)c->st_meta;
+            d_order = slot;
         }
         if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
         int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order);
@@ -713,6 +741,27 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     BRX_GUARD_END(BRX_ERR_OUT_OF_MEMORY, BRX_ERR_HIP)
 }
 
+// ---- compaction of a decoded batch (brx_util.hip) ------------------------------------------------------------------------
+void brx_launch_compact(const void *src, const uint64_t *src_off, const uint64_t *len, void *dst, const uint64_t *dst_off,
+                        uint32_t n, uint64_t total, void *hip_stream);
+
+extern "C" int brx_compact_batch(brx_ctx *c, const uint8_t *out, const uint64_t *out_off, const uint64_t *len, uint32_t n,
+                                 uint8_t *dst, const uint64_t *dst_off, uint64_t total, void *hip_stream) {
+    BRX_GUARD_BEGIN
+    if (!c) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_compact_batch: ctx is NULL");
+    if (n == 0 || total == 0) return BRX_SUCCESS;
+    if (!out || !out_off || !len || !dst || !dst_off) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_compact_batch: NULL argument");
+    if ((total + 16383u) / 16384u > 0x7fffffffull) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_compact_batch: more than 32 TiB");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    brx_launch_compact(out, out_off, len, dst, dst_off, n, total, st);
+    HIP_TRY(hipGetLastError());
+    if (!hip_stream) HIP_TRY(hipStreamSynchronize(st));
+    return BRX_SUCCESS;
+    BRX_GUARD_END(BRX_ERR_OUT_OF_MEMORY, BRX_ERR_HIP)
+}
+
 extern "C" void *brx_host_alloc(size_t bytes) {
     void *p = nullptr;
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
@@ -796,11 +845,13 @@ static int bounded_step(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const size_t bufsize = (size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK;
-    if (s->pos - s->shift + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK > bufsize) {
+    if (s->pos - s->shift >= (uint64_t)BRX_BOUNDED_WINDOW + 16u) {
         // slide the window: keep the last BRX_BOUNDED_WINDOW bytes (every back-reference reaches at most that far); the
-        // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged
+        // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged.  The kernel
+        // pauses at an arbitrary command boundary, so the window may be over by 1..15 bytes: then nothing moves (a move by
+        // zero bytes would never end -- ADVICE r2) and cap_abs below leaves the slice that much less slack.
         const uint64_t new_shift = (s->pos - BRX_BOUNDED_WINDOW) & ~15ull;
-        const uint64_t delta = new_shift - s->shift, keep = s->pos - new_shift;
+        const uint64_t delta = new_shift - s->shift, keep = s->pos - new_shift; // delta >= 16
         for (uint64_t done = 0; done < keep; done += delta) { // forward, in pieces no longer than the move: no overlap
             const size_t piece = (size_t)std::min<uint64_t>(delta, keep - done);
             HIP_TRY(hipMemcpyAsync(s->d_buf + done, s->d_buf + delta + done, piece, hipMemcpyDeviceToDevice, c->stream));
@@ -830,14 +881,18 @@ static int bounded_step(brx_stream *s) {
 }
 
 static void stream_detach(brx_stream *s) {
+    bounded_release(s); // (while s->ctx still names the device)
     s->ctx = nullptr;
+    if (s->bounded && !s->finished && s->lib_rc == BRX_SUCCESS) s->lib_rc = BRX_ERR_INVALID_ARGUMENT;
     if (!s->decoded) {
         s->decoded = true;
         s->lib_rc = BRX_ERR_INVALID_ARGUMENT; // the context went away before the stream was read
     }
 }
 
-extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n) {
+// The mode is decided BEFORE the stream becomes visible to the context: a bounded stream never sits in `pending` (a
+// concurrent read of another stream would decode it in its batch and empty its input -- ADVICE r2).
+static brx_stream *stream_new_impl(brx_ctx *ctx, const uint8_t *in, size_t n, bool force_bounded) {
     BRX_GUARD_BEGIN
     if (!ctx || (n && !in)) {
         fail(BRX_ERR_INVALID_ARGUMENT, "brx_stream_new: bad argument");
@@ -847,12 +902,17 @@ extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n)
     s->ctx = ctx;
     try {
         s->in.assign(in, in + n);
-        s->bounded = n >= BRX_BOUNDED_THRESHOLD;
-        if (!s->bounded) {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            ctx->pending.push_back(s);
-        }
+        s->bounded = force_bounded || n >= BRX_BOUNDED_THRESHOLD;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->live.push_back(s);
+        if (!s->bounded) ctx->pending.push_back(s);
     } catch (...) {
+        try {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            auto &l = ctx->live;
+            l.erase(std::remove(l.begin(), l.end(), s), l.end());
+        } catch (...) {
+        }
         delete s;
         throw;
     }
@@ -860,19 +920,9 @@ extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n)
     BRX_GUARD_END(nullptr, nullptr)
 }
 
-extern "C" brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n) {
-    brx_stream *s = brx_stream_new(ctx, in, n);
-    if (s && !s->bounded) {
-        try {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            auto &p = ctx->pending;
-            p.erase(std::remove(p.begin(), p.end(), s), p.end());
-        } catch (...) {
-        }
-        s->bounded = true;
-    }
-    return s;
-}
+extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n) { return stream_new_impl(ctx, in, n, false); }
+
+extern "C" brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n) { return stream_new_impl(ctx, in, n, true); }
 
 // Decode every pending stream of the context in one batch; streams whose guessed capacity was too small go into
 // the next round with the size the kernel asked for (at least x4), up to the 4 GiB - 256 B per-stream limit.
@@ -992,10 +1042,12 @@ extern "C" void brx_stream_free(brx_stream *s) {
     if (!s) return;
     bounded_release(s);
     try {
-        if (s->ctx && !s->decoded) {
+        if (s->ctx) {
             std::lock_guard<std::mutex> lk(s->ctx->mu);
             auto &p = s->ctx->pending;
             p.erase(std::remove(p.begin(), p.end(), s), p.end());
+            auto &l = s->ctx->live;
+            l.erase(std::remove(l.begin(), l.end(), s), l.end());
         }
     } catch (...) {
     }

@@ -1809,7 +1809,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             continue;
         }
 #endif
+#ifdef BRX_BRINGUP // (BRX_BRINGUP=1 at build time: per-stream statistics and LDS dumps; not in the shipped library)
         const u32 prof_on = a.debug != nullptr ? 1u : 0u;
+#else
+        const u32 prof_on = 0u;
+#endif
         const bool tiny = i1 - i0 <= (u64)a.tiny_bytes || i1 < i0;
         bool deferred = false;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
@@ -1831,6 +1835,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
                 st = generic_commands(HC_START);
                 while (st == HC_CONTINUE) st = generic_commands(HC_RESUME_R1);
+#ifdef BRX_BRINGUP
             } else if (a.debug_stop == 9u) { // bring-up: as 7, and every dump_interval-th parked state that the assembly
                                              // loop could be entered with goes to a.dump (input of tools/asm_emu.py)
                 st = generic_commands(HC_START);
@@ -1848,6 +1853,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     k++;
                     st = generic_commands(HC_RESUME_R1);
                 }
+#endif
             } else {
                 // The assembly loop (brx_hot.S) with the C++ loop as its safety net.  The C++ side reads the first
                 // insert&copy symbol (exact end-of-input rules) and decides whether the meta-block qualifies; then

@@ -72,9 +72,11 @@ def scatter_ragged(data, offsets, src: int = 0, device=None):
     return mine, (table[a:b + 1] - table[a]).contiguous(), (a, b), n
 
 
-def compact(out, out_off, out_len):
-    """The decoded bytes of a shard without the slack of the capacity slots: (flat uint8 tensor, int64 offsets[n+1]),
-    computed on the device (one gather by index)."""
+def compact(out, out_off, out_len, ctx=None):
+    """The decoded bytes of a shard without the slack of the capacity slots: (flat uint8 tensor, int64 offsets[n+1]).
+    With a `brx.Context` and device tensors: one pass of `brx_compact_batch` (brx_util.hip) at HBM rate, no temporaries.
+    Otherwise (CPU tensors of the gloo tests, or no context at hand): a gather by index, done in pieces of <= 64 MiB so the
+    int64 index never costs more than ~1.5 GB whatever the shard's size."""
     n = out_len.numel()
     lens = out_len.to(torch.int64)
     offs = torch.zeros(n + 1, dtype=torch.int64, device=out.device)
@@ -83,9 +85,26 @@ def compact(out, out_off, out_len):
     total = int(offs[-1].item()) if n else 0
     if total == 0:
         return torch.empty(0, dtype=torch.uint8, device=out.device), offs
-    src_start = out_off[:-1].to(torch.int64)
-    idx = torch.repeat_interleave(src_start - offs[:-1], lens) + torch.arange(total, dtype=torch.int64, device=out.device)
-    return out[idx], offs
+    src_start = out_off[:-1].to(torch.int64).contiguous()
+    if ctx is not None and out.is_cuda:
+        dst = torch.empty(total, dtype=torch.uint8, device=out.device)
+        lens = lens.contiguous()
+        torch.cuda.synchronize(out.device)  # the library's stream is not ordered after torch's (brx.h)
+        ctx.compact_batch_device(out.data_ptr(), src_start.data_ptr(), lens.data_ptr(), n, dst.data_ptr(), offs.data_ptr(), total)
+        return dst, offs
+    dst = torch.empty(total, dtype=torch.uint8, device=out.device)
+    offs_h = offs.cpu().numpy()
+    piece = 64 << 20
+    i = 0
+    while i < n:
+        j = int(np.searchsorted(offs_h, offs_h[i] + piece, side="right")) - 1
+        j = min(max(j, i + 1), n)
+        p0, p1 = int(offs_h[i]), int(offs_h[j])
+        if p1 > p0:
+            idx = torch.repeat_interleave(src_start[i:j] - offs[i:j], lens[i:j]) + torch.arange(p0, p1, dtype=torch.int64, device=out.device)
+            dst[p0:p1] = out[idx]
+        i = j
+    return dst, offs
 
 
 def gather_ragged(data, offsets, status, n_total: int, dst: int = 0, device=None):
@@ -156,7 +175,7 @@ def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=No
     if k:
         decode_fn(shard, offs, k, out, out_off, out_len, status)
     produced = torch.where(status == 0, out_len, torch.zeros_like(out_len))  # a failed stream contributes no bytes
-    cdata, coffs = compact(out, out_off, produced)
+    cdata, coffs = compact(out, out_off, produced, ctx=getattr(decode_fn, "ctx", None))
     return gather_ragged(cdata, coffs, status, n, dst=src, device=dev)
 
 
@@ -185,4 +204,5 @@ def hip_decode_fn(ctx):
         ctx.decode_batch_device(in_t.data_ptr(), in_off_t.data_ptr(), n, out_t.data_ptr(), out_off_t.data_ptr(),
                                 out_len_t.data_ptr(), status_t.data_ptr())
         ctx.synchronize()
+    fn.ctx = ctx  # (decode_sharded compacts with the library's kernel when the decode is the HIP path)
     return fn

@@ -169,6 +169,17 @@ int brx_generate_batch(brx_ctx *ctx, const uint8_t *src, const uint64_t *src_off
                        const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
                        const brx_opts *opts);
 
+/* ---- the decoded bytes of a batch, back to back (device memory only) ------------------------------------
+ * brx_decode_batch leaves stream i in a slot sized for the worst case; whoever ships the results on (the ragged gather of
+ * SURVEY 8e, a writer of one concatenated file) wants them without the slack:
+ *   dst[dst_off[i] .. dst_off[i] + len[i])  =  out[out_off[i] .. out_off[i] + len[i])      for i < n
+ * `len` is brx_decode_batch's out_len (zero the entries of failed streams first); dst_off is its exclusive prefix sum
+ * (n entries, computed by the caller, e.g. torch.cumsum) and `total` its grand total.  All pointers are DEVICE memory.
+ * hip_stream NULL = the context's own stream and the call returns when the copy is done; otherwise it is enqueued.
+ * One pass at HBM rate (reads `total`, writes `total`); no reference counterpart (a `Decompressor` owns one stream). */
+int brx_compact_batch(brx_ctx *ctx, const uint8_t *out, const uint64_t *out_off, const uint64_t *len, uint32_t n,
+                      uint8_t *dst, const uint64_t *dst_off, uint64_t total, void *hip_stream);
+
 /* ---- Read-shaped stream facade (one object = one stream, like one reference Decompressor) ----------
  * brx_stream_new copies the compressed bytes and queues the stream on its context.  The first brx_stream_read of
  * ANY queued stream decodes ALL streams queued on that context in one batch (N live Decompressors cost about one

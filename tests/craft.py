@@ -557,3 +557,33 @@ def long_stream(seed, rounds, first=1 << 16, total=1 << 20, wbits=22):
             k = len(out) - base
             out += out[base:base + k]
     return b.bytes(), bytes(out)
+
+
+def odd_long_stream(seed, rounds, first=1 << 16, mib=4, tail=2, wbits=22):
+    """`rounds` x (an uncompressed meta-block of `first` random bytes + a compressed meta-block of copies: doubling to 1 MiB,
+    1 MiB copies up to `mib` MiB, then ONE copy of `tail` bytes): every round is mib MiB + tail bytes, so command
+    boundaries drift by `tail` bytes per round and the bounded-memory reader's window ends up over by a few bytes --
+    less than its 16-byte slide granularity (the case of ADVICE r2 on brx_api.cpp bounded_step).  Returns (stream, expected)."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    out = bytearray()
+    total = (mib << 20) + tail
+    for r in range(rounds):
+        data = rng.randbytes(first)
+        raw_block(b, data)
+        out += data
+        base = len(out) - first
+        n, cmds = first, []
+        while n < (1 << 20):
+            cmds.append((b"", n, n))
+            out += out[base:base + n]
+            n *= 2
+        while n < (mib << 20):
+            cmds.append((b"", 1 << 20, 1 << 20))
+            out += out[len(out) - (1 << 20):]
+            n += 1 << 20
+        cmds.append((b"", tail, 1 << 20))
+        out += out[len(out) - (1 << 20):len(out) - (1 << 20) + tail]
+        MetaBlock(cmds, mlen=total - first).emit(b, r == rounds - 1, 0)
+    return b.bytes(), bytes(out)

@@ -484,9 +484,10 @@ def test_crafted_transform_and_quirk_streams(ctx):
     streams = [s for _, s, _, _ in sets]
     cap = 1 << 16
     want = [oracle.decode(s, 0, cap=cap) for s in streams]
-    tids = set()
     for (name, s, st, exp), w in zip(sets, want):
         assert st is None or w[0] == st, name
+    # (that these streams reach every transform id 0..120 is a property of the streams, pinned from the oracle's trace by
+    # tests/test_craft.py::test_transform_census_covers_all_121_ids; here the HIP path is held to the oracle on all of them)
     outs, status, out_len = ctx.decode_batch(streams, cap)
     bad = [(sets[i][0], w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
            if w[0] != st or (st == 0 and o != w[1])]
@@ -634,8 +635,10 @@ def test_farcopy_streams(ctx):
             assert o == e
 
 
-def test_two_overlapping_device_batches_on_two_hip_streams(ctx):
-    """Three BRX_MEM_DEVICE calls on one context, enqueued back to back on three HIP streams without a host sync in
+@pytest.mark.parametrize("order", [False, True], ids=["caller_order", "longest_first"])
+def test_two_overlapping_device_batches_on_two_hip_streams(ctx, order):
+    """(order=True: BRX_OPT_ORDER on every call -- each launch keeps its queue order in its own slot)
+    Three BRX_MEM_DEVICE calls on one context, enqueued back to back on three HIP streams without a host sync in
     between: each launch has its own work counters and hand-over lists, spill slabs are claimed by the waves from the
     shared pool, the results must be those of the oracle."""
     import torch
@@ -660,7 +663,7 @@ def test_two_overlapping_device_batches_on_two_hip_streams(ctx):
         torch.cuda.synchronize()
         for n, cap, exp, blob, in_off, out_off, out, out_len, status, st in jobs:  # no sync between the two launches
             ctx.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
-                                    out_len.data_ptr(), status.data_ptr(), hip_stream=st.cuda_stream)
+                                    out_len.data_ptr(), status.data_ptr(), hip_stream=st.cuda_stream, order=order)
         for job in jobs:
             job[-1].synchronize()
         for n, cap, exp, blob, in_off, out_off, out, out_len, status, st in jobs:
@@ -878,3 +881,81 @@ def test_device_path_longest_first_order(ctx):
             o0 = int(out_off[4096 + i].item())
             assert hashlib.sha256(host[o0:o0 + (1 << 20)].tobytes()).hexdigest() == man[i % len(man)]["sha256"]
     assert times[True] < times[False] * 1.25, times
+
+
+def test_bounded_window_over_by_less_than_its_slide_granularity(ctx):
+    """ADVICE r2 (brx_api.cpp bounded_step): the kernel pauses at an arbitrary command boundary, so the first pause past
+    16 MiB can leave the window over by 1..15 bytes -- less than the 16-byte granularity it slides by.  A move by zero
+    bytes used to loop forever.  craft.odd_long_stream drifts its boundaries by 2 bytes per 4 MiB round (pauses at 4 MiB,
+    8 MiB + 2, 12 MiB + 4, 16 MiB + 6); plus a text-like stream of odd-sized commands when libbrotlienc is present."""
+    import sys
+    import craft
+    from brotli_rs_amd import brx
+    L = brx.load_library()
+    cases = [craft.odd_long_stream(3, 6), craft.odd_long_stream(4, 6, tail=7)]
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import brotli_enc
+    if brotli_enc.available():
+        rng = random.Random(11)
+        texts = [_read(n) for n in ("alice29.txt", "asyoulik.txt", "lcet10.txt", "plrabn12.txt")]
+        parts, total = [], 0
+        while total < (22 << 20):
+            t = rng.choice(texts)
+            a = rng.randrange(len(t) - 5000)
+            parts.append(t[a:a + rng.randrange(500, 5000)])
+            total += len(parts[-1])
+        text = b"".join(parts)
+        cases.append((brotli_enc.compress(text, quality=2, lgwin=22), text))
+    buf = (ctypes.c_ubyte * ((1 << 20) + 3))()
+    for comp, exp in cases:
+        h = L.brx_stream_new_bounded(ctx._h, comp, len(comp))
+        got, total = hashlib.sha256(), 0
+        while True:
+            n = L.brx_stream_read(h, buf, len(buf))
+            assert n >= 0, (n, total)
+            if n == 0:
+                break
+            got.update(bytes(memoryview(buf)[:n]))
+            total += n
+        L.brx_stream_free(h)
+        assert total == len(exp) and got.hexdigest() == hashlib.sha256(exp).hexdigest()
+
+
+def test_streams_outlive_their_context_safely():
+    """brx_ctx_destroy detaches EVERY live stream of the context, bounded ones included (they never sit in the
+    pending list): later reads fail with a library error instead of touching the freed context, and free is safe."""
+    from brotli_rs_amd import brx
+    L = brx.load_library()
+    comp = _read("alice29.txt.compressed")
+    c = brx.Context(0)
+    buf = (ctypes.c_ubyte * 4096)()
+    hb = L.brx_stream_new_bounded(c._h, comp, len(comp))
+    assert L.brx_stream_read(hb, buf, len(buf)) == 4096  # device buffers of the bounded stream are live
+    hb2 = L.brx_stream_new_bounded(c._h, comp, len(comp))  # never read
+    hp = L.brx_stream_new(c._h, comp, len(comp))           # pending, never read
+    c.close()
+    for h in (hb, hb2, hp):
+        assert L.brx_stream_read(h, buf, len(buf)) < -900
+        L.brx_stream_free(h)
+    # the Python facade holds its context
+    d = brx.Decompressor(io.BytesIO(comp), brx.Context(0))
+    assert d.read() == _read("alice29.txt")
+    d.close()
+
+
+def test_compact_batch_kernel_matches_the_gather_by_index(ctx):
+    """brx_compact_batch (brx_util.hip) against torch's gather by index: ragged lengths incl. empty streams, slots at
+    every 16-byte phase, pieces that straddle streams, one stream longer than several pieces."""
+    import torch
+    from brotli_rs_amd import shard
+    dev = torch.device("cuda:0")
+    rng = random.Random(5)
+    lens = [0, 1, 15, 16, 17, 0, 100000, 3, 16384, 16385, 70000] + [rng.randrange(0, 40000) for _ in range(300)] + [0, 0, 5]
+    caps = [l + rng.randrange(0, 40) for l in lens]
+    out_off = torch.tensor(np.concatenate([[0], np.cumsum(caps)]), dtype=torch.int64, device=dev)
+    out = torch.randint(0, 256, (int(out_off[-1].item()) + 1,), dtype=torch.uint8, device=dev)
+    out_len = torch.tensor(lens, dtype=torch.int64, device=dev)
+    a, a_off = shard.compact(out, out_off, out_len, ctx=ctx)
+    b, b_off = shard.compact(out, out_off, out_len)
+    assert torch.equal(a_off, b_off) and a.numel() == sum(lens)
+    assert torch.equal(a, b)

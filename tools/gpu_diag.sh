@@ -1,4 +1,5 @@
 #!/bin/bash
+BRX_BRINGUP=1 python brotli-rs_amd/build.py --force > /dev/null 2>&1  # statistics / LDS dumps are compiled out of the shipped library
 set -u
 G=tests/golden/data
 for f in monkey.compressed alice29.txt.compressed metablock_reset.compressed backward65536.compressed; do

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Bring-up: collect parked decoder states (whole-LDS dumps at command boundaries) for tools/asm_emu.py.
+"""(Needs the bring-up build of the library: BRX_BRINGUP=1 python brotli-rs_amd/build.py --force.)
+Bring-up: collect parked decoder states (whole-LDS dumps at command boundaries) for tools/asm_emu.py.
 Run on the GPU box:  python tools/gpu_dump.py <interval> <max> <out.bin> <stream files...>
 Each stream is decoded alone (batch of one) with the C++ command loop re-entered after every command
 (BRX_DEBUG_STOP=9); every interval-th parked state of an assembly-eligible meta-block is appended to out.bin."""

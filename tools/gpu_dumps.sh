@@ -1,5 +1,6 @@
 #!/bin/bash
 # Bring-up: C++-only command loops (parity subset) + whole-LDS state dumps for tools/asm_emu.py (run on the GPU box)
+BRX_BRINGUP=1 python brotli-rs_amd/build.py --force > /dev/null 2>&1  # statistics / LDS dumps are compiled out of the shipped library
 set -u
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Which command-loop path do the meta-blocks of a set of streams take (BRX_DEBUG_STATS counters)?"""
+"""(Needs the bring-up build of the library: BRX_BRINGUP=1 python brotli-rs_amd/build.py --force.)
+Which command-loop path do the meta-blocks of a set of streams take (BRX_DEBUG_STATS counters)?"""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""How much table memory do the meta-blocks of large high-quality streams need?  Runs a batch with BRX_NO_DEFER=1 and the
+"""(Needs the bring-up build of the library: BRX_BRINGUP=1 python brotli-rs_amd/build.py --force.)
+How much table memory do the meta-blocks of large high-quality streams need?  Runs a batch with BRX_NO_DEFER=1 and the
 bring-up statistics on and reads each stream's final spill-slab fill (scr_top, words beyond the regular 1 728 words of
 LDS table memory, of the stream's LAST meta-block that spilled).  One-off, GPU box."""
 import os
