@@ -434,7 +434,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
 #ifdef BRX_BRINGUP // (build.py with BRX_BRINGUP=1: per-stream statistics, LDS dumps for tools/asm_emu.py)
     unsigned long long *dbg = nullptr;
     if (c->debug_stats) {
-        if (hipMalloc(&dbg, (size_t)n * 80) == hipSuccess) { (void)hipMemset(dbg, 0, (size_t)n * 80); a.debug = dbg; }
+        if (hipMalloc(&dbg, (size_t)n * (80 + 256)) == hipSuccess) { (void)hipMemset(dbg, 0, (size_t)n * (80 + 256)); a.debug = dbg; }
     }
     const size_t dump_bytes = (16u + (size_t)c->dump_max * BRX_DUMP_WORDS) * 4u;
     if (c->dump_max && c->debug_stop == 9u && hipMalloc(&a.dump, dump_bytes) == hipSuccess) (void)hipMemset(a.dump, 0, 64);
@@ -474,14 +474,20 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     }
     if (dbg) {
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)n * 10);
-        (void)hipMemcpy(h.data(), dbg, (size_t)n * 80, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h((size_t)n * 42);
+        (void)hipMemcpy(h.data(), dbg, (size_t)n * (80 + 256), hipMemcpyDeviceToHost);
         static const char *nm[10] = {"hdr", "iac", "lit", "dist", "copy", "ncmd", "nlit", "fastmb", "total", "scr_top"};
         for (uint32_t i = 0; i < n && i < (c->debug_stats_all ? n : 2u); i++) {
             fprintf(stderr, "[brx stats] stream %u:", i);
             for (int q = 0; q < 10; q++) fprintf(stderr, " %s=%llu", nm[q], h[(size_t)i * 10 + q]);
             fprintf(stderr, "\n[brx stats] words:");
             for (int q = 0; q < 8; q++) fprintf(stderr, " %u %u", (unsigned)h[(size_t)i * 10 + q], (unsigned)(h[(size_t)i * 10 + q] >> 32));
+            fprintf(stderr, "\n[brx phases] cycles(visits):");
+            static const char *pn[16] = {"frame", "header", "gen_start", "gen_resume", "asm", "finish", "h_simple", "h_clcode", "h_clsyms",
+                                         "h_build", "h_cmsyms", "h_imtf", "h_other", "dec_load", "setup", "status"};
+            for (int q = 0; q < 16; q++)
+                if (h[(size_t)n * 10 + (size_t)i * 32 + 16 + q])
+                    fprintf(stderr, " %s=%llu(%llu)", pn[q], h[(size_t)n * 10 + (size_t)i * 32 + q], h[(size_t)n * 10 + (size_t)i * 32 + 16 + q]);
             fprintf(stderr, "\n");
         }
         (void)hipFree(dbg);

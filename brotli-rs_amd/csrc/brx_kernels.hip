@@ -70,10 +70,30 @@ __shared__ Lds g_lds;
 
 #define FI __device__ __attribute__((always_inline)) inline
 
+// Bring-up (BRX_BRINGUP=1 at build time): cycle timers of the phases of a stream, 32 slots per wave in an LDS array of their
+// own (128 B more per wave: 15 waves per CU instead of 16 -- a measuring build).  PT_BEGIN(t); ... PT_ADD(slot, t) adds the
+// cycles since the last mark to the slot (and counts the visit in slot + 16) and moves the mark.
+#ifdef BRX_BRINGUP
+__shared__ unsigned long long g_prof[32];
+#define PT_BEGIN(t) unsigned long long t = __builtin_readcyclecounter()
+#define PT_ADD(slot, t) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0u) { g_prof[slot] += n_ - t; g_prof[(slot) + 16] += 1ull; } t = __builtin_readcyclecounter(); } while (0)
+#else
+#define PT_BEGIN(t) do { } while (0)
+#define PT_ADD(slot, t) do { } while (0)
+#endif
+// slots: 0 seg_frame  1 cold_header  2 generic_commands(HC_START / whole)  3 generic_commands(resume)  4 asm_commands  5 seg_finish
+//        6 header: kind + simple code fields  7 header: 18-entry code-length code  8 header: code-length symbols  9 build_code
+//        10 context map symbols  11 inverse move-to-front  12 header: everything else (block types / counts / misc / entry)
+//        13 dec_load / dec_load_in  14 stream setup in the dispatcher  15 status store
+
 // ---- wave-level primitives ---------------------------------------------------------------------------
 FI u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 FI u32 rdl(u32 v, u32 lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane); }
 FI u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// vec with lane `lane` replaced by the wave-uniform `val` (a compare and a select: gfx9's v_writelane_b32 takes one SGPR
+// operand only, its lane select would have to travel through M0)
+FI u32 wrl(u32 val, u32 lane, u32 vec) { return threadIdx.x == lane ? val : vec; }
 
 // Closed-form code tables (spec section 5 / 6; reference src/lookuptable/mod.rs:59-123, src/lib.rs:962-976),
 // packed (base << 5) | extra_bits and held one entry per lane.
@@ -108,6 +128,7 @@ struct Dec {
     u32 cbase;
     u64 win;             // dwords ww, ww+1
     u32 ww;
+    u32 nav, hb_lastw, hb_lastmask; // header-path reader (hb_*): valid bits in `win`, the stream's last dword and its real bits
     // output side
     u8 *out;             // stream's output base
     __amdgpu_buffer_rsrc_t out_rsrc; // same, as a buffer resource: far back-references are buffer_load_ubyte
@@ -353,6 +374,24 @@ FI void dec_load(Dec &d, const Lds &s) {
     in_seek(d, get64(s, 3));
 }
 
+// The header path (cold_header) needs the input cursor and the table memory, nothing of the output side: loading and
+// storing only those keeps ~30 wave-uniform values out of its register allocation (with all of Dec live from dec_load to
+// dec_store LLVM spilled SGPRs into VGPR lanes all over the header code: 187 spill writes / 412 reloads, r02 build).
+FI void dec_load_in(Dec &d, const Lds &s) {
+    d.lane = threadIdx.x;
+    d.in_words = (const u32 *)(uintptr_t)get64(s, 0); d.w_end = rfl(s.st[2]);
+    d.bitend = get64(s, 5);
+    d.lds_top = rfl(s.st[18]); d.scr_top = rfl(s.st[19]); d.scratch = (u32 *)(uintptr_t)get64(s, 20);
+    d.pool = (const BrxSlabPool *)(uintptr_t)get64(s, ST_POOL);
+    d.cbase = 0xffffff00u; // force a re-stage of the input chunks
+    d.chunkA = 0; d.chunkB = 0;
+    in_seek(d, get64(s, 3));
+}
+FI void dec_store_in(const Dec &d, Lds &s) {
+    put64(s, 3, d.bitpos);
+    s.st[18] = d.lds_top; s.st[19] = d.scr_top; put64(s, 20, (u64)(uintptr_t)d.scratch);
+}
+
 // ---- prefix codes ----------------------------------------------------------------------------------------
 // Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols in (length, symbol)
 // order -- as u16 (literal, insert&copy, block-type / block-count / context-map codes) or as u32 (distance codes, WIDE).
@@ -409,67 +448,141 @@ FI u32 decode_sym_wide(Dec &d, const Lds &s, u32 h, u32 &sym) {
     return decode_sym_as<false, true>(d, s, h, sym);
 }
 
-// Build a general code from s.lens[0..n) (canonical assignment, reference src/huffman/mod.rs:19-43; the
-// bl_count[0] quirk Q7 vanishes under the reference's own masking of the code to `len` bits).
+// ---- the header path's bit reader ----------------------------------------------------------------------------
+// Everything between MLEN and the first command (cold_header) reads its bits through hb_*: a 64-bit window with >= 32
+// valid bits, refilled a dword at a time, over the input PADDED WITH ZEROS behind its last real bit -- and never checks
+// for the end of the input per field.  One check at the end (and at every error exit) restores the reference's
+// behaviour exactly: each read of the header fails in exactly one way when the bits run out -- UnexpectedEOF (every
+// `?` on a bit read in src/lib.rs:501-1177, the Ok(None) arms of the lookups) -- and a prefix-code lookup is decided by the
+// bits it consumes, never by the ones it only peeks at.  So up to the first read that crosses the end both readers see the
+// same bits and make the same decisions; the exact reader then stops with UnexpectedEOF; this one runs on over zeros
+// (every loop of the header is bounded by an alphabet size or a declared count) and finds cursor > end afterwards.
+FI u32 hb_word(Dec &d, u32 w) {
+    const u32 v = in_word(d, w); // (0 from the stream's last dword on)
+    return w == d.hb_lastw ? v & d.hb_lastmask : v;
+}
+FI void hb_begin(Dec &d) { // from the exact reader's cursor d.bitpos
+    const u32 w = (u32)(d.bitpos >> 5), sh = (u32)d.bitpos & 31u;
+    d.hb_lastw = (u32)((d.bitend - 1ull) >> 5);
+    const u32 r = (u32)d.bitend & 31u;
+    d.hb_lastmask = r ? (1u << r) - 1u : 0xffffffffu;
+    const u64 lo = hb_word(d, w), hi = hb_word(d, w + 1u);
+    d.win = (lo | (hi << 32)) >> sh;
+    d.nav = 64u - sh;
+    d.ww = w + 2u; // the next dword to enter the window
+}
+FI u64 hb_pos(const Dec &d) { return 32ull * d.ww - d.nav; }
+FI bool hb_over(const Dec &d) { return hb_pos(d) > d.bitend; }
+FI u32 hb_peek(const Dec &d) { return (u32)d.win; } // 32 valid bits
+FI void hb_skip(Dec &d, u32 n) { // n <= 32
+    d.win >>= n;
+    d.nav -= n;
+    if (d.nav < 32u) {
+        d.win |= (u64)hb_word(d, d.ww) << d.nav;
+        d.nav += 32u;
+        d.ww += 1u;
+    }
+}
+FI u32 hb_bits(Dec &d, u32 n) { // n <= 24
+    const u32 v = hb_peek(d) & ((1u << n) - 1u);
+    hb_skip(d, n);
+    return v;
+}
+
+// inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1 / 2 / 4 / 8, zeros shifted in)
+FI u32 row_scan_add(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    return x;
+}
+// lanes below this one whose bit is set in the wave mask m
+FI u32 lanes_below(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+
+// The 32 header words of a general code from its length histogram: lane L (1..15) passes the number of length-L codes in
+// `cnt` (other lanes: anything).  Canonical assignment, reference src/huffman/mod.rs:19-43 (the bl_count[0] quirk Q7
+// vanishes under the reference's own masking of the code to `len` bits), as two prefix sums over the lanes:
+//   limit[L] = (first_code[L] + count[L]) << (15 - L) = sum over k <= L of count[k] << (15 - k)     (the Kraft sum)
+//   base[L]  = offset[L] - first_code[L],  offset[L] = sum over k < L of count[k]
+// Allocates the table (header + `nnz` symbol entries), stores the header, returns h; off = offset[L] in lane L.
 // Precondition (checked by the callers like the reference does): Kraft sum <= 1, at least 2 non-zero lengths.
+FI u32 emit_code_header(Dec &d, Lds &s, u32 cnt, const bool wide, u32 &off) {
+    const u32 lane = d.lane, L = lane & 15u;
+    const u32 c = (lane - 1u) < 15u ? cnt : 0u;
+    const u32 lim = row_scan_add(c << (15u - L));
+    const u32 offi = row_scan_add(c);
+    off = offi - c;
+    const u32 base = off - ((lim >> (15u - L)) - c);
+    const u32 nnz = rdl(offi, 15);
+    const u32 maxlen = 63u - (u32)__builtin_clzll(ballot(c != 0u) | 1ull);
+    const u32 h = tm_alloc(d, BRX_HDR_WORDS + (wide ? nnz : ((nnz + 1u) >> 1)));
+    const u32 w0 = lane == 0u ? 0u : lim << 16;                              // header[2L]
+    const u32 w1 = lane == 0u ? (2u | (maxlen << 8) | (nnz << 16)) : base;  // header[2L + 1]; header[1] = kind | max_len | symbols
+    if (h < BRX_TM_WORDS) { if (lane < 16u) { tm_st32<true>(d, s, h + 2u * lane, w0); tm_st32<true>(d, s, h + 2u * lane + 1u, w1); } }
+    else { if (lane < 16u) { tm_st32<false>(d, s, h + 2u * lane, w0); tm_st32<false>(d, s, h + 2u * lane + 1u, w1); } }
+    return h;
+}
+FI void code_put_symbol(const Dec &d, Lds &s, u32 h, const bool wide, bool on, u32 slot, u32 sym) {
+    if (wide) {
+        if (h < BRX_TM_WORDS) { if (on) tm_st32<true>(d, s, h + BRX_HDR_WORDS + slot, sym); }
+        else { if (on) tm_st32<false>(d, s, h + BRX_HDR_WORDS + slot, sym); }
+    } else {
+        if (h < BRX_TM_WORDS) { if (on) tm_st16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, sym); }
+        else { if (on) tm_st16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, sym); }
+    }
+}
+
+// Build a general code from s.lens[0..n).  Lane-parallel: the histogram is one LDS atomic per 64 symbols, the header two
+// prefix sums (emit_code_header), and a symbol's place in the (length, symbol)-sorted list is
+//   running offset of its length  +  number of lower lanes of its chunk with the same length
+// (four ballots of the length's bits give every lane the mask of its peers; the running offsets live in LDS and move by one
+// atomic add per chunk).  16 words behind the longest alphabet (704) serve as the histogram / the running offsets.
 FI u32 build_code(Dec &d, Lds &s, u32 n, const bool wide = false) {
     const u32 lane = d.lane;
-    u32 cnt = 0; // lane L: number of codes of length L
-    for (u32 c = 0; c < n; c += 64u) {
-        u32 i = c + lane;
-        u32 my = i < n ? s.lens[i] : 0u;
-        u64 any = ballot(my != 0u);
-        if (any == 0ull) continue;
-        for (u32 l = 1; l <= 15u; l++) {
-            u64 m = ballot(my == l);
-            if (lane == l) cnt += (u32)__builtin_popcountll(m);
-        }
+    u32 *const cnt = (u32 *)&s.lens[704];
+    if (lane < 16u) cnt[lane] = 0u;
+    const u32 nch = (n + 63u) >> 6;
+    for (u32 c = 0; c < nch; c++) {
+        const u32 i = c * 64u + lane;
+        const u32 my = i < n ? s.lens[i] : 0u;
+        __hip_atomic_fetch_add(&cnt[my], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (zeros count into cnt[0]: never read)
     }
-    u32 code = 0, off = 0, hv = 0, offv = 0, maxlen = 0, present = 0;
-    for (u32 l = 1; l <= 15u; l++) {
-        u32 c = rdl(cnt, l);
-        u32 limit = (code + c) << (15u - l);
-        if (lane == 2u * l) hv = limit << 16;
-        if (lane == 2u * l + 1u) hv = off - code; // base[l]
-        if (lane == l) offv = off;
-        if (c) {
-            maxlen = l;
-            present |= 1u << l;
-        }
-        off += c;
-        code = (code + c) << 1;
+    u32 off;
+    const u32 h = emit_code_header(d, s, cnt[lane & 15u], wide, off);
+    if (lane < 16u) cnt[lane] = off;
+    for (u32 c = 0; c < nch; c++) {
+        const u32 i = c * 64u + lane;
+        const u32 my = i < n ? s.lens[i] : 0u;
+        if (ballot(my != 0u) == 0ull) continue;
+        const u64 b0 = ballot((my & 1u) != 0u), b1 = ballot((my & 2u) != 0u), b2 = ballot((my & 4u) != 0u), b3 = ballot((my & 8u) != 0u);
+        u64 eq = (my & 1u) ? b0 : ~b0;
+        eq &= (my & 2u) ? b1 : ~b1;
+        eq &= (my & 4u) ? b2 : ~b2;
+        eq &= (my & 8u) ? b3 : ~b3;
+        const u32 slot = cnt[my] + lanes_below(eq);
+        code_put_symbol(d, s, h, wide, my != 0u, slot, i);
+        __hip_atomic_fetch_add(&cnt[my], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    u32 nnz = off;
-    u32 h = tm_alloc(d, BRX_HDR_WORDS + (wide ? nnz : ((nnz + 1u) >> 1)));
-    if (lane == 1u) hv = 2u | (maxlen << 8) | (nnz << 16); // header[1]: kind | max_len | number of symbols
-    const bool inl = h < BRX_TM_WORDS;
-    if (inl) { if (lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + lane, hv); }
-    else { if (lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + lane, hv); }
-    const u64 lt = (1ull << lane) - 1ull;
-    for (u32 c = 0; c < n; c += 64u) {
-        u32 i = c + lane;
-        u32 my = i < n ? s.lens[i] : 0u;
-        u64 any = ballot(my != 0u);
-        if (any == 0ull) continue;
-        u32 slot = 0xffffffffu; // this lane's position in the sorted symbol list
-        u32 pr = present;
-        while (pr) {
-            u32 l = (u32)__builtin_ctz(pr);
-            pr &= pr - 1u;
-            u64 m = ballot(my == l);
-            if (m == 0ull) continue;
-            u32 run = rdl(offv, l);
-            if (my == l) slot = run + (u32)__builtin_popcountll(m & lt);
-            if (lane == l) offv += (u32)__builtin_popcountll(m);
-        }
-        if (wide) {
-            if (inl) { if (slot != 0xffffffffu) tm_st32<true>(d, s, h + BRX_HDR_WORDS + slot, i); }
-            else { if (slot != 0xffffffffu) tm_st32<false>(d, s, h + BRX_HDR_WORDS + slot, i); }
-        } else {
-            if (inl) { if (slot != 0xffffffffu) tm_st16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
-            else { if (slot != 0xffffffffu) tm_st16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + slot, i); }
-        }
-    }
+    return h;
+}
+
+// A simple prefix code of 2..4 symbols (src/lib.rs:597-665): the same table from the (length, symbol) pairs directly --
+// no pass over the alphabet.  Within one length the symbols go in ascending order (what the reference's insertion order
+// amounts to in every NSYM case), so the list is the pairs sorted by (length, symbol).
+FI u32 build_simple(Dec &d, Lds &s, u32 nsym, u32 k0, u32 k1, u32 k2, u32 k3, const bool wide) { // k = length << 16 | symbol
+    if (nsym < 3u) k2 = 0xffffffffu;
+    if (nsym < 4u) k3 = 0xffffffffu;
+    u32 t;
+#define BRX_CSWAP(a, b) do { t = a < b ? a : b; b = a < b ? b : a; a = t; } while (0)
+    BRX_CSWAP(k0, k1); BRX_CSWAP(k2, k3); BRX_CSWAP(k0, k2); BRX_CSWAP(k1, k3); BRX_CSWAP(k1, k2);
+#undef BRX_CSWAP
+    const u32 lane = d.lane;
+    const u32 cnt = (u32)((k0 >> 16) == lane) + (u32)((k1 >> 16) == lane) + (u32)((k2 >> 16) == lane) + (u32)((k3 >> 16) == lane);
+    u32 off;
+    const u32 h = emit_code_header(d, s, cnt, wide, off);
+    const u32 mine = lane == 0u ? k0 : lane == 1u ? k1 : lane == 2u ? k2 : k3;
+    code_put_symbol(d, s, h, wide, lane < nsym, lane, mine & 0xffffu);
     return h;
 }
 
@@ -486,42 +599,25 @@ FI void lens_clear(const Dec &d, Lds &s, u32 n) {
 }
 
 // parse_complex_prefix_code, src/lib.rs:667-875 (Q6, Q15): code-length code over {0..17}, then the lengths.
-// Fills s.lens[0..alphabet); the caller builds the table.
-FI u32 read_complex_lens(Dec &d, Lds &s, u32 kind, u32 alphabet) {
-    u32 v;
-    const u32 hskip = kind;
-    u32 cl_lo = 0, cl_hi = 0; // 18 x 3-bit code lengths packed: symbols 0..9 in cl_lo, 10..17 in cl_hi
+// Fills s.lens[0..alphabet); the caller builds the table.  (hb_* reader: no end-of-input tests here, see above.)
+FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
+    PT_BEGIN(pt);
+    const u32 lane = d.lane;
+    u32 clv = 0; // lane sy < 18: length of code-length symbol sy
     u32 sum = 0, nonzero = 0, single = 0;
     // order of transmission: 1,2,3,4,0,5,17,6,16,7,8,...,15 (src/lib.rs:669)
-    const u64 ORDER = 0xfedcba987ull;        // symbols 7..15 for positions 9..17
     for (u32 i = hskip; i < 18u; i++) {
         // fixed code (src/lib.rs:120-125), stream order: 00->0 01->3 10->4 110->2 1110->1 1111->5
-        u64 rem = in_remaining(d);
-        u32 p = in_peek_raw(d) & 15u;
+        const u32 p = hb_peek(d) & 15u;
         u32 len, val;
         if ((p & 1u) == 0u) { len = 2; val = (p & 2u) ? 3u : 0u; }
         else if ((p & 2u) == 0u) { len = 2; val = 4u; }
         else if ((p & 4u) == 0u) { len = 3; val = 2u; }
         else { len = 4; val = (p & 8u) ? 5u : 1u; }
-        // bits beyond the end may be garbage; the reference would hit EOF while walking: the walk reads
-        // exactly `len` bits when they exist.  With fewer real bits than the shortest consistent code it fails.
-        if (rem < 4u) {
-            // re-derive with only `rem` real bits: a code of length len needs len bits
-            u32 pm = p & ((1u << (u32)rem) - 1u);
-            u32 need;
-            if (rem < 2u) need = 2;
-            else if ((pm & 1u) == 0u) need = 2;
-            else if ((pm & 2u) == 0u) need = 2;
-            else if (rem < 3u) need = 3;
-            else if ((pm & 4u) == 0u) need = 3;
-            else need = 4;
-            if ((u64)need > rem) return ST_EOF;
-        }
-        in_consume(d, len);
-        u32 symi = i < 4u ? i + 1u : i == 4u ? 0u : i == 5u ? 5u : i == 6u ? 17u : i == 7u ? 6u : i == 8u ? 16u
-                   : (u32)((ORDER >> (4u * (i - 9u))) & 15u);
+        hb_skip(d, len);
         if (val) {
-            if (symi < 10u) cl_lo |= val << (3u * symi); else cl_hi |= val << (3u * (symi - 10u));
+            const u32 symi = i < 4u ? i + 1u : i == 4u ? 0u : i == 5u ? 5u : i == 6u ? 17u : i == 7u ? 6u : i == 8u ? 16u : i - 2u;
+            clv = wrl(val, symi, clv);
             sum += 32u >> val;
             nonzero++;
             single = symi;
@@ -532,64 +628,66 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 kind, u32 alphabet) {
     if (nonzero == 0u) return ST_NO_CODE_LENGTH;
     if (nonzero >= 2u && sum < 32u) return ST_CODE_LENGTHS_CHECKSUM;
 
-    // 5-bit lookup table for the code-length code, one entry per lane (lanes 0..31): (symbol << 4) | len
+    // 5-bit lookup table for the code-length code, one entry per lane (lanes 0..31): (symbol << 4) | len.  Canonical codes
+    // lane-parallel: lane sy's code = first code of its length + the number of lower symbols of the same length.
     u32 cltab = 0;
     if (nonzero >= 2u) {
-        u32 cp = 0; // 6 x 5-bit counts per length
-        for (u32 sy = 0; sy < 18u; sy++) {
-            u32 l = sy < 10u ? (cl_lo >> (3u * sy)) & 7u : (cl_hi >> (3u * (sy - 10u))) & 7u;
-            cp += 1u << (5u * l);
+        const u32 l = lane < 18u ? clv : 0u;
+        const u64 b0 = ballot((l & 1u) != 0u), b1 = ballot((l & 2u) != 0u), b2 = ballot((l & 4u) != 0u);
+        u64 eq = (l & 1u) ? b0 : ~b0;
+        eq &= (l & 2u) ? b1 : ~b1;
+        eq &= (l & 4u) ? b2 : ~b2;
+        const u32 rank = lanes_below(eq);
+        u32 code = 0, mycode = 0;
+        for (u32 k = 1; k <= 5u; k++) { // first code of each length (lengths 1..5: the fixed code's values)
+            if (l == k) mycode = code + rank;
+            const u64 mk = ((k & 1u) ? b0 : ~b0) & ((k & 2u) ? b1 : ~b1) & ((k & 4u) ? b2 : ~b2);
+            code = (code + (u32)__builtin_popcountll(mk)) << 1;
         }
-        u64 np = 0; // next canonical code per length, 8 bits each
-        u32 code = 0;
-        for (u32 l = 1; l <= 5u; l++) {
-            code = (code + (l == 1u ? 0u : (cp >> (5u * (l - 1u))) & 31u)) << 1;
-            np |= (u64)code << (8u * l);
-        }
-        for (u32 sy = 0; sy < 18u; sy++) {
-            u32 l = sy < 10u ? (cl_lo >> (3u * sy)) & 7u : (cl_hi >> (3u * (sy - 10u))) & 7u;
-            if (l == 0u) continue;
-            u32 cd = (u32)(np >> (8u * l)) & 255u;
-            np += 1ull << (8u * l);
-            u32 rev = __brev(cd) >> (32u - l);
-            if ((d.lane & ((1u << l) - 1u)) == rev) cltab = (sy << 4) | l;
+        const u32 rev = l ? __brev(mycode) >> (32u - l) : 0u;
+        u64 todo = ballot(l != 0u);
+        while (todo) { // every used symbol claims the table entries whose low `length` bits are its (bit-reversed) code
+            const u32 sy = (u32)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const u32 ls = rdl(l, sy), rs = rdl(rev, sy);
+            if ((lane & ((1u << ls) - 1u)) == rs) cltab = (sy << 4) | ls;
         }
     }
 
     lens_clear(d, s, alphabet);
+    PT_ADD(7, pt);
+    // The lengths themselves.  The 64 lengths of the chunk being decoded collect in the lanes of `cur` (v_writelane) and go
+    // to s.lens with one byte store per lane when the chunk is left.
     u32 total = 0, i = 0, nz = 0;
     u32 last_symbol = 0xffu, last_repeat = 0, last_nz = 8;
+    u32 cur = 0;
+    bool dirty = false;
+#define BRX_LENS_FLUSH(base_) do { if (dirty) s.lens[(base_) + lane] = (u8)cur; cur = 0u; dirty = false; } while (0)
     while (i < alphabet) {
         u32 sym;
         if (nonzero == 1u) {
             sym = single; // single-symbol code: zero bits (Q5)
         } else {
-            u64 rem = in_remaining(d);
-            u32 e = rdl(cltab, in_peek_raw(d) & 31u);
-            u32 l = e & 15u;
-            if (rem < 5u) { // garbage-safe: decide with the real bits only
-                u32 pm = in_peek_raw(d) & ((1u << (u32)rem) - 1u);
-                e = rdl(cltab, pm);
-                l = e & 15u;
-                if ((u64)l > rem) return ST_EOF;
-            }
+            const u32 e = rdl(cltab, hb_peek(d) & 31u);
             sym = e >> 4;
-            in_consume(d, l);
+            hb_skip(d, e & 15u);
         }
         if (sym <= 15u) {
-            if (d.lane == 0u) s.lens[i] = (u8)sym;
+            cur = wrl(sym, i & 63u, cur);
             i++;
             last_symbol = sym;
             last_repeat = 0;
             if (sym) {
+                dirty = true;
                 nz++;
                 last_nz = sym;
                 total += 32768u >> sym;
                 if (total == 32768u) break;
                 if (total > 32768u) return ST_CODE_LENGTHS_CHECKSUM;
             }
+            if ((i & 63u) == 0u) BRX_LENS_FLUSH(i - 64u);
         } else if (sym == 16u) {
-            if (!in_bits(d, 2, v)) return ST_EOF;
+            const u32 v = hb_bits(d, 2);
             u32 add, new_repeat;
             if (last_symbol == 16u && last_repeat) {
                 new_repeat = 4u * (last_repeat - 2u) + v + 3u;
@@ -599,83 +697,90 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 kind, u32 alphabet) {
                 add = new_repeat;
             }
             if (i + add > alphabet) return ST_PARSE_COMPLEX_LENGTHS;
-            for (u32 k = d.lane; k < add; k += 64u) s.lens[i + k] = (u8)last_nz;
-            i += add;
             nz += add;
             total += add * (32768u >> last_nz);
+            for (u32 left = add; left != 0u;) { // the run, chunk by chunk
+                const u32 a0 = i & 63u, k = left < 64u - a0 ? left : 64u - a0;
+                cur = (lane - a0) < k ? last_nz : cur;
+                dirty = true;
+                i += k;
+                left -= k;
+                if ((i & 63u) == 0u) BRX_LENS_FLUSH(i - 64u);
+            }
             if (total == 32768u) break;
             if (total > 32768u) return ST_CODE_LENGTHS_CHECKSUM;
             last_repeat = new_repeat;
             last_symbol = 16u;
         } else {
-            if (!in_bits(d, 3, v)) return ST_EOF;
+            const u32 v = hb_bits(d, 3);
+            u32 ni;
             if (last_symbol == 17u && last_repeat) {
-                u32 new_repeat = 8u * (last_repeat - 2u) + v + 3u;
-                i += new_repeat - last_repeat;
+                const u32 new_repeat = 8u * (last_repeat - 2u) + v + 3u;
+                ni = i + (new_repeat - last_repeat);
                 last_repeat = new_repeat;
             } else {
                 last_repeat = 3u + v;
-                i += last_repeat;
+                ni = i + last_repeat;
             }
-            if (i > alphabet) return ST_PARSE_COMPLEX_LENGTHS;
+            if (ni > alphabet) return ST_PARSE_COMPLEX_LENGTHS;
+            if ((ni >> 6) != (i >> 6)) BRX_LENS_FLUSH(i & ~63u); // (the chunks in between stay zero: lens_clear)
+            i = ni;
             last_symbol = 17u;
         }
     }
+    BRX_LENS_FLUSH((i - 1u) & ~63u); // (dirty: position i - 1 was the last one written -- the loop may have left on a chunk's last symbol)
+#undef BRX_LENS_FLUSH
+    PT_ADD(8, pt);
     if (nz < 2u) return ST_LESS_THAN_TWO_NONZERO;
     return ST_OK;
 }
 
 // parse_prefix_code, src/lib.rs:877-889 = kind (:589-595) + simple (:597-665, Q8) or complex (:667-875, Q6, Q15)
 FI u32 read_prefix_code(Dec &d, Lds &s, u32 alphabet, u32 &h, const bool wide = false) {
-    u32 kind, v;
-    if (!in_bits(d, 2, kind)) return ST_EOF;
+    PT_BEGIN(pt);
+    const u32 kind = hb_bits(d, 2);
     if (kind == 1u) { // ---- simple
-        u32 bit_width = 32u - (u32)__builtin_clz(alphabet - 1u);
-        if (!in_bits(d, 2, v)) return ST_EOF;
-        u32 nsym = v + 1u;
+        const u32 bit_width = 32u - (u32)__builtin_clz(alphabet - 1u);
+        const u32 nsym = hb_bits(d, 2) + 1u;
         u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        if (!in_bits(d, bit_width, s0)) return ST_EOF;
+        s0 = hb_bits(d, bit_width);
         if (s0 >= alphabet) return ST_INVALID_SYMBOL;
         if (nsym > 1u) {
-            if (!in_bits(d, bit_width, s1)) return ST_EOF;
+            s1 = hb_bits(d, bit_width);
             if (s1 >= alphabet) return ST_INVALID_SYMBOL;
         }
         if (nsym > 2u) {
-            if (!in_bits(d, bit_width, s2)) return ST_EOF;
+            s2 = hb_bits(d, bit_width);
             if (s2 >= alphabet) return ST_INVALID_SYMBOL;
         }
         if (nsym > 3u) {
-            if (!in_bits(d, bit_width, s3)) return ST_EOF;
+            s3 = hb_bits(d, bit_width);
             if (s3 >= alphabet) return ST_INVALID_SYMBOL;
         }
         if (nsym > 1u && s0 == s1) return ST_INVALID_SYMBOL;
         if (nsym > 2u && (s0 == s2 || s1 == s2)) return ST_INVALID_SYMBOL;
         if (nsym > 3u && (s0 == s3 || s1 == s3 || s2 == s3)) return ST_INVALID_SYMBOL;
         u32 tree_select = 0;
-        if (nsym == 4u && !in_bits(d, 1, tree_select)) return ST_EOF;
+        if (nsym == 4u) tree_select = hb_bits(d, 1);
         if (nsym == 1u) {
             h = build_single(d, s, s0);
+            PT_ADD(6, pt);
             return ST_OK;
         }
-        // Within one length the reference inserts the symbols in ascending order in every NSYM case, so the
-        // canonical code is a function of the per-symbol lengths alone.
-        lens_clear(d, s, alphabet);
         u32 l0, l1, l2, l3;
         if (nsym == 2u) { l0 = 1; l1 = 1; l2 = 0; l3 = 0; }
         else if (nsym == 3u) { l0 = 1; l1 = 2; l2 = 2; l3 = 0; }
         else if (!tree_select) { l0 = l1 = l2 = l3 = 2; }
         else { l0 = 1; l1 = 2; l2 = 3; l3 = 3; }
-        if (d.lane == 0u) {
-            s.lens[s0] = (u8)l0;
-            s.lens[s1] = (u8)l1;
-            if (nsym > 2u) s.lens[s2] = (u8)l2;
-            if (nsym > 3u) s.lens[s3] = (u8)l3;
-        }
-    } else {
-        u32 rc = read_complex_lens(d, s, kind, alphabet);
-        if (rc) return rc;
+        h = build_simple(d, s, nsym, (l0 << 16) | s0, (l1 << 16) | s1, (l2 << 16) | s2, (l3 << 16) | s3, wide);
+        PT_ADD(6, pt);
+        return ST_OK;
     }
+    const u32 rc = read_complex_lens(d, s, kind, alphabet);
+    if (rc) return rc;
+    PT_BEGIN(pb);
     h = build_code(d, s, alphabet, wide);
+    PT_ADD(9, pb);
     return ST_OK;
 }
 
@@ -970,14 +1075,49 @@ struct Cat {
 };
 
 // parse_n_bltypes, src/lib.rs:501-525 (also NTREESL / NTREESD)
-FI u32 read_n_bltypes(Dec &d, u32 &n) {
-    u32 b, k, e;
-    if (!in_bits(d, 1, b)) return ST_EOF;
-    if (!b) { n = 1; return ST_OK; }
-    if (!in_bits(d, 3, k)) return ST_EOF;
-    if (k == 0u) { n = 2; return ST_OK; }
-    if (!in_bits(d, k, e)) return ST_EOF;
-    n = (1u << k) + 1u + e;
+FI u32 read_n_bltypes(Dec &d) {
+    if (!hb_bits(d, 1)) return 1u;
+    const u32 k = hb_bits(d, 3);
+    if (k == 0u) return 2u;
+    return (1u << k) + 1u + hb_bits(d, k);
+}
+// Lookup in a code of the header (block types, block counts, context maps: 16-bit symbol entries) through the hb_* reader.
+// `hv` = the tree's header words across the lanes (loaded once per tree by the caller: hd_tree).  An unassigned codeword
+// of an incomplete code reads max_len + 1 bits and yields None (Q15), like decode_sym_as.
+FI u32 hd_tree(const Dec &d, const Lds &s, u32 h) {
+    return h < BRX_TM_WORDS ? tm_ld32<true>(d, s, h + (d.lane & 31u)) : tm_ld32<false>(d, s, h + (d.lane & 31u));
+}
+FI u32 hd_decode(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sym) {
+    const u32 h0 = rdl(hv, 1);
+    const u32 kind = h0 & 3u;
+    if (kind == 0u) return LK_NONE;
+    if (kind == 1u) {
+        sym = h0 >> 16;
+        return LK_OK;
+    }
+    const u32 v = __brev(hb_peek(d) & 0x7fffu) >> 17; // first stream bit = MSB of a 15-bit left-aligned code
+    const u64 m = ballot((v << 16) < hv) & 0x55555554ull; // lanes 2, 4 .. 30 carry limit[1..15] << 16
+    if (m == 0ull) {
+        hb_skip(d, ((h0 >> 8) & 0xffu) + 1u);
+        return LK_NONE;
+    }
+    const u32 L = (u32)__builtin_ctzll(m) >> 1;
+    const u32 idx = ((v >> (15u - L)) + rdl(hv, 2u * L + 1u)) & 0xffffu;
+    sym = h < BRX_TM_WORDS ? rfl(tm_ld16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + idx)) : rfl(tm_ld16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
+    hb_skip(d, L);
+    return LK_OK;
+}
+// first block count of a category (parse_first_block_count_* :989-1014 over parse_block_count :957-987): base and extra bits
+// of the 26 block count codes in closed form (spec section 6)
+FI u32 hd_block_count(Dec &d, const Lds &s, u32 h, u32 &blen) {
+    u32 sym;
+    if (hd_decode(d, s, h, hd_tree(d, s, h), sym) != LK_OK) return ST_EOF;
+    if (sym > 25u) return ST_INVALID_BLOCK_COUNT_CODE;
+    u32 nb, base;
+    if (sym < 16u) { const u32 g = sym >> 2; nb = 2u + g; base = 1u + 16u * ((1u << g) - 1u) + ((sym & 3u) << nb); }
+    else if (sym < 18u) { nb = 6u; base = sym == 16u ? 241u : 305u; }
+    else { nb = sym == 25u ? 24u : sym - 11u; base = 241u + (1u << (sym - 11u)); }
+    blen = base + hb_bits(d, nb);
     return ST_OK;
 }
 // parse_block_count, src/lib.rs:957-987 (Ok(None) -> UnexpectedEOF, :977)
@@ -1012,44 +1152,74 @@ FI u32 cat_tick(Dec &d, const Lds &s, Cat &c, bool &switched) {
 
 // parse_context_map, src/lib.rs:1070-1144, second half: the run-length coded map itself (the RLEMAX field and
 // the prefix code `h` over rlemax+ntrees symbols are read by the header loop).  Values go to table memory
-// bytes [cm, cm+len).
+// bytes [cm, cm+len), which the caller has zeroed: zero runs only move the cursor.  Values collect 64 at a time in the
+// lanes of one register; the inverse move-to-front transform (:1164-1177) then runs over the stored map, again 64 entries
+// per register, with the front 64 entries of its list in the lanes of m0 (a map rarely names a tree index >= 64).
 FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len) {
-    u32 b, v;
-    u32 pushed = 0;
+    PT_BEGIN(pt);
+    const u32 lane = d.lane;
+    const u32 hv = hd_tree(d, s, h);
+    u32 pushed = 0, cur = 0;
+    bool dirty = false;
+#define BRX_CM_FLUSH(base_) do { if (dirty) { if (cm < TM_BYTES) { if ((base_) + lane < len) tm_st8<true>(d, s, cm + (base_) + lane, cur); } \
+                                              else { if ((base_) + lane < len) tm_st8<false>(d, s, cm + (base_) + lane, cur); } } \
+                                 cur = 0u; dirty = false; } while (0)
     while (pushed < len) {
         u32 code;
-        u32 lk = decode_sym(d, s, h, code);
-        if (lk == LK_NONE) return ST_PARSE_CONTEXT_MAP;
-        if (lk == LK_EOF) return ST_EOF;
+        const u32 lk = hd_decode(d, s, h, hv, code);
+        if (lk != LK_OK) return ST_PARSE_CONTEXT_MAP;
         if (code > 0u && code <= rlemax) {
-            if (!in_bits(d, code, v)) return ST_EOF;
-            u32 repeat = (1u << code) + v;
+            const u32 repeat = (1u << code) + hb_bits(d, code);
             if (pushed + repeat > len) return ST_RUN_LENGTH_EXCEEDED;
-            tm_zero_bytes(d, s, cm + pushed, repeat);
+            if (((pushed + repeat) >> 6) != (pushed >> 6)) BRX_CM_FLUSH(pushed & ~63u);
             pushed += repeat;
         } else {
-            tm_set8(d, s, cm + pushed, code == 0u ? 0u : code - rlemax);
+            if (code) {
+                cur = wrl(code - rlemax, pushed & 63u, cur);
+                dirty = true;
+            }
             pushed++;
+            if ((pushed & 63u) == 0u) BRX_CM_FLUSH(pushed - 64u);
         }
     }
-    if (!in_bits(d, 1, b)) return ST_EOF;
-    if (b) { // inverse_move_to_front_transform, src/lib.rs:1164-1177: the 256-entry list lives 4 per lane
-        u32 m0 = d.lane, m1 = d.lane + 64u, m2 = d.lane + 128u, m3 = d.lane + 192u; // mtf[lane + 64*k]
-        for (u32 k = 0; k < len; k++) {
-            u32 idx = tm_u8(d, s, cm + k);
-            u32 q = idx >> 6, l = idx & 63u;
-            u32 value = q == 0u ? rdl(m0, l) : q == 1u ? rdl(m1, l) : q == 2u ? rdl(m2, l) : rdl(m3, l);
-            tm_set8(d, s, cm + k, value);
-            // shift mtf[0..idx) up by one, put value in front
-            u32 c0 = rdl(m0, 63), c1 = rdl(m1, 63), c2 = rdl(m2, 63);
-            u32 s0 = (u32)__shfl_up((int)m0, 1), s1 = (u32)__shfl_up((int)m1, 1), s2 = (u32)__shfl_up((int)m2, 1),
-                s3 = (u32)__shfl_up((int)m3, 1);
-            if (d.lane == 0u) { s0 = value; s1 = c0; s2 = c1; s3 = c2; }
-            if (d.lane <= idx) m0 = s0;
-            if (d.lane + 64u <= idx) m1 = s1;
-            if (d.lane + 128u <= idx) m2 = s2;
-            if (d.lane + 192u <= idx) m3 = s3;
+    if (pushed & 63u) BRX_CM_FLUSH(pushed & ~63u);
+#undef BRX_CM_FLUSH
+    const u32 imtf = hb_bits(d, 1);
+    PT_ADD(10, pt);
+    if (imtf) { // inverse_move_to_front_transform, src/lib.rs:1164-1177: the 256-entry list lives 4 per lane
+        u32 m0 = lane, m1 = lane + 64u, m2 = lane + 128u, m3 = lane + 192u; // mtf[lane + 64*k]
+        for (u32 base = 0; base < len; base += 64u) {
+            const u32 cnt = len - base < 64u ? len - base : 64u;
+            const u32 ba = cm + base + (lane < cnt ? lane : 0u);
+            u32 vec = cm < TM_BYTES ? tm_ld8<true>(d, s, ba) : tm_ld8<false>(d, s, ba);
+            for (u32 k = 0; k < cnt; k++) {
+                const u32 idx = rdl(vec, k);
+                if (idx == 0u) {
+                    vec = wrl(rdl(m0, 0), k, vec);
+                } else if (idx < 64u) { // the front of the list: m0 alone moves (one DPP wave shift)
+                    const u32 value = rdl(m0, idx);
+                    const u32 up = (u32)__builtin_amdgcn_update_dpp((int)m0, (int)m0, 0x138, 0xf, 0xf, false); // wave_shr:1
+                    m0 = lane == 0u ? value : (lane <= idx ? up : m0);
+                    vec = wrl(value, k, vec);
+                } else {
+                    const u32 q = idx >> 6, l = idx & 63u;
+                    const u32 value = q == 1u ? rdl(m1, l) : q == 2u ? rdl(m2, l) : rdl(m3, l);
+                    vec = wrl(value, k, vec);
+                    // shift mtf[0..idx) up by one, put value in front
+                    const u32 c0 = rdl(m0, 63), c1 = rdl(m1, 63), c2 = rdl(m2, 63);
+                    u32 s0 = (u32)__shfl_up((int)m0, 1), s1 = (u32)__shfl_up((int)m1, 1), s2 = (u32)__shfl_up((int)m2, 1),
+                        s3 = (u32)__shfl_up((int)m3, 1);
+                    if (lane == 0u) { s0 = value; s1 = c0; s2 = c1; s3 = c2; }
+                    m0 = s0;
+                    if (lane + 64u <= idx) m1 = s1;
+                    if (lane + 128u <= idx) m2 = s2;
+                    if (lane + 192u <= idx) m3 = s3;
+                }
+            }
+            if (cm < TM_BYTES) { if (lane < cnt) tm_st8<true>(d, s, cm + base + lane, vec); }
+            else { if (lane < cnt) tm_st8<false>(d, s, cm + base + lane, vec); }
         }
+        PT_ADD(11, pt);
     }
     return ST_OK;
 }
@@ -1064,12 +1234,9 @@ struct MB { // per-meta-block scalars the command loop needs
 // Meta-block header (reference states NBltypesL .. PrefixCodesDistances, src/lib.rs:1745-2002), out of line.
 // Input: decoder state in Lds::st.  Output: status; on ST_OK the header results sit in Lds::mbw and the
 // advanced input cursor / table-memory tops in Lds::st.
-__device__ __noinline__ u32 cold_header() {
-    Lds &s = g_lds;
-    Dec d;
-    dec_load(d, s);
+FI u32 header_body(Dec &d, Lds &s) {
     Cat L, I, D, cur;
-    u32 rc, v;
+    u32 rc;
     d.lds_top = 0;
     d.scr_top = 0;
     // ---- header: ONE loop whose tail reads "the next prefix code"; the head consumes the code read by the
@@ -1086,7 +1253,7 @@ __device__ __noinline__ u32 cold_header() {
         u32 alphabet = 0;
         if (step == S_CAT_N) { // parse_n_bltypes_{l,i,d} :527-546 and what follows each (:1745-1885)
             cur.btype = 0; cur.btype_prev = 1; cur.blen = 0xffffffffu; cur.h_types = 0; cur.h_counts = 0;
-            if ((rc = read_n_bltypes(d, cur.nbl))) return rc;
+            cur.nbl = read_n_bltypes(d);
             if (cur.nbl >= 2u) {
                 alphabet = cur.nbl + 2u;
                 step = S_CAT_TYPES;
@@ -1102,23 +1269,24 @@ __device__ __noinline__ u32 cold_header() {
             step = S_CAT_COUNTS;
         } else if (step == S_CAT_COUNTS) {
             cur.h_counts = h;
-            if ((rc = read_block_count(d, s, h, cur.blen))) return rc; // parse_first_block_count_* :989-1014
+            if ((rc = hd_block_count(d, s, h, cur.blen))) return rc; // parse_first_block_count_* :989-1014
             if (c == 0u) L = cur; else if (c == 1u) I = cur; else D = cur;
             c++;
             step = c < 3u ? S_CAT_N : S_MISC;
             continue;
         } else if (step == S_MISC) {
-            if (!in_bits(d, 2, v)) return ST_EOF; // parse_n_postfix :548
-            npostfix = v;
-            if (!in_bits(d, 4, v)) return ST_EOF; // parse_n_direct :555
-            ndirect = v << npostfix;
+            npostfix = hb_bits(d, 2);            // parse_n_postfix :548
+            ndirect = hb_bits(d, 4) << npostfix; // parse_n_direct :555
             dalpha = 16u + ndirect + (48u << npostfix);
             cmode_w = tm_alloc(d, (L.nbl + 3u) >> 2); // context modes, 2 bits per literal block type :562
-            for (u32 i = 0; i < L.nbl; i++) {
-                if (!in_bits(d, 2, v)) return ST_EOF;
-                tm_set8(d, s, cmode_w * 4u + i, v);
+            for (u32 base = 0; base < L.nbl; base += 64u) { // (64 modes collect in the lanes of one register)
+                const u32 cnt = L.nbl - base < 64u ? L.nbl - base : 64u;
+                u32 vec = 0;
+                for (u32 i = 0; i < cnt; i++) vec = wrl(hb_bits(d, 2), i, vec);
+                if (cmode_w < BRX_TM_WORDS) { if (d.lane < cnt) tm_st8<true>(d, s, cmode_w * 4u + base + d.lane, vec); }
+                else { if (d.lane < cnt) tm_st8<false>(d, s, cmode_w * 4u + base + d.lane, vec); }
             }
-            if ((rc = read_n_bltypes(d, ntl))) return rc; // parse_n_trees_l :575
+            ntl = read_n_bltypes(d); // parse_n_trees_l :575
             cml = tm_alloc(d, 16u * L.nbl) * 4u; // 64 bytes per block type, zero = tree 0
             tm_zero_words(d, s, cml >> 2, 16u * L.nbl);
             if (ntl >= 2u) {
@@ -1130,7 +1298,7 @@ __device__ __noinline__ u32 cold_header() {
                 continue;
             }
         } else if (step == S_NTD) {
-            if ((rc = read_n_bltypes(d, ntd))) return rc; // parse_n_trees_d :582
+            ntd = read_n_bltypes(d); // parse_n_trees_d :582
             cmd = tm_alloc(d, D.nbl) * 4u; // 4 bytes per block type
             tm_zero_words(d, s, cmd >> 2, D.nbl);
             if (ntd >= 2u) {
@@ -1156,13 +1324,8 @@ __device__ __noinline__ u32 cold_header() {
         }
         else if (step == S_CM) {
             // parse_context_map :1070-1144: RLEMAX, then a prefix code over rlemax+ntrees symbols, then the map
-            u32 b;
-            if (!in_bits(d, 1, b)) return ST_EOF;
             rlemax = 0;
-            if (b) {
-                if (!in_bits(d, 4, v)) return ST_EOF;
-                rlemax = v + 1u;
-            }
+            if (hb_bits(d, 1)) rlemax = hb_bits(d, 4) + 1u;
             save_lds = d.lds_top; // the map's code is dead once the map is read
             save_scr = d.scr_top;
             alphabet = rlemax + (which ? ntd : ntl);
@@ -1187,7 +1350,20 @@ __device__ __noinline__ u32 cold_header() {
         w[18] = I.nbl; w[19] = I.btype; w[20] = I.btype_prev; w[21] = I.blen; w[22] = I.h_types; w[23] = I.h_counts;
         w[24] = D.nbl; w[25] = D.btype; w[26] = D.btype_prev; w[27] = D.blen; w[28] = D.h_types; w[29] = D.h_counts;
     }
-    dec_store(d, s);
+    return ST_OK;
+}
+__device__ __noinline__ u32 cold_header() {
+    Lds &s = g_lds;
+    Dec d;
+    PT_BEGIN(pl);
+    dec_load_in(d, s);
+    hb_begin(d);
+    PT_ADD(13, pl);
+    u32 rc = header_body(d, s);
+    if (hb_over(d)) rc = ST_EOF; // a read crossed the end of the input: UnexpectedEOF came first (see hb_*)
+    if (rc) return rc;
+    d.bitpos = hb_pos(d);
+    dec_store_in(d, s);
     return ST_OK;
 }
 
@@ -1817,9 +1993,15 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         const bool tiny = i1 - i0 <= (u64)a.tiny_bytes || i1 < i0;
         bool deferred = false;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
+#ifdef BRX_BRINGUP
+        if (lane < 32u) g_prof[lane] = 0ull;
+#endif
+        PT_BEGIN(pd);
         u32 st = seg_frame();
+        PT_ADD(0, pd);
         while (st == SEG_NEED_HEADER) {
             st = cold_header();
+            PT_ADD(1, pd);
             if (st) break;
 #if BRX_LEVEL < BRX_LEVELS - 1
             if (a.defer != nullptr && get64(s, 20) != 0ull) { // this meta-block's tables spilled into a slab: a stream
@@ -1832,6 +2014,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // bytes (a handful of commands, e.g. the RLE-like fills of BASELINE configs 3 / 4): preparing the
                 // assembly loop's tables and handing over at every long copy costs more than it saves there
                 st = generic_commands(HC_WHOLE);
+                PT_ADD(2, pd);
             } else if (a.debug_stop == 7u) { // bring-up: the C++ loop alone, one command per call
                 st = generic_commands(HC_START);
                 while (st == HC_CONTINUE) st = generic_commands(HC_RESUME_R1);
@@ -1860,21 +2043,27 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // the assembly runs until something unusual comes up, C++ takes exactly one command (or finishes
                 // the meta-block), and so on.
                 st = generic_commands(HC_START);
+                PT_ADD(2, pd);
                 const bool use_asm = rfl(s.mbw[MBW_ASM]) != 0u;
                 if (prof_on && lane == 0u) s.pad[use_asm ? 2 : 0]++;
                 if (st == HC_CONTINUE && !use_asm) st = generic_commands(HC_RESUME_R1_WHOLE);
                 while (st == HC_CONTINUE) {
+                    PT_ADD(3, pd);
                     const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
+                    PT_ADD(4, pd);
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                     }
                     st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
                 }
+                PT_ADD(3, pd);
             }
             if (st) break;
             st = seg_frame();
+            PT_ADD(0, pd);
         }
         seg_finish();
+        PT_ADD(5, pd);
         {
             const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
             if (slab != nullptr) scratch_release(a.pool, slab);
@@ -1892,6 +2081,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             a.debug[(size_t)sid * 10u + 8] = (u64)__builtin_readcyclecounter() - tstream;
             a.debug[(size_t)sid * 10u + 9] = s.st[19];
         }
+#ifdef BRX_BRINGUP
+        if (prof_on && lane < 32u) a.debug[(size_t)a.n * 10u + (size_t)sid * 32u + lane] = g_prof[lane];
+#endif
         if (lane == 0u) {
             a.status[sid] = (int)st;
             a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)needed : (u64)pos;
