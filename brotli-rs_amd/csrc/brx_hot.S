@@ -417,6 +417,21 @@
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
     TAKE CLEN, \rid
 .endm
+// The same in two halves: the compare and the speculative fetches are issued EARLY (at .Lcopy: the next insert&copy symbol's
+// bits are known as soon as the distance is), the length and the TAKE follow at .Lcmd_pre -- the fetch's LDS round trip runs
+// under the copy's bookkeeping.  vcc, VS (and VR, VU, VI) must survive in between: the common copy paths write none of them.
+.macro LOOKUP2F_EARLY lim, basep, scale, rd
+    v_bfrev_b32 VR, WSRC
+    v_lshrrev_b32 VU, 1, VR
+    v_cmp_lt_u32 vcc, VU, \lim
+    v_lshrrev_b32 VI, VSH, VR
+    v_lshl_add_u32 VI, VI, \scale, \basep
+    \rd VS, VI
+.endm
+.macro LOOKUP2F_LATE rid
+    s_ff1_i32_b32 CLEN, vcc_lo                          // code length
+    TAKE CLEN, \rid
+.endm
 #endif
 
 // ======================================================================================================== entry
@@ -772,11 +787,25 @@
     s_branch .Lr1
 
 // ======================================================================================================== R0
+// .Lcmd: the lookup of the insert&copy symbol from scratch (the uncommon copy paths end here);
+// .Lcmd_pre: entered from the common copy paths, which issued the lookup's compare and fetches at .Lcopy.
+#ifdef BRX_NO_SPEC
+.Lcmd_pre:
+#endif
 .Lcmd:
     PROF_MARK s31                                       // copy + tail
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
     LOOKUP2F VIACL, VIACB, 1, ds_read_u16, 3
+#ifndef BRX_NO_SPEC
+    s_branch .Lcmd_have
+.Lcmd_pre:
+    PROF_MARK s31                                       // copy + tail
+    s_sub_u32 IBLEN, IBLEN, 1
+    s_cbranch_scc1 .Lx_r0_switch
+    LOOKUP2F_LATE 11
+#endif
+.Lcmd_have:
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte offset of the symbol's record in the insert&copy table
     s_load_dwordx4 s[92:95], IACTAB, T0                 // = INS base, CPY base, DCTX, extra-bit counts
@@ -830,9 +859,17 @@
 // ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542): takes the next CPY lanes
 // of the pending register
 .Lcopy:
-    s_sub_u32 T0, 63, PFREE                             // (63, not 64: s_bfm_b64 takes a 6-bit width)
-    s_min_u32 T0, T0, DIST                              // the common case: CPY <= min(free lanes, distance); the end of
-    s_cmp_gt_u32 CPY, T0                                // the meta-block is checked behind the copy (.Lcopy_tail)
+    // ONE test for the common case: the copy's lanes -- PFREE + CPY of them in use afterwards -- must fit the pending register
+    // (<= 63: s_bfm_b64 takes a 6-bit width) and must not exceed the distance: then the copy does not overlap itself
+    // (CPY <= DIST) AND its source ends before the first pending byte (POS - DIST + CPY <= PBASE = POS - PFREE).  Everything
+    // else -- lanes used up or a source that reaches into pending bytes (land, come back), overlap, long copies -- is out of
+    // line.  The end of the meta-block is checked behind the copy (.Lcopy_tail).
+#ifndef BRX_NO_SPEC
+    LOOKUP2F_EARLY VIACL, VIACB, 1, ds_read_u16         // the NEXT command's insert&copy symbol (.Lcmd_pre)
+#endif
+    s_add_u32 T3, PFREE, CPY
+    s_min_u32 T0, DIST, 63
+    s_cmp_gt_u32 T3, T0
     s_cbranch_scc1 .Lcopy_slow
     s_sub_u32 T2, PBASE, DIST                           // + lane = position of this lane's source byte  (PBASE = POS - PFREE)
     s_cmp_gt_u32 DIST, RING
@@ -842,13 +879,17 @@
     v_add_u32 VT0, T2, VLANE
     buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
     s_mov_b64 exec, XLOOP
-.Lcopy_issued:
-    s_add_u32 PFREE, PFREE, CPY
+    s_mov_b32 PFREE, T3
     s_add_u32 POS, POS, CPY
+.Lcopy_tail_pre:
+    s_cmp_ge_u32 POS, MBEND
+    s_cbranch_scc0 .Lcmd_pre
+    s_branch .Lcopy_end
 .Lcopy_tail:                                            // (the flush cursor is checked whenever pending copies land)
 .Lflush_back_cmd:
     s_cmp_ge_u32 POS, MBEND
     s_cbranch_scc0 .Lcmd
+.Lcopy_end:
     s_cmp_eq_u32 POS, MBEND
     s_cbranch_scc0 .Lcopy_overrun
     s_mov_b32 INS, 0
@@ -858,22 +899,19 @@
     s_sub_u32 PFREE, PFREE, CPY
     s_branch .Lx_r2
 
-// ---- source inside the ring.  If it reaches into bytes that are still pending, land those first.
+// ---- source inside the ring (final bytes: the test above keeps it clear of the pending ones)
 .Lcopy_near:
-    s_add_u32 T3, T2, PFREE
-    s_add_u32 T3, T3, CPY                               // end of the source = POS - DIST + CPY
-    s_cmp_gt_u32 T3, PBASE
-    s_cbranch_scc0 .Lcopy_near_go
-    s_call_b64 LINKB, .Lland
-    s_sub_u32 T2, PBASE, DIST
-.Lcopy_near_go:
     s_add_u32 T2, T2, SKEW
     s_bfm_b64 exec, CPY, PFREE
     v_add_u32 VT0, T2, VLANE
     v_and_b32 VT0, RMASK, VT0
     ds_read_u8 VPEND, VT0
     s_mov_b64 exec, XLOOP
-    s_branch .Lcopy_issued
+    s_mov_b32 PFREE, T3
+    s_add_u32 POS, POS, CPY
+    s_cmp_ge_u32 POS, MBEND
+    s_cbranch_scc0 .Lcmd_pre
+    s_branch .Lcopy_end
 
 .Ldist_special:
     s_bitcmp1_b32 DTREE, 30
@@ -1175,7 +1213,9 @@
     v_add_u32 VT0, T2, VLANE
     global_load_ubyte VPEND, VT0, DICTP
     s_mov_b64 exec, XLOOP
-    s_branch .Lcopy_issued
+    s_add_u32 PFREE, PFREE, CPY
+    s_add_u32 POS, POS, CPY
+    s_branch .Lcopy_tail                                // (no early lookup on this path: it does not come through .Lcopy)
 
 // ======================================================================================================== helpers
 // Land the pending copies: lanes 0..PFREE-1 of VPEND hold the bytes of stream positions PBASE.. (PBASE = POS - PFREE;
@@ -1342,6 +1382,9 @@
     REFILL_STUB 5
     REFILL_STUB 6
     REFILL_STUB 8
+#ifndef BRX_NO_SPEC
+    REFILL_STUB 11
+#endif
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
