@@ -796,6 +796,7 @@
     PROF_MARK s31                                       // copy + tail
     s_sub_u32 IBLEN, IBLEN, 1
     s_cbranch_scc1 .Lx_r0_switch
+.Lcmd_ticked:                                           // (back from an insert&copy block switch)
     LOOKUP2F VIACL, VIACB, 1, ds_read_u16, 3
 #ifndef BRX_NO_SPEC
     s_branch .Lcmd_have
@@ -830,6 +831,7 @@
     // ---- distance symbol (reference parse_distance_code :1367-1410)
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
+.Ldist_ticked:                                          // (back from a distance block switch)
     s_waitcnt lgkmcnt(0)
     LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF, 5
     s_waitcnt lgkmcnt(0)
@@ -952,9 +954,9 @@
     s_sub_u32 RUN, INS, 1
     s_mov_b32 INS, 0
 .endm
-.macro LIT_RUN_SETUP flush_stub
+.macro LIT_RUN_SETUP flush_stub, switch_stub
     s_cmp_eq_u32 LBLEN, 0
-    s_cbranch_scc1 .Lx_lit_block
+    s_cbranch_scc1 \switch_stub
     s_min_u32 RUN, INS, LBLEN
     s_sub_u32 T6, FLUSHAT, POS                          // (a copy may have ended exactly on the flush block: flush first)
     s_cbranch_scc1 \flush_stub
@@ -976,6 +978,9 @@
 // out of line: the flush at a run's end; the refill of a run's loop, which gives the untouched rest of the run back
 // (INS, LBLEN, POS) before the input staging rolls -- that may poison the block counts or find the end of the input
 .macro LIT_RUN_STUBS id, again, flush_stub
+.Llsw_\id:                                              // the literal block is used up at a run's start: switch, set the run up again
+    s_call_b64 LINKB, .Lsw_L
+    s_branch \again
 \flush_stub:
     s_call_b64 LINKC, .Lflush
     s_cmp_lg_u32 INS, 0
@@ -1022,7 +1027,8 @@
 .macro LIT_LOOP sfx, mixed, rid
 .Llit\sfx:
     s_sub_u32 LBLEN, LBLEN, 1
-    s_cbranch_scc1 .Lx_lit_switch
+    s_cbranch_scc1 .Lx_lit_switch\sfx
+.Llit_ticked\sfx:
     s_waitcnt lgkmcnt(0)                                // VH = tree descriptor of this literal's context
     v_cmp_gt_i32 vcc, 0, VH
     s_cbranch_vccnz .Llit_single\sfx
@@ -1102,7 +1108,7 @@
     s_cbranch_scc0 .Lno_lits
     s_branch .Lexit
 .Llit_r_run:
-    LIT_RUN_SETUP .Lflush_stub_lit_r
+    LIT_RUN_SETUP .Lflush_stub_lit_r, .Llsw_9
 .Llit_r:
     LIT_R_BODY 9
     s_sub_u32 RUN, RUN, 1
@@ -1116,8 +1122,6 @@
     s_cmp_eq_u32 POS, MBEND
     s_cbranch_scc0 .Lno_lits
     s_branch .Lexit                                     // :2069 the copy part of the last command is ignored
-.Lx_lit_block:                                          // literal block count exhausted (or poisoned) at a run start
-    s_branch .Lexit
 
 // one literal tree, resident: no contexts
 .Lhave_lits1:
@@ -1127,7 +1131,7 @@
     LIT_RUN_FAST .Llit1_run
     s_branch .Llit1
 .Llit1_run:
-    LIT_RUN_SETUP .Lflush_stub_lit1
+    LIT_RUN_SETUP .Lflush_stub_lit1, .Llsw_7
 .Llit1:
     LOOKUP2F VLITL, VLITB, 1, ds_read_u16, 7
     v_and_b32 VT0, RMASK, VPA
@@ -1385,6 +1389,9 @@
 #ifndef BRX_NO_SPEC
     REFILL_STUB 11
 #endif
+    REFILL_STUB 12
+    REFILL_STUB 13
+    REFILL_STUB 14
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
@@ -1589,19 +1596,226 @@
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
 
-// ======================================================================================================== exits
-.Lx_r0_switch:                                          // insert&copy block count exhausted (or poisoned)
+// ======================================================================================================== block switches
+// Block switch command (reference parse_block_switch_command + the block count that follows it, src/lib.rs:1226-1284,
+// :957-987), inside the loop.  .Lswitch: in T7 = offset of the category's words in Lds::mbw (48 literals / 72 insert&copy /
+// 96 distances: nbl, btype, btype_prev, blen, h_types, h_counts), return address LINKD.  Reads the block type code and the
+// block count code, writes btype / btype_prev back to Lds::mbw and returns with SCC = 0, s13 = the new block type,
+// T0 = the new count - 1.  Returns with SCC = 1 and NOTHING consumed when the counters are poisoned (the end of the input is
+// near: the C++ side takes over) or one of the two codes is not a complete general code (one-symbol or incomplete codes:
+// the C++ side reads them with the reference's exact rules).  Uses s12-s15, s36-s38, T2, T3, v14, v15, v20-v25, VLB;
+// T4 / T5 (the literal context) and T7 are preserved.
+.Lswitch:
+    s_bitcmp1_b32 FLAGS, 0
+    s_cbranch_scc1 .Lsw_ret                             // (SCC = 1)
+    v_mov_b32 VT0, T7
+    ds_read_b64 v[20:21], VT0 offset:LDS_MBW            // nbl, btype
+    ds_read_b32 v22, VT0 offset:LDS_MBW+8               // btype_prev
+    ds_read_b64 v[24:25], VT0 offset:LDS_MBW+16         // h_types, h_counts
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 s12, v20
+    v_readfirstlane_b32 s13, v21
+    v_readfirstlane_b32 s14, v22
+    v_readfirstlane_b32 s36, v24
+    v_readfirstlane_b32 s37, v25
+    s_lshl_b32 s36, s36, 2
+    s_lshl_b32 s37, s37, 2
+    s_add_u32 s36, s36, LDS_TM                          // header of the block type code
+    s_add_u32 s37, s37, LDS_TM                          // header of the block count code
+    v_add_u32 VT1, s36, VLANE8
+    v_add_u32 VT2, s37, VLANE8
+    ds_read_b64 VLB, VT1                                // limits / bases of the type code (lane 0: 0, the info word)
+    ds_read_b64 v[14:15], VT2                           // ... of the count code
+    s_waitcnt lgkmcnt(0)
+    // both must be complete general codes: kind 2 in the info word, limit[15] = 2^15 (left-aligned: 0x80000000)
+    v_readlane_b32 T2, VBASE, 0
+    v_readlane_b32 T3, v15, 0
+    s_and_b32 T2, T2, 3
+    s_and_b32 T3, T3, 3
+    s_cmp_lg_u32 T2, 2
+    s_cbranch_scc1 .Lsw_ret
+    s_cmp_lg_u32 T3, 2
+    s_cbranch_scc1 .Lsw_ret
+    v_readlane_b32 T2, VLIM, 15
+    v_readlane_b32 T3, v14, 15
+    s_cmp_lg_u32 T2, 0x80000000
+    s_cbranch_scc1 .Lsw_ret
+    s_cmp_lg_u32 T3, 0x80000000
+    s_cbranch_scc1 .Lsw_ret
+    LOOKUP2 VLIM, VBASE, s36, 1, ds_read_u16, SYMOFF, 12
+    s_waitcnt lgkmcnt(0)
+    v_readlane_b32 s15, VS, CLEN                        // block type code: 0 = the previous type, 1 = the next one, n = type n - 2
+    s_add_u32 T2, s13, 1
+    s_cmp_eq_u32 T2, s12
+    s_cselect_b32 T2, 0, T2                             // (btype + 1) mod nbl
+    s_sub_u32 T3, s15, 2
+    s_cmp_eq_u32 s15, 1
+    s_cselect_b32 T3, T2, T3
+    s_cmp_eq_u32 s15, 0
+    s_cselect_b32 T3, s14, T3
+    v_mov_b32 v20, T3
+    v_mov_b32 v21, s13
+    v_mov_b32 VT0, T7
+    ds_write_b32 VT0, v20 offset:LDS_MBW+4              // btype
+    ds_write_b32 VT0, v21 offset:LDS_MBW+8              // btype_prev = the old type
+    s_mov_b32 s13, T3
+    LOOKUP2 v14, v15, s37, 1, ds_read_u16, SYMOFF, 13
+    s_waitcnt lgkmcnt(0)
+    v_readlane_b32 s15, VS, CLEN                        // block count code 0..25: base T3 and extra bits T2 (spec section 6)
+    s_cmp_ge_u32 s15, 18
+    s_cbranch_scc1 .Lsw_hi
+    s_cmp_ge_u32 s15, 16
+    s_cbranch_scc1 .Lsw_mid
+    s_lshr_b32 T2, s15, 2                               // codes 0..15 in groups of four: 2 + g extra bits
+    s_bfm_b32 T3, T2, 0
+    s_lshl_b32 T3, T3, 4
+    s_add_u32 T3, T3, 1                                 // 1 + 16 * (2^g - 1)
+    s_add_u32 T2, T2, 2
+    s_and_b32 s38, s15, 3
+    s_lshl_b32 s38, s38, T2
+    s_add_u32 T3, T3, s38
+    s_branch .Lsw_extra
+.Lsw_mid:                                               // 16, 17: 6 extra bits, bases 241 and 305
+    s_mov_b32 T2, 6
+    s_sub_u32 T3, s15, 16
+    s_lshl_b32 T3, T3, 6
+    s_add_u32 T3, T3, 241
+    s_branch .Lsw_extra
+.Lsw_hi:                                                // 18..24: code - 11 extra bits, base 241 + 2^(code - 11); 25: 24 bits
+    s_sub_u32 T2, s15, 11
+    s_bfm_b32 T3, 1, T2
+    s_add_u32 T3, T3, 241
+    s_cmp_eq_u32 s15, 25
+    s_cselect_b32 T2, 24, T2
+.Lsw_extra:
+    TAKE_EXTRA s38, T3, T2, 14
+    s_sub_u32 T0, s38, 1
+    s_cmp_lg_u32 T0, T0                                 // SCC = 0
+.Lsw_ret:
+    s_setpc_b64 LINKD
+
+// ---- insert&copy block switch: the tree of the new block type becomes the resident one
+.Lx_r0_switch:
+    s_mov_b32 T7, 72
+    s_call_b64 LINKD, .Lswitch
+    s_cbranch_scc1 .Lx_r0_bail
+    s_mov_b32 IBLEN, T0
+    ds_read_b32 v20, VZERO offset:LDS_MBW+24            // hi: handle table of the insert&copy trees
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T2, v20
+    s_add_u32 T2, T2, s13
+    s_lshl_b32 T2, T2, 2
+    v_mov_b32 VT0, T2
+    ds_read_b32 VT1, VT0 offset:LDS_TM
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T2, VT1
+    s_lshl_b32 T2, T2, 2
+    s_add_u32 T2, T2, LDS_TM
+    s_add_u32 T3, T2, SYMOFF
+    v_add_u32 VT0, T2, VLANE8
+    ds_read_b64 VIAC, VT0
+    s_waitcnt lgkmcnt(0)
+    v_lshl_add_u32 VIACB, VIACB, 1, T3                  // folded bases (LOOKUP2F)
+    s_branch .Lcmd_ticked
+.Lx_r0_bail:                                            // insert&copy block count exhausted and not switched here (or poisoned)
     s_mov_b32 IBLEN, 0
     s_mov_b32 EXITC, 0
     s_branch .Lexit
+
+// ---- literal block switch at a run's start (register-resident loops): the context -> tree map of the new block type
+.Lsw_L:
+    s_bitcmp1_b32 FLAGS, 4
+    s_cbranch_scc1 .Lexit                               // block types that differ in context mode: the C++ side
+    s_mov_b32 T7, 48
+    s_call_b64 LINKD, .Lswitch
+    s_cbranch_scc1 .Lexit                               // (nothing changed: the C++ side finds the run as it is)
+    s_add_u32 LBLEN, T0, 1                              // (run form: literals that can be decoded before the next switch)
+    s_bitcmp1_b32 FLAGS, 5
+    s_cbranch_scc0 .Lsw_L_done                          // one literal tree: no context map
+    ds_read_b32 v20, VZERO offset:LDS_MBW+12            // cml: byte address of the literal context map
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T2, v20
+    s_lshl_b32 T3, s13, 6
+    s_add_u32 T2, T2, T3
+    s_mov_b64 exec, -1
+    v_add_u32 VT0, T2, VLANE
+    ds_read_u8 VT4, VT0 offset:LDS_TM                   // lane c: tree index of context id c
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 VCMAP, 1, VT4
+    s_mov_b64 exec, XLOOP
+.Lsw_L_done:
+    s_setpc_b64 LINKB
+
+// ---- literal block switch inside the per-literal loop (one context mode, trees in LDS): the context -> tree descriptor
+// table of the new block type, and the descriptor of the literal in progress again
+.Lx_lit_switch_u:
+    s_mov_b32 T7, 48
+    s_call_b64 LINKD, .Lswitch
+    s_cbranch_scc1 .Lx_lit_switch
+    s_mov_b32 LBLEN, T0
+    ds_read_b32 v20, VZERO offset:LDS_MBW+12
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T2, v20
+    s_lshl_b32 T3, s13, 6
+    s_add_u32 T2, T2, T3
+    s_mov_b64 exec, -1
+    v_add_u32 VT0, T2, VLANE
+    ds_read_u8 VT4, VT0 offset:LDS_TM
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 VT4, 2, VT4
+    ds_bpermute_b32 VT4, VT4, VLHOFF
+    v_lshlrev_b32 VT3, 2, VLANE
+    s_waitcnt lgkmcnt(0)
+    ds_write_b32 VT3, VT4 offset:LDS_CMH
+    s_mov_b64 exec, XLOOP
+    ds_read_b32 VH, VC offset:LDS_CMH
+    s_branch .Llit_ticked_u
+.Lx_lit_switch_m:                                       // (block types of different context modes: the C++ side switches)
 .Lx_lit_switch:                                         // literal block count exhausted (or poisoned), mid-run
     s_mov_b32 LBLEN, 0
     s_add_u32 INS, INS, 1                               // (the loop counter runs one behind)
     s_branch .Lexit
+
+// ---- distance block switch: the trees of the new block type's four distance contexts, then this command's again
 .Lx_dist_switch:
+    s_mov_b32 T7, 96
+    s_call_b64 LINKD, .Lswitch
+    s_cbranch_scc1 .Lx_dist_bail
+    s_mov_b32 DBLEN, T0
+    ds_read_b32 v20, VZERO offset:LDS_MBW+16            // cmd: byte address of the distance context map (4 bytes per type)
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T2, v20
+    s_lshl_b32 T3, s13, 2
+    s_add_u32 T2, T2, T3
+    v_mov_b32 VT0, T2
+    ds_read_b32 VT2, VT0 offset:LDS_TM
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 CMDW, VT2
+    s_mov_b64 exec, -1
+    v_lshlrev_b32 VT3, 3, VLANE
+    v_lshrrev_b32 VT3, VT3, CMDW
+    v_and_b32 VT3, 0xff, VT3
+    v_lshlrev_b32 VT3, 2, VT3
+    ds_bpermute_b32 VDH4, VT3, VDHOFF
+    s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, XLOOP
+    s_mov_b32 T2, 0xc0000000
+    v_writelane_b32 VDH4, T2, 4                         // "tree" of an implicit distance code 0
+    s_nop 0                                             // (a VALU-written VGPR needs one wait state before v_readlane)
+    v_readlane_b32 DTREE, VDH4, DCTX
+    s_nop 1
+    v_add_u32 VT0, DTREE, VLANE8
+    ds_read_b64 VDH, VT0
+    s_cmp_lt_i32 DTREE, 0
+    s_cbranch_scc0 .Ldist_ticked
+    s_and_b32 DCODE, DTREE, 0xffff                      // a one-symbol tree (always a last-distance code here)
+    s_branch .Ldist_ring_s
+.Lx_dist_bail:
     s_mov_b32 DBLEN, 0
     s_mov_b32 INS, 0
     s_branch .Lexit
+
+// ======================================================================================================== exits
 .Lx_dist_unfit:                                         // back to R1 with the literals done: the C++ side reads the distance
     s_add_u32 SNAV, SNAV, CLEN                          // (un-take the symbol: the bit cursor is derived from SNAV)
     s_add_u32 DBLEN, DBLEN, 1
@@ -1678,6 +1892,13 @@
     s_cmp_eq_u32 EXITC, 3
     s_cselect_b32 T0, 1, 0
     s_cselect_b32 EXITC, 2, EXITC
+    // bit 4 of the exit word: the cursor is within the last dwords of the stream (the loop will not run again): the C++ side
+    // then finishes the meta-block in ONE call instead of one command per call with a futile re-entry here in between
+    s_add_u32 T1, CBASE, WL
+    s_add_u32 T1, T1, 3
+    s_cmp_ge_u32 T1, WSAFE
+    s_cselect_b32 T1, 16, 0
+    s_or_b32 EXITC, EXITC, T1
     v_mov_b32 v20, DIST
     v_mov_b32 v21, T0
     v_mov_b32 v22, EXITC

@@ -319,6 +319,8 @@ FI u32 in_byte_tail(Dec &d) {
 #define HC_RESUME_R1 3u  // resume at the loop top; one command, park
 #define HC_RESUME_R2 4u  // resume with the distance known; one command, park
 #define HC_RESUME_R1_WHOLE 5u // resume at the loop top and run the meta-block to its end
+#define HC_TO_END 8u     // flag on HC_RESUME_R0 .. R2: do not park after one command, run the meta-block to its end (the assembly
+                         // loop reported the cursor within the last dwords of the stream: it would only hand straight back)
 #define HC_CONTINUE 200u // returned when parked (meta-block not finished)
 #define MBW_ASM 31
 #define MBW_MBLEFT 32
@@ -363,12 +365,8 @@ FI void dec_load(Dec &d, const Lds &s) {
     d.t_dict = (const u8 *)(uintptr_t)get64(s, 23); d.t_xforms = (const BrxTransform *)(uintptr_t)get64(s, 25);
     d.t_lut = (const u32 *)(uintptr_t)get64(s, 27); d.wd = get64(s, 29); d.wd_limit = get64(s, 31);
     d.pool = (const BrxSlabPool *)(uintptr_t)get64(s, ST_POOL);
-    {
-        u32 ki = K_INS[d.lane < 24u ? d.lane : 23u], kc = K_COPY[(d.lane - 32u) < 24u ? d.lane - 32u : 23u];
-        u32 mi = 0u - (u32)(d.lane < 24u), mc = 0u - (u32)((d.lane - 32u) < 24u); // bitwise selects: branch-free
-        d.v_ic = (ki & mi) | (kc & mc);
-    }
-    d.v_lut0 = d.t_lut[d.lane]; d.v_lut1 = d.t_lut[64u + d.lane]; d.v_lut2 = d.t_lut[128u + d.lane];
+    // (the per-lane constant vectors v_ic / v_lut0..2 are not loaded here: the kernel loads them once per wave and hands them
+    // to generic_commands as arguments -- five global loads less per call of a segment)
     d.cbase = 0xffffff00u; // force a re-stage of the input chunks
     d.chunkA = 0; d.chunkB = 0;
     in_seek(d, get64(s, 3));
@@ -997,6 +995,21 @@ FI void window_copy(Dec &d, Lds &s, u32 dist, u32 len, u32 &p1, u32 &p2) {
             maybe_flush(d, s);
             continue;
         }
+        if (de < 64u && done + dist >= dist * ((63u + dist) / dist)) de = dist * ((63u + dist) / dist); // period-preserving distance >= 64
+        if (rem >= 64u && rem < 1088u && de >= 64u && de <= BRX_RING_BYTES - 64u) {
+            // the tail of a long copy (what a periodic fill or the 1 KiB steps leave over, < 1088 bytes), or a medium one: whole
+            // 64-byte steps inside the ring, one LDS read and one LDS write each -- none of the per-step decisions below
+            const u32 steps = rem >> 6;
+            for (u32 k = 0; k < steps; k++) {
+                const u32 v = d.pos + d.a + d.lane;
+                s.ring[v & RMASK] = s.ring[(v - de) & RMASK];
+                d.pos += 64u;
+                maybe_flush(d, s);
+            }
+            done += steps << 6;
+            bulk_used = true; // (p1 / p2 from the ring at the end)
+            continue;
+        }
         u32 n = rem < 64u ? rem : 64u;
         const u32 mis = (d.pos + d.a) & 15u;
         if (rem >= 1088u && mis) n = 16u - mis; // short step that aligns the cursor for the bulk path
@@ -1498,7 +1511,9 @@ FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mo
 // arena, exact end-of-input and capacity checks at every field.  Out of line.  It is also the safety net of the
 // assembly loop (modes and resume points: HC_* above; a parked command travels in Lds::mbw).  Errors return at once
 // (they are final).
-FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
+FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
+    const u32 mode = mode_in & 7u;
+    const bool to_end = (mode_in & HC_TO_END) != 0u;
     MB m;
     Cat L, I, D;
     mb_load(s, m, L, I, D);
@@ -1510,8 +1525,8 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
     u32 p1, p2;
     ctx_bytes(d, s, p1, p2);
     u32 insert_len = 0, copy_len = 0, implicit_zero = 0, distance = 0, dist_bad = 0;
-    u32 budget = (mode == HC_WHOLE || mode == HC_RESUME_R1_WHOLE) ? 0xffffffffu : mode == HC_START ? 0u : 1u;
-    const bool oneshot = mode >= HC_RESUME_R0 && mode <= HC_RESUME_R2;
+    u32 budget = (mode == HC_WHOLE || mode == HC_RESUME_R1_WHOLE || to_end) ? 0xffffffffu : mode == HC_START ? 0u : 1u;
+    const bool oneshot = mode >= HC_RESUME_R0 && mode <= HC_RESUME_R2 && !to_end;
     u32 phase2 = mode == HC_RESUME_R2 ? 1u : 0u;
     if (mode >= HC_RESUME_R0) {
         mb_left = rfl(s.mbw[MBW_MBLEFT]);
@@ -1705,10 +1720,22 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode) {
     }
     return rc;
 }
-__device__ __noinline__ u32 generic_commands(u32 mode_in) {
+// per-lane constant vectors of the C++ command loop, loaded once per wave by the kernel (wave_consts) and passed by value
+struct WaveConsts { u32 v_ic, v_lut0, v_lut1, v_lut2; };
+FI WaveConsts wave_consts(const u32 *t_lut) {
+    const u32 lane = threadIdx.x;
+    WaveConsts c;
+    const u32 ki = K_INS[lane < 24u ? lane : 23u], kc = K_COPY[(lane - 32u) < 24u ? lane - 32u : 23u];
+    const u32 mi = 0u - (u32)(lane < 24u), mc = 0u - (u32)((lane - 32u) < 24u); // bitwise selects: branch-free
+    c.v_ic = (ki & mi) | (kc & mc);
+    c.v_lut0 = t_lut[lane]; c.v_lut1 = t_lut[64u + lane]; c.v_lut2 = t_lut[128u + lane];
+    return c;
+}
+__device__ __noinline__ u32 generic_commands(u32 mode_in, u32 v_ic, u32 v_lut0, u32 v_lut1, u32 v_lut2) {
     Lds &s = g_lds;
     Dec d;
     dec_load(d, s);
+    d.v_ic = v_ic; d.v_lut0 = v_lut0; d.v_lut1 = v_lut1; d.v_lut2 = v_lut2;
     const u32 rc = generic_body(d, s, rfl(mode_in)); // errors return from the middle: park the state here
     dec_store(d, s);
     return rc;
@@ -1848,6 +1875,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
     if (a.debug_stop == 1u) return;
+    const WaveConsts wc = wave_consts((const u32 *)a.t.context_lut);
+#define generic_commands(m_) generic_commands((m_), wc.v_ic, wc.v_lut0, wc.v_lut1, wc.v_lut2)
     u32 *const counter = a.work_counter + BRX_LEVEL;
 #if BRX_LEVEL > 0
     const u32 n_streams = rfl(a.defer != nullptr ? __builtin_nontemporal_load(&a.work_counter[4 + BRX_LEVEL]) : 0u);
@@ -1959,7 +1988,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     if ((u64)rfl(s.st[10]) >= pause_at) { paused = true; break; }
                     if (rfl(s.mbw[MBW_ASM]) != 0u) {
                         const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
-                        st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
+                        st = generic_commands(HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u)));
                     } else {
                         st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
                     }
@@ -2054,7 +2083,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     if (prof_on && lane == 0u) {
                         s.pad[4 + (r & 3u)]++;
                     }
-                    st = generic_commands(HC_RESUME_R0 + (r > 2u ? 1u : r));
+                    st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | ((r & 16u) ? HC_TO_END : 0u));
                 }
                 PT_ADD(3, pd);
             }
@@ -2090,6 +2119,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         }
     }
 }
+
+#undef generic_commands
 
 void BRX_LAUNCH_NAME(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
     hipLaunchKernelGGL(BRX_KERNEL_NAME, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);

@@ -801,7 +801,7 @@ def run_one(insts, index, rec, comp, expect, cmds, tables, args):
     st2 = lambda k: lds_u32(lds2, ST + 4 * k)
     mbw2 = lambda k: lds_u32(lds2, MBW + 4 * k)
     pos2, vfl2, bit2 = st2(10), st2(12), st2(3) | (st2(4) << 32)
-    exitc = mbw2(38)
+    exitc = mbw2(38) & 15  # (bit 4: the cursor is within the last dwords of the stream)
     res = {"steps": steps, "pos0": pos, "pos1": pos2, "exit": exitc, "cycles": w.cycles, "count": w.count, "bits": bit2 - bitpos}
     # 1. output bytes: flushed part in HBM, the rest in the ring
     fl2 = vfl2 - a
