@@ -465,7 +465,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         (void)hipMemcpy(h.data(), a.dump, dump_bytes, hipMemcpyDeviceToHost);
         const uint32_t nrec = std::min(h[0], c->dump_max);
         if (FILE *f = fopen(c->dump_path.c_str(), "ab")) {
-            const uint64_t hdr[4] = {0x32504d5544585242ull /* "BRXDUMP2": insert&copy entries as symbol << 6 | distance context */, nrec, (uint64_t)(uintptr_t)d_in, (uint64_t)(uintptr_t)d_out};
+            const uint64_t hdr[4] = {0x31504d5544585242ull /* "BRXDUMP1" */, nrec, (uint64_t)(uintptr_t)d_in, (uint64_t)(uintptr_t)d_out};
             fwrite(hdr, 8, 4, f);
             fwrite(h.data() + 16, 4, (size_t)nrec * BRX_DUMP_WORDS, f);
             fclose(f);

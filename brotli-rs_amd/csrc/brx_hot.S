@@ -808,23 +808,20 @@
 #endif
 .Lcmd_have:
     s_waitcnt lgkmcnt(0)
-    v_readlane_b32 T0, VS, CLEN                         // symbol << 6 | distance context (prepare_fast_tables)
-    s_lshr_b32 T1, T0, 2                                // byte offset of the symbol's record (SMEM drops the two low bits)
-    s_load_dwordx4 s[92:95], IACTAB, T1                 // = INS base, CPY base, DCTX, extra-bit counts
-    // The distance tree depends on the copy code only, and the entry names its context: its limits / bases are asked for
-    // while the record is still on its way (one round trip for both instead of two in a row).
-    s_nop 1                                             // (a VALU-written SGPR needs 4 wait states before it selects a lane)
-    v_readlane_b32 DTREE, VDH4, T0                      // (lane = the low six bits)
-    s_nop 1
-    v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
-    ds_read_b64 VDH, VT0
+    v_readlane_b32 T0, VS, CLEN                         // byte offset of the symbol's record in the insert&copy table
+    s_load_dwordx4 s[92:95], IACTAB, T0                 // = INS base, CPY base, DCTX, extra-bit counts
     s_waitcnt lgkmcnt(0)
     s_cmp_lg_u32 s95, 0
     s_cbranch_scc1 .Liac_extras                         // (three commands in ten on text)
 
 // ======================================================================================================== R1
-.Lr1_have:
+.Lr1:
     PROF_MARK s23                                       // insert&copy symbol (+ extras; + entry)
+    // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
+    v_readlane_b32 DTREE, VDH4, DCTX
+    s_nop 1
+    v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
+    ds_read_b64 VDH, VT0
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
@@ -941,14 +938,7 @@
     s_bfe_u32 T3, s95, 0x80008                          // copy extra bits
     TAKE_EXTRA INS, INS, T2, 1
     TAKE_EXTRA CPY, CPY, T3, 2
-    s_branch .Lr1_have
-// (entry with a parked command: the distance tree of its copy length is asked for here)
-.Lr1:
-    v_readlane_b32 DTREE, VDH4, DCTX
-    s_nop 1
-    v_add_u32 VT0, DTREE, VLANE8
-    ds_read_b64 VDH, VT0
-    s_branch .Lr1_have
+    s_branch .Lr1
 
 // ---- literal runs (the register-resident loops)
 // The common run is the whole insert: no block end, no flush block end inside it (a flush that falls due exactly at its

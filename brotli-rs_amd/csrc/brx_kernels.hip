@@ -406,9 +406,7 @@ FI void dec_store_in(const Dec &d, Lds &s) {
 // assembly loop, prepare_fast_tables() rewrites them in place into the form that loop wants (MBW_ASM = 1; the C++ loop
 // reads the same form then):
 //   literal trees      sym | info << 8, info = the literal's share of the NEXT literal's context id (context_info())
-//   insert&copy trees  sym << 6 | distance context (0..3 = min(copy code, 3); 4 = implicit distance code 0, symbols < 128):
-//                      >> 2 it is the byte offset of the symbol's record in BrxDeviceTables::iac, and its low six bits select the
-//                      lane of the distance context's tree -- the loop asks for that tree before the record has arrived
+//   insert&copy trees  sym << 4 = byte offset of the symbol's record in BrxDeviceTables::iac
 //   distance trees     0x80000000 | code for the 16 last-distance codes, else nbits | base << 5 with
 //                      distance = base + (extra << NPOSTFIX)  (decode_distance, src/lib.rs:1412-1481)
 #define BRX_HDR_WORDS 32u
@@ -1488,11 +1486,7 @@ FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mo
         const u32 h = rfl(s.tm[m.hi + t]);
         const u32 nnz = rfl(s.tm[h + 1u]) >> 16;
         u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
-        for (u32 k = d.lane; k < nnz; k += 64u) {
-            const u32 sym = sy[k];
-            const u32 cc = (u32)((0x21202101010ull >> (4u * (sym >> 6))) & 15u) * 8u + (sym & 7u); // copy length code
-            sy[k] = (u16)((sym << 6) | (sym < 128u ? 4u : cc < 3u ? cc : 3u));
-        }
+        for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 4);
     }
     for (u32 t = 0; uniform && t < m.ntl; t++) {
         const u32 h = rfl(s.tm[m.hl + t]);
@@ -1581,7 +1575,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
         u32 lk_ = decode_sym(d, s, tm_u32(d, s, m.hi + I.btype), sym_);                    \
         if (lk_ == LK_NONE) return ST_PARSE_IAC;                                           \
         if (lk_ == LK_EOF) return ST_EOF;                                                  \
-        if (fast_tables) sym_ >>= 6;                                                       \
+        if (fast_tables) sym_ >>= 4;                                                       \
         implicit_zero = sym_ < 128u ? 1u : 0u; /* :2012-2015 */                            \
         u32 cell_ = sym_ >> 6;                                                             \
         u32 ioff_ = (u32)((0x22120110000ull >> (4u * cell_)) & 15u) * 8u;                  \

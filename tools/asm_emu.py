@@ -727,25 +727,6 @@ def load_tables():
     return dic, lut, np.frombuffer(bytes(xf), dtype=np.uint8), iac.view(np.uint8)
 
 
-def iac_entries_r02_to_r03(lds):
-    """BRXDUMP1 files (round 2 kernels) hold insert&copy symbol entries as symbol << 4; the loop now expects
-    symbol << 6 | distance context (brx_kernels.hip, prepare_fast_tables): rewrite them in the LDS image."""
-    w32 = lds.view(np.uint32)
-    w16 = lds.view(np.uint16)
-    tm0 = 2048 // 4                      # table memory starts behind the ring
-    mbw = 9920 // 4
-    hi, n_iac = int(w32[mbw + 6]), int(w32[mbw + 18])
-    cell_cpy = (0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16)
-    for t in range(n_iac):
-        h = int(w32[tm0 + hi + t])
-        nnz = int(w32[tm0 + h + 1]) >> 16
-        base = (tm0 + h + 32) * 2
-        for k in range(nnz):
-            sym = int(w16[base + k]) >> 4
-            cc = cell_cpy[sym >> 6] + (sym & 7)
-            w16[base + k] = (sym << 6) | (4 if sym < 128 else min(cc, 3))
-
-
 def read_dumps(path):
     recs = []
     nlaunch = 0
@@ -755,13 +736,11 @@ def read_dumps(path):
             if len(h) < 32:
                 break
             magic, nrec, d_in, d_out = struct.unpack("<QQQQ", h)
-            assert magic in (0x31504d5544585242, 0x32504d5544585242), "not a BRXDUMP1 / BRXDUMP2 file"
+            assert magic == 0x31504d5544585242, "not a BRXDUMP1 file"
             for _ in range(nrec):
                 w = np.frombuffer(f.read(DUMP_WORDS * 4), dtype=np.uint32)
-                lds = w[16:].copy().view(np.uint8)
-                if magic == 0x31504d5544585242:
-                    iac_entries_r02_to_r03(lds)
-                recs.append({"launch": (d_in, d_out), "ordinal": nlaunch, "sid": int(w[0]), "k": int(w[1]), "lds": lds})
+                recs.append({"launch": (d_in, d_out), "ordinal": nlaunch, "sid": int(w[0]), "k": int(w[1]),
+                             "lds": w[16:].copy().view(np.uint8)})
             nlaunch += 1
     read_dumps.launches = nlaunch
     return recs
