@@ -48,6 +48,12 @@ WORKLOADS = {
     "quickfoxx16384": (["quickfox"], 16384),
     "ukkonooax16384": (["ukkonooa"], 16384),
     "monkeyx16384": (["monkey"], 16384),
+    # BASELINE configs[4]'s shape WITHOUT a committed fixture: 64 distinct 1 MiB streams made on the GPU by the adaptive generator
+    # (brx_generate_batch, BRX_GEN_ADAPTIVE) from rotations of the Canterbury texts the reference holds: 16 meta-blocks each,
+    # codes from each meta-block's statistics, two literal trees behind a context map, ~80 literal block switches per stream
+    "gen_c5x1024": (["gen:%d" % k for k in range(64)], 1024),
+    # a MIXED batch of the reference's texts (rows of different length and statistics side by side)
+    "mixed_textx4096": (["alice29.txt", "asyoulik.txt", "plrabn12.txt", "lcet10.txt"], 4096),
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic
@@ -333,7 +339,12 @@ def main():
     fixtures, n = WORKLOADS[args.workload]
     if args.streams:
         n = args.streams
-    fx = [load_fixture(f) for f in fixtures]
+    if fixtures[0].startswith("gen:"):  # made here, on the GPU, before anything is timed
+        corpus = b"".join(open(os.path.join(GOLD, t), "rb").read() for t in ("lcet10.txt", "alice29.txt", "plrabn12.txt", "asyoulik.txt"))
+        srcs = [(corpus[(k * 18211) % len(corpus):] + corpus)[:1 << 20] for k in range(len(fixtures))]
+        fx = list(zip(ctx.generate_batch(srcs, metablock_bytes=65536, adaptive=True), srcs))
+    else:
+        fx = [load_fixture(f) for f in fixtures]
     K = len(fx)
     comp, expect = fx[0]
     batch = Batch(torch, np, dev, fx, n)
@@ -425,8 +436,9 @@ def main():
         res = {"metric": "decompressed MB/s (whole node), %s batch" % args.workload, "value": round(value, 1),
                "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "u8", "data": "synthetic (fixture(s) %s replicated)" % ",".join(fixtures),
-               "config": {"workload": "%d x %s per GPU" % (n, "|".join(f + ".compressed" for f in fixtures)),
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic (fixture(s) %s replicated)" % (",".join(fixtures) if len(fixtures) <= 8 else "%s .. %s" % (fixtures[0], fixtures[-1])),
+               "config": {"workload": "%d x %s per GPU" % (n, ("%d distinct 1 MiB streams made on the GPU (brx_generate_batch, adaptive)" % len(fixtures))
+                                                              if fixtures[0].startswith("gen:") else "|".join(f + ".compressed" for f in fixtures)),
                           "streams_per_gpu": n,
                           "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
@@ -533,6 +545,8 @@ def main():
                 res["cpu_libbrotlidec"] = other  # informational: Google's optimized C decoder, if the image has it
             try:  # informational: the oracle on every host core at once (CPU baseline item b)
                 import subprocess
+                if fixtures[0].startswith("gen:"):
+                    raise KeyError("no file")
                 fixture_path = os.path.join(C5 if fixtures[0].startswith("c5_") else GOLD, fixtures[0] + ".compressed")
                 o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), fixture_path, "4"],
                                    capture_output=True, text=True, timeout=120)

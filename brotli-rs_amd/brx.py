@@ -17,6 +17,7 @@ MEM_DEVICE = 1
 OPT_TIMING = 2
 OPT_ORDER = 4
 GEN_SWITCHES = 8
+GEN_ADAPTIVE = 16
 
 OK = 0
 OUTPUT_TOO_SMALL = 25
@@ -161,25 +162,26 @@ class Context:
 
     # ---- stream generator (brx_generate_batch): inputs -> valid Brotli streams, made on the GPU ----------
     @staticmethod
-    def generate_slot_bytes(n_bytes, metablock_bytes=65536):
+    def generate_slot_bytes(n_bytes, metablock_bytes=65536, adaptive=False):
         """A slot size that always suffices for an input of n_bytes (brx.h)."""
-        return n_bytes + n_bytes // 8 + 256 * (n_bytes // metablock_bytes + 2)
+        return n_bytes + n_bytes // 8 + (2048 if adaptive else 256) * (n_bytes // metablock_bytes + 2)
 
-    def generate_batch(self, sources, metablock_bytes=65536, switches=False):
+    def generate_batch(self, sources, metablock_bytes=65536, switches=False, adaptive=False):
         """list of bytes -> list of Brotli streams (host buffers; the work happens on the device).  switches: two literal
-        block types taking turns every 100 literals (BRX_GEN_SWITCHES)."""
+        block types taking turns every 100 literals (BRX_GEN_SWITCHES).  adaptive: the wave-per-stream generator with codes
+        from each meta-block's statistics, two literal trees behind a context map, real block switches (BRX_GEN_ADAPTIVE)."""
         n = len(sources)
         if n == 0:
             return []
         src_off = np.zeros(n + 1, dtype=np.uint64)
         src_off[1:] = np.cumsum([len(x) for x in sources], dtype=np.uint64)
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        out_off[1:] = np.cumsum([self.generate_slot_bytes(len(x), metablock_bytes) for x in sources], dtype=np.uint64)
+        out_off[1:] = np.cumsum([self.generate_slot_bytes(len(x), metablock_bytes, adaptive) for x in sources], dtype=np.uint64)
         blob = np.frombuffer(b"".join(sources) or b"\0", dtype=np.uint8)
         out = np.zeros(int(out_off[-1]), dtype=np.uint8)
         out_len = np.zeros(n, dtype=np.uint64)
         status = np.full(n, -1, dtype=np.int32)
-        opts = _Opts(MEM_HOST | (GEN_SWITCHES if switches else 0), 0, None)
+        opts = _Opts(MEM_HOST | (GEN_SWITCHES if switches else 0) | (GEN_ADAPTIVE if adaptive else 0), 0, None)
         rc = self._lib.brx_generate_batch(self._h, blob.ctypes.data, src_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
                                           out_len.ctypes.data, status.ctypes.data, metablock_bytes, ctypes.byref(opts))
         if rc != 0:
@@ -188,9 +190,9 @@ class Context:
         return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
 
     def generate_batch_device(self, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr, metablock_bytes=65536,
-                              hip_stream=None, switches=False):
+                              hip_stream=None, switches=False, adaptive=False):
         """Raw device pointers (e.g. torch tensors): nothing leaves the GPU."""
-        opts = _Opts(MEM_DEVICE | (GEN_SWITCHES if switches else 0), 0, hip_stream)
+        opts = _Opts(MEM_DEVICE | (GEN_SWITCHES if switches else 0) | (GEN_ADAPTIVE if adaptive else 0), 0, hip_stream)
         rc = self._lib.brx_generate_batch(self._h, src_ptr, src_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
                                           metablock_bytes, ctypes.byref(opts))
         if rc != 0:

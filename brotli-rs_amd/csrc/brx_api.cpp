@@ -677,6 +677,9 @@ extern "C" int brx_synchronize(brx_ctx *c, void *hip_stream) {
 void brx_launch_generate(const void *src, const uint64_t *src_off, uint32_t n, void *out, const uint64_t *out_off,
                          uint64_t *out_len, int32_t *status, const void *header, uint32_t header_bits, uint32_t mb_bytes,
                          uint32_t switches, uint32_t *hash, void *hip_stream);
+void brx_launch_generate_adaptive(const void *src, const uint64_t *src_off, uint32_t n, void *out, const uint64_t *out_off,
+                                  uint64_t *out_len, int32_t *status, uint32_t mb_bytes, uint32_t *hash, void *cmds, uint32_t cmd_cap,
+                                  const void *context_lut, void *hip_stream);
 
 extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
                                   const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
@@ -701,16 +704,30 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
         HIP_TRY(hipMalloc(&c->d_gen_header, sizeof BRX_GEN_HEADER));
         HIP_TRY(hipMemcpy(c->d_gen_header, BRX_GEN_HEADER, sizeof BRX_GEN_HEADER, hipMemcpyHostToDevice));
     }
-    const uint32_t per_launch = 32768;  // streams per launch: bounds the hash tables (8 KiB per stream) at 256 MiB
-    const size_t hash_bytes = (size_t)std::min(n, per_launch) * 2048u * 4u;
+    // BRX_GEN_ADAPTIVE: one wavefront per stream, codes from the meta-block's own statistics; the commands of the meta-block
+    // being written wait in a scratch list (12 bytes each, at most one per 4 input bytes)
+    hipStream_t st_for_run = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
+    const bool adaptive = (flags & BRX_GEN_ADAPTIVE) != 0;
+    const uint32_t cmd_cap = metablock_bytes / 4u + 2u;
+    const size_t per_stream = 2048u * 4u + (adaptive ? (size_t)cmd_cap * 12u : 0u);
+    // streams per launch: bounds the scratch (hash tables, 8 KiB per stream; command lists) at ~1 GiB
+    const uint32_t per_launch = (uint32_t)std::min<size_t>(32768, std::max<size_t>(64, ((size_t)1 << 30) / per_stream));
+    const size_t hash_bytes = (size_t)std::min(n, per_launch) * per_stream;
+    auto run = [&](const void *s_, const uint64_t *so, uint32_t m, void *o_, const uint64_t *oo, uint64_t *ol, int32_t *stt) {
+        if (adaptive)
+            brx_launch_generate_adaptive(s_, so, m, o_, oo, ol, stt, metablock_bytes, (uint32_t *)c->st_gen,
+                                         c->st_gen + (size_t)std::min(n, per_launch) * 2048u * 4u, cmd_cap, c->d_lut, st_for_run);
+        else
+            brx_launch_generate(s_, so, m, o_, oo, ol, stt, c->d_gen_header + header_at, header_bits, metablock_bytes, switches,
+                                (uint32_t *)c->st_gen, st_for_run);
+    };
     hipStream_t st = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
     if (flags & BRX_MEM_DEVICE) {
         int rc = grow(&c->st_gen, &c->st_gen_cap, hash_bytes);
         if (rc) return rc;
         for (uint32_t k = 0; k < n; k += per_launch) { // (same stream: the launches run one after the other and share the tables)
             const uint32_t m = std::min(per_launch, n - k);
-            brx_launch_generate(src, src_off + k, m, out, out_off + k, out_len + k, status + k, c->d_gen_header + header_at, header_bits,
-                                metablock_bytes, switches, (uint32_t *)c->st_gen, st);
+            run(src, src_off + k, m, out, out_off + k, out_len + k, status + k);
             HIP_TRY(hipGetLastError());
         }
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
@@ -735,8 +752,7 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     HIP_TRY(hipMemcpyAsync(d_soff, h.data(), 2 * tab, hipMemcpyHostToDevice, st));
     for (uint32_t k = 0; k < n; k += per_launch) {
         const uint32_t m = std::min(per_launch, n - k);
-        brx_launch_generate(c->st_gen + a_src, d_soff + k, m, c->st_gen + a_out, d_ooff + k, d_len + k, d_st + k,
-                            c->d_gen_header + header_at, header_bits, metablock_bytes, switches, (uint32_t *)c->st_gen, st);
+        run(c->st_gen + a_src, d_soff + k, m, c->st_gen + a_out, d_ooff + k, d_len + k, d_st + k);
         HIP_TRY(hipGetLastError());
     }
     if (o_bytes) HIP_TRY(hipMemcpyAsync(out + o_lo, c->st_gen + a_out, o_bytes, hipMemcpyDeviceToHost, st));

@@ -1700,6 +1700,11 @@
     s_call_b64 LINKD, .Lswitch
     s_cbranch_scc1 .Lx_r0_bail
     s_mov_b32 IBLEN, T0
+    // (the switch's own reads may have rolled the input staging into the last dwords of the stream and POISONED the
+    // counters meanwhile -- .Lnear_end saved the stale ones: the new count is the real one, the live one stays poisoned)
+    s_bitcmp1_b32 FLAGS, 0
+    s_cselect_b32 IBLEN_REAL, IBLEN, IBLEN_REAL
+    s_cselect_b32 IBLEN, 0, IBLEN
     ds_read_b32 v20, VZERO offset:LDS_MBW+24            // hi: handle table of the insert&copy trees
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 T2, v20
@@ -1730,6 +1735,9 @@
     s_call_b64 LINKD, .Lswitch
     s_cbranch_scc1 .Lexit                               // (nothing changed: the C++ side finds the run as it is)
     s_add_u32 LBLEN, T0, 1                              // (run form: literals that can be decoded before the next switch)
+    s_bitcmp1_b32 FLAGS, 0                              // (poisoned during the switch: see .Lx_r0_switch)
+    s_cselect_b32 LBLEN_REAL, LBLEN, LBLEN_REAL
+    s_cselect_b32 LBLEN, 0, LBLEN
     s_bitcmp1_b32 FLAGS, 5
     s_cbranch_scc0 .Lsw_L_done                          // one literal tree: no context map
     ds_read_b32 v20, VZERO offset:LDS_MBW+12            // cml: byte address of the literal context map
@@ -1753,6 +1761,9 @@
     s_call_b64 LINKD, .Lswitch
     s_cbranch_scc1 .Lx_lit_switch
     s_mov_b32 LBLEN, T0
+    s_bitcmp1_b32 FLAGS, 0                              // (poisoned during the switch: see .Lx_r0_switch)
+    s_cselect_b32 LBLEN_REAL, LBLEN, LBLEN_REAL
+    s_cselect_b32 LBLEN, 0, LBLEN
     ds_read_b32 v20, VZERO offset:LDS_MBW+12
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 T2, v20

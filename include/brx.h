@@ -73,6 +73,11 @@ enum {
 #define BRX_MEM_DEVICE 1u /* every pointer argument (data, offset tables, out_len, status) is device memory */
 #define BRX_OPT_TIMING 2u /* record HIP-event timings of the kernels of this call (brx_last_timing) */
 #define BRX_GEN_SWITCHES 8u /* brx_generate_batch only: two literal block types taking turns every 100 literals */
+#define BRX_GEN_ADAPTIVE 16u /* brx_generate_batch only: the adaptive generator -- one wavefront per stream, prefix codes built
+                                from each meta-block's own statistics (<= 15 bits, complex form with zero runs), two literal
+                                trees behind a context map (mode UTF8), two literal block types switching every 1200 / 700
+                                literals, last-distance codes; a slot of  len + len / 8 + 2048 * (len / metablock_bytes + 2)
+                                bytes always suffices */
 #define BRX_OPT_ORDER 4u  /* BRX_MEM_DEVICE only: queue the longest compressed streams first (a ragged batch finishes when
                              its longest stream does).  Costs one synchronous read of the offset table; the host-pointer
                              path always orders.  The work queue itself is dynamic: a wave that finishes a stream takes the

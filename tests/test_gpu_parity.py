@@ -959,3 +959,56 @@ def test_compact_batch_kernel_matches_the_gather_by_index(ctx):
     b, b_off = shard.compact(out, out_off, out_len)
     assert torch.equal(a_off, b_off) and a.numel() == sum(lens)
     assert torch.equal(a, b)
+
+
+def test_adaptive_generator_round_trip(ctx):
+    """BRX_GEN_ADAPTIVE (csrc/brx_gen.hip, one wavefront per stream): prefix codes built from each meta-block's statistics,
+    two literal trees behind a UTF8 context map, two literal block types switching every 1200 / 700 literals, last-distance
+    codes.  Every stream must decode back to its input with the oracle AND with the HIP path; the oracle's census must show
+    what the streams were built to contain; text must shrink well below what the flat-code generator reaches."""
+    rng = random.Random(78)
+    alice, lcet = _read("alice29.txt"), _read("lcet10.txt")
+    sources = [alice, lcet[:300000], alice[:70000], alice[1000:1004], b"", b"x", b"ab" * 40000, bytes(70001), rng.randbytes(5000),
+               rng.randbytes(65536), alice[:65536], alice[:65537], alice[:65535], (alice[:3000] + rng.randbytes(200)) * 40,
+               _read("asyoulik.txt"), rng.randbytes(3) * 30000, bytes(range(256)) * 300, b"a", b"ab", b"abc", b"abcd", b"abcde",
+               bytes([7]) * 5, alice[:1199], alice[:1200], alice[:1201], alice[:1901]]
+    for mb in (65536, 4096, 1 << 20, 1000, 300):
+        streams = ctx.generate_batch(sources, metablock_bytes=mb, adaptive=True)
+        for i, (src, s) in enumerate(zip(sources, streams)):
+            st, out = oracle.decode(s, 0, cap=len(src) + 64)
+            assert st == 0 and out == src, (mb, i, st, len(src), len(s))
+        outs, status, out_len = ctx.decode_batch(streams, [len(x) + (i % 13) for i, x in enumerate(sources)])
+        assert not status.any(), (mb, status)
+        assert all(o == x for o, x in zip(outs, sources)), mb
+        assert all(len(s) <= ctx.generate_slot_bytes(len(x), mb, adaptive=True) for s, x in zip(streams, sources))
+        if mb >= 65536:
+            stats = oracle.decode(streams[0], want_stats=True)[2]
+            assert stats["meta_blocks"] == -(-len(alice) // mb), stats
+            assert stats["block_switches"] >= 30, stats          # ~ one per 950 literals
+            assert len(streams[0]) < 0.50 * len(alice), (mb, len(streams[0]))   # entropy coding on top of LZ77 (flat codes: 65 %)
+            assert len(streams[6]) < 600 and len(streams[7]) < 600               # fills collapse
+    # 1 MiB streams with the shape of BASELINE config 5: ~80 block switches each, 16 meta-blocks
+    big = (lcet + alice + _read("plrabn12.txt"))[: 1 << 20]
+    streams = ctx.generate_batch([big, big[::-1]], metablock_bytes=65536, adaptive=True)
+    for src, s in zip((big, big[::-1]), streams):
+        st, out, stats = oracle.decode(s, want_stats=True)
+        assert st == 0 and out == src and stats["meta_blocks"] == 16 and stats["block_switches"] >= 30, stats
+    outs, status, _ = ctx.decode_batch(streams, 1 << 20)
+    assert not status.any() and outs[0] == big and outs[1] == big[::-1]
+
+
+def test_regression_streams(ctx):
+    """Streams that once decoded wrong (tests/golden/regress/: stream + expected bytes, found by tools/gen_fuzz.py).
+    r03_switch_poison: a 2.7 KB stream of the adaptive generator whose literal block switch reads its count code just as the
+    input staging reaches the last dwords of the stream (the loop's counters were poisoned under the switch's feet)."""
+    d = os.path.join(GOLDEN, "regress")
+    names = sorted(f[:-len(".compressed")] for f in os.listdir(d) if f.endswith(".compressed"))
+    streams = [open(os.path.join(d, n + ".compressed"), "rb").read() for n in names]
+    expects = [open(os.path.join(d, n), "rb").read() for n in names]
+    for s, e in zip(streams, expects):
+        st, out = oracle.decode(s, 0, cap=len(e) + 64)
+        assert st == 0 and out == e
+    for reps in (1, 300):
+        outs, status, _ = ctx.decode_batch(streams * reps, [len(e) + 16 for e in expects] * reps)
+        assert not status.any(), status[:8]
+        assert all(o == e for o, e in zip(outs, expects * reps))

@@ -44,13 +44,17 @@ for r in range(rounds):
         sources.append(bytes(d))
     mb = rng.choice((200, 1000, 4096, 65536, 1 << 20))
     sw = rng.random() < 0.5
-    made = ctx.generate_batch(sources, metablock_bytes=mb, switches=sw)
+    ad = r % 2 == 1  # every other round: the adaptive generator (codes from statistics, context map, real block switches)
+    made = ctx.generate_batch(sources, metablock_bytes=mb, switches=sw, adaptive=ad)
     outs, status, out_len = ctx.decode_batch(made, [len(s) + rng.randrange(0, 40) for s in sources])
     for i, (src, o, st) in enumerate(zip(sources, outs, status)):
         total += 1
         if st != 0 or o != src:
             bad += 1
-            print("MISMATCH round trip", r, i, int(st), len(src), mb, sw)
+            print("MISMATCH round trip", r, i, int(st), len(src), mb, sw, ad)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "genfuzz_fail_%d_%d.src" % (r, i)), "wb").write(src)
+            open(os.path.join(ROOT, "gpurun_out", "genfuzz_fail_%d_%d.compressed" % (r, i)), "wb").write(made[i])
     cs = []
     for s in made:
         m = bytearray(s)
@@ -70,7 +74,7 @@ for r in range(rounds):
         total += 1
         if int(st) != e[0] or (e[0] == 0 and o != e[1]):
             bad += 1
-            print("MISMATCH corrupted", r, i, int(st), e[0], mb, sw, cs[i][:16].hex())
-    print("round %d (meta-blocks of %d, switches %s): %d streams so far, %d mismatches" % (r, mb, sw, total, bad), flush=True)
+            print("MISMATCH corrupted", r, i, int(st), e[0], mb, sw, ad, cs[i][:16].hex())
+    print("round %d (meta-blocks of %d, %s): %d streams so far, %d mismatches" % (r, mb, "adaptive" if ad else "switches %s" % sw, total, bad), flush=True)
 ctx.close()
 sys.exit(1 if bad else 0)
