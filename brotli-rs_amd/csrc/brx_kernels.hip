@@ -661,6 +661,34 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
     u32 cur = 0;
     bool dirty = false;
 #define BRX_LENS_FLUSH(base_) do { if (dirty) s.lens[(base_) + lane] = (u8)cur; cur = 0u; dirty = false; } while (0)
+    if (nonzero >= 2u) {
+        // the loop below in hand-written assembly (brx_lens.S: same reader, same rules, ~22 instructions per length instead of
+        // the ~60 the compiler makes of it); the one-symbol code-length code (no bits at all, Q5) stays with the C++ form
+        u32 stat, nz_a, i_a, dirty_a, cur_a, vt0, vt1;
+        u64 win = d.win;
+        u32 nav = d.nav, ww = d.ww, cbase = d.cbase, cha = d.chunkA, chb = d.chunkB;
+        asm volatile(
+#if BRX_LEVEL == 0
+#include "_gen/brx_lens_asm.h"
+#elif BRX_LEVEL == 1
+#include "_gen/brx_lens_asm_l1.h"
+#elif BRX_LEVEL == 2
+#include "_gen/brx_lens_asm_l2.h"
+#else
+#include "_gen/brx_lens_asm_l3.h"
+#endif
+            : "=s"(stat), "=s"(nz_a), "=s"(i_a), "=s"(dirty_a), "+s"(win), "+s"(nav), "+s"(ww), "+s"(cbase), "+v"(cha), "+v"(chb),
+              "=&v"(cur_a), "=&v"(vt0), "=&v"(vt1)
+            : "s"(alphabet), "s"(d.w_end), "s"(d.hb_lastw), "s"(d.hb_lastmask), "s"((u64)(uintptr_t)d.in_words), "v"(cltab), "v"(lane)
+            : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+              "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90");
+        d.win = win; d.nav = nav; d.ww = ww; d.cbase = cbase; d.chunkA = cha; d.chunkB = chb;
+        if (dirty_a) s.lens[((i_a - 1u) & ~63u) + lane] = (u8)cur_a;
+        PT_ADD(8, pt);
+        if (stat) return stat;
+        if (nz_a < 2u) return ST_LESS_THAN_TWO_NONZERO;
+        return ST_OK;
+    }
     while (i < alphabet) {
         u32 sym;
         if (nonzero == 1u) {
