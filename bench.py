@@ -130,7 +130,7 @@ def kernel_source_id():
     """sha256 (16 hex digits) of the kernel sources: ties a committed PMC traffic measurement to the kernel it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("brx_hot.S", "brx_kernels.hip", "brx_device.h"):
+    for f in ("brx_hot.S", "brx_lens.S", "brx_kernels.hip", "brx_device.h"):
         h.update(open(os.path.join(ROOT, "brotli-rs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
