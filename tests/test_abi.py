@@ -95,3 +95,7 @@ def test_assembly_loop_passes_the_wait_state_lint():
                            env=dict(os.environ, ASM_DEFS=defs))
         assert r.returncode == 0, r.stdout + r.stderr
         assert "0 finding(s)" in r.stdout
+    # the code-length symbol loop of the header path (an asm statement with operands: stand-in registers for the lint)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py"), os.path.join(ROOT, "brotli-rs_amd", "csrc", "brx_lens.S")],
+                       capture_output=True, text=True, env=dict(os.environ, ASM_DEFS="LDS_LENS=8960"))
+    assert r.returncode == 0 and "0 finding(s)" in r.stdout, r.stdout + r.stderr

@@ -29,6 +29,12 @@ def disassemble():
     with tempfile.TemporaryDirectory() as t:
         pp, obj = os.path.join(t, "hot.s"), os.path.join(t, "hot.o")
         subprocess.check_call(["cpp", "-P", "-x", "assembler-with-cpp"] + ["-D" + d for d in os.environ.get("ASM_DEFS", "").split()] + [SRC, "-o", pp])
+        txt = open(pp).read()
+        if "@" in txt:  # an asm statement with operands (brx_lens.S): `@n@` = operand n -- stand-in registers for the lint
+            ops = {0: "s0", 1: "s1", 2: "s2", 3: "s3", 4: "s[4:5]", 5: "s6", 6: "s7", 7: "s8", 8: "v8", 9: "v9", 10: "v10", 11: "v11",
+                   12: "v12", 13: "s13", 14: "s14", 15: "s15", 16: "s16", 17: "s[18:19]", 18: "v18", 19: "v19"}
+            txt = re.sub(r"@(\d+)@", lambda m: ops[int(m.group(1))], txt)
+            open(pp, "w").write(txt)
         subprocess.check_call([CLANG, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", pp, "-o", obj])
         out = subprocess.check_output([OBJDUMP, "-d", obj]).decode()
     ins = []
