@@ -46,6 +46,8 @@ def _build_locked(verbose):
     prof = ["-DBRX_PROF"] if os.environ.get("BRX_PROF") == "1" else []  # bring-up: timers inside the loop
     if os.environ.get("BRX_NO_SPEC") == "1":
         prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
+    if os.environ.get("BRX_PIN_NOPS"):
+        prof.append("-DPIN_NOPS=%d" % int(os.environ["BRX_PIN_NOPS"]))  # A/B: position of the loop (profiles/r03_pins.txt)
     # two builds of the loop (brx_hot.S, "Two builds of this file"): bit window in VGPRs (full chip) / in SGPRs (few waves per CU)
     # ... each for the four instances of the kernel (brx_device.h: the wider ones have their LDS offsets LDS_GROW further up)
     variants = [("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_")]

@@ -435,13 +435,7 @@
 #endif
 
 // ======================================================================================================== entry
-    // Where the loop sits relative to the 32-byte instruction fetch windows is worth 2 % (measured: all 8 dword offsets, both
-    // builds; profiles/r02_alignment.txt): pin it -- 256-byte alignment, then the offset that measured best.
     .p2align 8
-    s_nop 0
-    s_nop 0
-    s_nop 0
-    s_nop 0
     s_getreg_b32 PRIOW, hwreg(HW_REG_HW_ID, 0, 4)       // this wave's slot in its SIMD (phase of the priority rotation, .Lspecial)
     s_waitcnt vmcnt(0) lgkmcnt(0)
     v_mov_b32 VZERO, 0
@@ -787,6 +781,17 @@
     s_branch .Lr1
 
 // ======================================================================================================== R0
+// Where the loop sits relative to the 32-byte instruction fetch windows is worth 2 - 5 % (measured: all 8 dword offsets, both
+// builds; profiles/r02_alignment.txt, profiles/r03_pins.txt): pin it -- 256-byte alignment right in FRONT OF THE LOOP (the entry
+// code above ends with a branch: the padding is never executed, and edits of the entry code no longer move the loop), then the
+// offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
+#ifndef PIN_NOPS
+#define PIN_NOPS 10
+#endif
+    .p2align 8
+    .rept PIN_NOPS
+    s_nop 0
+    .endr
 // .Lcmd: the lookup of the insert&copy symbol from scratch (the uncommon copy paths end here);
 // .Lcmd_pre: entered from the common copy paths, which issued the lookup's compare and fetches at .Lcopy.
 #ifdef BRX_NO_SPEC
@@ -1073,8 +1078,9 @@
 .endm
     LIT_LOOP _u, 0, 4
     LIT_LOOP _m, 1, 8
-// resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway), tree pair through the
-// VGPR index mode
+// resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway; the same on the vector side --
+// three uniform VALU instructions + v_readfirstlane for four SALU -- measured slower at every loop position, profiles/r03_ab.txt),
+// tree pair through the VGPR index mode
 .Llit_r_start:
     v_lshrrev_b32 VT0, 2, VC                            // (this loop works on the context id itself, not id * 4)
     v_lshrrev_b32 VT1, 2, VB4
