@@ -188,6 +188,14 @@
 #define VTREES1 v71
 #define VCMIDX v55          // (entry only) 4 * tree index per context id
 #define VCMAP v86           // lane c: 2 * tree index of context id c (the M0 value of its pair)
+// -DBRX_DIST_RESIDENT (the sparse-launch build): limits / folded bases of the four distance-context trees of the current block
+// type in v87..v94 (pairs, reached through M0 like the literal trees): no LDS round trip for a tree's header in front of a
+// distance symbol.  Costs three scalar instructions per distance symbol -- for launches that leave the scalar ALU idle.
+#define VDTREES v87
+#define VDTREES1 v88
+#ifdef BRX_WIN_SGPR
+#define BRX_DIST_RESIDENT
+#endif
 
 // The bit window (a VGPR pair with the same value in every lane, or an SGPR pair: see TAKE); bits are taken from its low end; SNAV =
 // number of valid bits (>= 32 after a REFILL_CHECK).  A lone wave pays ~4.2 cycles per instruction, ~10 per scalar
@@ -755,6 +763,9 @@
     s_cselect_b32 DCTX, 4, DCTX
     s_mov_b32 T0, 0xc0000000
     v_writelane_b32 VDH4, T0, 4                         // "tree" of an implicit distance code 0
+#ifdef BRX_DIST_RESIDENT
+    s_call_b64 LINKB, .Lload_dtrees
+#endif
     s_mov_b32 EXITC, 1
     s_and_b32 T0, VFL, 0xfffffc00
     s_add_u32 T0, T0, 1024                              // BRX_FLUSH_BLOCK + BRX_FLUSH_LAG
@@ -786,7 +797,11 @@
 // code above ends with a branch: the padding is never executed, and edits of the entry code no longer move the loop), then the
 // offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
 #ifndef PIN_NOPS
+#ifdef BRX_WIN_SGPR
+#define PIN_NOPS 8                                      // (the sparse-launch build, with its resident distance trees: profiles/r03_ab.txt)
+#else
 #define PIN_NOPS 10
+#endif
 #endif
     .p2align 8
     .rept PIN_NOPS
@@ -824,9 +839,11 @@
     PROF_MARK s23                                       // insert&copy symbol (+ extras; + entry)
     // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
     v_readlane_b32 DTREE, VDH4, DCTX
+#ifndef BRX_DIST_RESIDENT
     s_nop 1
     v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
     ds_read_b64 VDH, VT0
+#endif
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
@@ -837,8 +854,22 @@
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
 .Ldist_ticked:                                          // (back from a distance block switch)
+#ifdef BRX_DIST_RESIDENT
+    s_lshl_b32 T6, DCTX, 1
+    v_bfrev_b32 VR, WSRC
+    v_lshrrev_b32 VU, 1, VR
+    v_lshrrev_b32 VI, VSH, VR
+    s_set_gpr_idx_on T6, 6                              // SRC1 | SRC2 + T6
+    v_cmp_lt_u32 vcc, VU, VDTREES
+    v_lshl_add_u32 VI, VI, 2, VDTREES1
+    s_set_gpr_idx_off
+    ds_read_b32 VS, VI
+    s_ff1_i32_b32 CLEN, vcc_lo
+    TAKE CLEN, 5
+#else
     s_waitcnt lgkmcnt(0)
     LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF, 5
+#endif
     s_waitcnt lgkmcnt(0)
     // payload of the distance symbol (decode_distance :1412-1481): extra-bit count | base << 5, or (bit 31) one of the 16
     // last-distance codes / a symbol without payload form (BRX_DIST_UNFIT: handed back with its bits un-taken)
@@ -1819,10 +1850,15 @@
     s_mov_b32 T2, 0xc0000000
     v_writelane_b32 VDH4, T2, 4                         // "tree" of an implicit distance code 0
     s_nop 0                                             // (a VALU-written VGPR needs one wait state before v_readlane)
+#ifdef BRX_DIST_RESIDENT
+    s_call_b64 LINKB, .Lload_dtrees
+    v_readlane_b32 DTREE, VDH4, DCTX
+#else
     v_readlane_b32 DTREE, VDH4, DCTX
     s_nop 1
     v_add_u32 VT0, DTREE, VLANE8
     ds_read_b64 VDH, VT0
+#endif
     s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc0 .Ldist_ticked
     s_and_b32 DCODE, DTREE, 0xffff                      // a one-symbol tree (always a last-distance code here)
@@ -1831,6 +1867,31 @@
     s_mov_b32 DBLEN, 0
     s_mov_b32 INS, 0
     s_branch .Lexit
+#ifdef BRX_DIST_RESIDENT
+// limits and folded bases ((base << 2) + address of the symbol list) of the four distance-context trees named by VDH4 into
+// v87..v94.  A one-symbol tree (descriptor < 0) has no header: its pair is never used (.Ldist_special).  Clobbers T2, T3, VT0, VLB.
+.Lload_dtrees:
+    s_mov_b32 T3, 0
+.Lld_loop:
+    v_readlane_b32 T2, VDH4, T3
+    s_cmp_lt_i32 T2, 0
+    s_cbranch_scc1 .Lld_next
+    v_add_u32 VT0, T2, VLANE8
+    ds_read_b64 VLB, VT0
+    s_add_u32 T2, T2, SYMOFF
+    s_waitcnt lgkmcnt(0)
+    v_lshl_add_u32 VBASE, VBASE, 2, T2
+    s_lshl_b32 T2, T3, 1
+    s_set_gpr_idx_on T2, 8                              // VGPR index mode, destination + T2
+    v_mov_b32 VDTREES, VLIM
+    v_mov_b32 VDTREES1, VBASE
+    s_set_gpr_idx_off
+.Lld_next:
+    s_add_u32 T3, T3, 1
+    s_cmp_lt_u32 T3, 4
+    s_cbranch_scc1 .Lld_loop
+    s_setpc_b64 LINKB
+#endif
 
 // ======================================================================================================== exits
 .Lx_dist_unfit:                                         // back to R1 with the literals done: the C++ side reads the distance
