@@ -188,12 +188,13 @@
 #define VTREES1 v71
 #define VCMIDX v55          // (entry only) 4 * tree index per context id
 #define VCMAP v86           // lane c: 2 * tree index of context id c (the M0 value of its pair)
-// -DBRX_DIST_RESIDENT (the sparse-launch build): limits / folded bases of the four distance-context trees of the current block
-// type in v87..v94 (pairs, reached through M0 like the literal trees): no LDS round trip for a tree's header in front of a
-// distance symbol.  Costs three scalar instructions per distance symbol -- for launches that leave the scalar ALU idle.
+// BRX_DIST_RESIDENT: limits / folded bases of the four distance-context trees of the current block type in v87..v94 (pairs,
+// reached through M0 like the literal trees): no LDS round trip for a tree's header in front of a distance symbol, at the price of
+// three scalar instructions per distance symbol.  Sparse launches -5 % (config 5 48.3 -> 45.9 ms), a full chip -0.7 %
+// (profiles/r03_ab.txt; each build at its own best position).  The serial-fetch A/B build (BRX_NO_SPEC) keeps the LDS form.
 #define VDTREES v87
 #define VDTREES1 v88
-#ifdef BRX_WIN_SGPR
+#ifndef BRX_NO_SPEC
 #define BRX_DIST_RESIDENT
 #endif
 
@@ -798,9 +799,9 @@
 // offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
 #ifndef PIN_NOPS
 #ifdef BRX_WIN_SGPR
-#define PIN_NOPS 8                                      // (the sparse-launch build, with its resident distance trees: profiles/r03_ab.txt)
+#define PIN_NOPS 8                                      // (the sparse-launch build: profiles/r03_ab.txt)
 #else
-#define PIN_NOPS 10
+#define PIN_NOPS 11
 #endif
 #endif
     .p2align 8
