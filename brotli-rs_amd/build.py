@@ -48,6 +48,8 @@ def _build_locked(verbose):
         prof.append("-DBRX_NO_SPEC")  # A/B: serial symbol fetch instead of the lane-speculative one
     if os.environ.get("BRX_PIN_NOPS"):
         prof.append("-DPIN_NOPS=%d" % int(os.environ["BRX_PIN_NOPS"]))  # A/B: position of the loop (profiles/r03_pins.txt)
+    extra = ["-D" + d for d in os.environ.get("BRX_DEFS", "").split()]  # A/B: defines for the loop AND the C++ side
+    prof += extra
     # two builds of the loop (brx_hot.S, "Two builds of this file"): bit window in VGPRs (full chip) / in SGPRs (few waves per CU)
     # ... each for the four instances of the kernel (brx_device.h: the wider ones have their LDS offsets LDS_GROW further up)
     variants = [("brx_hot_asm.h", [], None), ("brx_hot_asm_sw.h", ["-DBRX_WIN_SGPR"], ".LS_")]
@@ -77,7 +79,7 @@ def _build_locked(verbose):
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
     if os.environ.get("BRX_BRINGUP") == "1" or os.environ.get("BRX_PROF") == "1":
         cmd.append("-DBRX_BRINGUP")  # bring-up: BRX_DEBUG_STATS / BRX_DEBUG_STOP=9 + BRX_DEBUG_DUMP (tools/gpu_dumps.sh, tools/span_stats.py)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += extra + [os.path.join(CSRC, s) for s in SOURCES]
     tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
     cmd += ["-o", tmp]
     if verbose:

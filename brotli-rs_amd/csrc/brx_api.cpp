@@ -249,14 +249,15 @@ static int ctx_init(brx_ctx *c, int device) {
         static const uint8_t cell_ins[11] = {0, 0, 0, 0, 8, 8, 0, 16, 8, 16, 16}, cell_cpy[11] = {0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16};
         static const uint8_t ndbits[25] = {0, 0, 0, 0, 10, 10, 11, 11, 10, 10, 10, 10, 10, 9, 9, 8, 7, 7, 8, 7, 7, 6, 6, 5, 5};
         // record of symbol s = dwords 4s .. 4s+3 (one s_load_dwordx4 of the assembly loop, straight into its INS / CPY /
-        // DCTX registers): insert base, copy base, distance context min(copy_len - 2, 3) -- a function of the copy code --
-        // or 4 for an implicit distance code 0 (src/lib.rs:2012-2015), insert extra bits | copy extra bits << 8
+        // DCTX registers): insert base, copy base, 2 * distance context (min(copy_len - 2, 3), a function of the copy
+        // code; 4 for an implicit distance code 0, src/lib.rs:2012-2015 -- doubled: the loop uses it as the lane of the tree's
+        // descriptor and as the offset of the tree's register pair), insert extra bits | copy extra bits << 8
         std::vector<uint32_t> t(704 * 4 + 64, 0u);
         for (unsigned sym = 0; sym < 704; sym++) {
             unsigned cell = sym >> 6, ic = cell_ins[cell] + ((sym >> 3) & 7u), cc = cell_cpy[cell] + (sym & 7u);
             t[4 * sym] = ins_base[ic];
             t[4 * sym + 1] = cpy_base[cc];
-            t[4 * sym + 2] = sym < 128 ? 4u : (cc < 3u ? cc : 3u);
+            t[4 * sym + 2] = 2u * (sym < 128 ? 4u : (cc < 3u ? cc : 3u));
             t[4 * sym + 3] = ins_extra[ic] | ((uint32_t)cpy_extra[cc] << 8);
         }
         uint32_t off = 0;

@@ -61,7 +61,7 @@ struct BrxDeviceTables {
     const uint8_t *context_lut; // Lut0 | Lut1 | Lut2, 3 x 256 B
     const BrxTransform *xforms; // 121 entries
     const uint32_t *iac;        // insert&copy symbol records for the assembly loop (brx_hot.S): 704 x {insert base, copy
-                                // base, distance context (4 = implicit distance 0), insert extra bits | copy extra bits
+                                // base, 2 * distance context (4 = implicit distance 0), insert extra bits | copy extra bits
                                 // << 8}, then at dword 2816 64 dwords DOFFSET | NDBITS << 24
 };
 

@@ -82,7 +82,6 @@
 #define VFL s54
 #define FLUSHAT s55
 #define WINDOW s56
-#define D0 s57
 #define INS s92                 // INS, CPY, DCTX and s95 are one insert&copy record (s_load_dwordx4)
 #define CPY s93
 #define MBLEFT s61              // scratch: bytes left in the meta-block = MBEND - POS, computed where needed
@@ -139,9 +138,7 @@
 #define VS v7
 #define VLEN v54
 #define VDP v55
-#define VD1 v65
-#define VD2 v68
-#define VD3 v69
+#define VRING v65               // lanes 0..3 = the four last distances, most recent first (pushed by one DPP row shift)
 #define VPA v8
 #define VLHOFF v9
 #define VDHOFF v10
@@ -322,6 +319,14 @@
     s_call_b64 LINKA, .Lspecial
     s_branch .Lrf_back_\id
 .endm
+// A register-resident tree keeps its limits as COUNTS -- lane L: limit[L] in units of L-bit codes (first_code + count), the
+// header word >> (31 - L) -- so that its compare works on the candidate index the lane computes anyway (the top L bits of
+// the window) and no 31-bit copy of the window is needed: one VALU instruction less per lookup (profiles/r03_ab.txt).
+// (Lane 0 of a general tree stays 0 = never; the all-ones lane 0 of a resident one-symbol tree stays "always".)
+.macro TO_COUNTS reg, tmp
+    v_add_u32 \tmp, -1, VSH
+    v_lshrrev_b32 \reg, \tmp, \reg
+.endm
 // Canonical prefix-code lookup (table layout: brx_kernels.hip, "Table layout in table memory").
 // lim = per-lane limit[L] << 16 (lane 0: 0), base = per-lane base[L] of the tree (lane L, L = 1..15; lanes >= 16 repeat).
 // Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
@@ -360,7 +365,7 @@
 .endm
 .macro LOOKUP2F lim, basep, scale, rd, rid
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
+    v_lshrrev_b32 VU, VSH, VR                           // (limits of a resident tree are counts: TO_COUNTS)
     v_cmp_lt_u32 vcc, VU, \lim
     s_ff1_i32_b32 CLEN, vcc_lo
     v_readlane_b32 T3, \basep, CLEN
@@ -373,7 +378,7 @@
 .endm
 .macro LOOKUP2X rid
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
+    v_lshrrev_b32 VU, VSH, VR
     s_set_gpr_idx_on T6, 2
     v_cmp_lt_u32 vcc, VU, VTREES
     s_set_gpr_idx_off
@@ -404,10 +409,9 @@
 // v_movrel) redirects the second source of the compare (limits) and the third of the shift-add (folded bases).
 .macro LOOKUP2X rid
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
     v_lshrrev_b32 VI, VSH, VR
     s_set_gpr_idx_on T6, 6                              // SRC1 | SRC2 + T6
-    v_cmp_lt_u32 vcc, VU, VTREES
+    v_cmp_lt_u32 vcc, VI, VTREES
     v_lshl_add_u32 VI, VI, 1, VTREES1
     s_set_gpr_idx_off
     ds_read_u16 VS, VI
@@ -418,9 +422,8 @@
 // folded once when the tree is loaded, so the candidate address is one shift and one shift-add.
 .macro LOOKUP2F lim, basep, scale, rd, rid
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
-    v_cmp_lt_u32 vcc, VU, \lim
     v_lshrrev_b32 VI, VSH, VR
+    v_cmp_lt_u32 vcc, VI, \lim                          // (limits as counts: TO_COUNTS)
     v_lshl_add_u32 VI, VI, \scale, \basep
     \rd VS, VI
     s_ff1_i32_b32 CLEN, vcc_lo                          // code length
@@ -431,9 +434,8 @@
 // under the copy's bookkeeping.  vcc, VS (and VR, VU, VI) must survive in between: the common copy paths write none of them.
 .macro LOOKUP2F_EARLY lim, basep, scale, rd
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
-    v_cmp_lt_u32 vcc, VU, \lim
     v_lshrrev_b32 VI, VSH, VR
+    v_cmp_lt_u32 vcc, VI, \lim
     v_lshl_add_u32 VI, VI, \scale, \basep
     \rd VS, VI
 .endm
@@ -474,9 +476,9 @@
     v_readfirstlane_b32 SKEW, v31
     v_readfirstlane_b32 VFL, v32
     v_readfirstlane_b32 WINDOW, v33
-    v_readfirstlane_b32 D0, v34
-    v_mov_b32 VD1, v35
-    ds_read_b64 v[20:21], VZERO offset:LDS_ST+64        // dist2, dist3
+    v_min_u32 VRING, 3, VLANE
+    v_lshlrev_b32 VRING, 2, VRING
+    ds_read_b32 VRING, VRING offset:LDS_ST+56          // lane k = dist k
     ds_read_b32 v22, VZERO offset:LDS_ST+92             // t_dict (st[23], st[24]: only 4-byte aligned)
     ds_read_b32 v23, VZERO offset:LDS_ST+96
     ds_read_b32 v26, VZERO offset:LDS_ST+100            // t_xforms (st[25], st[26])
@@ -514,8 +516,6 @@
     v_lshlrev_b32 VT0, 2, VT0
     global_load_dword VCHB, VT0, INP
     s_waitcnt lgkmcnt(0)
-    v_mov_b32 VD2, v20
-    v_mov_b32 VD3, v21
     v_readfirstlane_b32 s76, v22
     v_readfirstlane_b32 s77, v23
     v_readfirstlane_b32 T4, v24
@@ -622,12 +622,13 @@
     v_readfirstlane_b32 T7, VT1                         // h of the insert&copy tree
     v_readfirstlane_b32 CMDW, VT2
     v_readfirstlane_b32 T0, VT3                         // context mode
-    // CMH[c] = descriptor of the literal tree of context id c; VDH4 lane k = descriptor of the distance tree of
+    // CMH[c] = descriptor of the literal tree of context id c; VDH4 lane 2k = descriptor of the distance tree of
     // distance context k (both for the current block types; a block switch leaves the loop and re-enters here)
     v_lshlrev_b32 VT4, 2, VT4
     v_mov_b32 VCMIDX, VT4
     ds_bpermute_b32 VT4, VT4, VLHOFF
-    v_lshlrev_b32 VT3, 3, VLANE
+    v_lshrrev_b32 VT3, 1, VLANE                         // lane 2k (and 2k + 1) = context k
+    v_lshlrev_b32 VT3, 3, VT3
     v_lshrrev_b32 VT3, VT3, CMDW
     v_and_b32 VT3, 0xff, VT3
     v_lshlrev_b32 VT3, 2, VT3
@@ -698,6 +699,7 @@
     s_add_u32 T7, T7, SYMOFF
     s_waitcnt lgkmcnt(0)
     v_lshl_add_u32 VBASE, VBASE, 1, T7                  // folded bases (LOOKUP2F)
+    TO_COUNTS VLIM, VT1
     s_branch .Lent_r_store
 .Lent_r_single:
     v_mov_b32 VLIM, 0
@@ -763,7 +765,8 @@
     s_cmp_lg_u32 IZ, 0
     s_cselect_b32 DCTX, 4, DCTX
     s_mov_b32 T0, 0xc0000000
-    v_writelane_b32 VDH4, T0, 4                         // "tree" of an implicit distance code 0
+    s_lshl_b32 DCTX, DCTX, 1                            // (kept doubled: VDH4 lane and resident register pair in one)
+    v_writelane_b32 VDH4, T0, 8                         // "tree" of an implicit distance code 0
 #ifdef BRX_DIST_RESIDENT
     s_call_b64 LINKB, .Lload_dtrees
 #endif
@@ -780,6 +783,8 @@
     s_cbranch_scc1 .Lexit
     v_lshl_add_u32 VIACB, VIACB, 1, HISYM               // folded bases of the resident trees (LOOKUP2F)
     v_lshl_add_u32 VLITB, VLITB, 1, LITSYM
+    TO_COUNTS VIACL, VT3
+    TO_COUNTS VLITL, VT3
     // (HISYM and LITSYM are free from here on) the context masks of the resident literal loop, which works on id, not id * 4:
     // id = ((info >> 2) & MA2) | share of the previous literal; share = ((info & MB) << SB) >> 2 = a bit field of the entry
     s_lshr_b32 MA2, MA, 2
@@ -799,7 +804,7 @@
 // offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
 #ifndef PIN_NOPS
 #ifdef BRX_WIN_SGPR
-#define PIN_NOPS 8                                      // (the sparse-launch build: profiles/r03_ab.txt)
+#define PIN_NOPS 5                                      // (the sparse-launch build: profiles/r03_ab.txt)
 #else
 #define PIN_NOPS 11
 #endif
@@ -856,12 +861,10 @@
     s_cbranch_scc1 .Lx_dist_switch
 .Ldist_ticked:                                          // (back from a distance block switch)
 #ifdef BRX_DIST_RESIDENT
-    s_lshl_b32 T6, DCTX, 1
     v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VU, 1, VR
     v_lshrrev_b32 VI, VSH, VR
-    s_set_gpr_idx_on T6, 6                              // SRC1 | SRC2 + T6
-    v_cmp_lt_u32 vcc, VU, VDTREES
+    s_set_gpr_idx_on DCTX, 6                            // SRC1 | SRC2 + 2 * context
+    v_cmp_lt_u32 vcc, VI, VDTREES
     v_lshl_add_u32 VI, VI, 2, VDTREES1
     s_set_gpr_idx_off
     ds_read_b32 VS, VI
@@ -890,10 +893,8 @@
     s_cmp_gt_u32 DIST, MAXA                             // MAXA: min(POS, WINDOW) as of its last exact evaluation (a lower bound)
     s_cbranch_scc1 .Ldict_check                         // :1476 not pushed: static dictionary reference
 .Ldist_push_ok:
-    v_mov_b32 VD3, VD2                                  // (only the most recent distance lives in an SGPR)
-    v_mov_b32 VD2, VD1
-    v_mov_b32 VD1, D0
-    s_mov_b32 D0, DIST
+    v_mov_b32_dpp VRING, VRING row_shr:1 row_mask:0xf bank_mask:0xf
+    v_writelane_b32 VRING, DIST, 0
 
 // ---- window copy of <= 64 bytes that does not overlap its source (copy_literals :1483-1542): takes the next CPY lanes
 // of the pending register
@@ -956,7 +957,7 @@
     s_bitcmp1_b32 DTREE, 30
     s_cbranch_scc0 .Ldist_single
 .Ldist_zero:
-    s_mov_b32 DIST, D0
+    v_readlane_b32 DIST, VRING, 0
     s_cmp_gt_u32 DIST, MAXA
     s_cbranch_scc0 .Lcopy
     s_min_u32 MAXA, POS, WINDOW
@@ -1199,9 +1200,9 @@
 .Ldist_ring_s:
     s_cmp_eq_u32 DCODE, 0
     s_cbranch_scc1 .Ldist_zero
-    v_readfirstlane_b32 T5, VD1
-    v_readfirstlane_b32 T6, VD2
-    v_readfirstlane_b32 T7, VD3
+    v_readlane_b32 T5, VRING, 1
+    v_readlane_b32 T6, VRING, 2
+    v_readlane_b32 T7, VRING, 3
     s_cmp_ge_u32 DCODE, 4
     s_cbranch_scc1 .Ldist_delta
     s_mov_b32 DIST, T5
@@ -1211,8 +1212,9 @@
     s_cselect_b32 DIST, T7, DIST
     s_branch .Ldist_push
 .Ldist_delta:
+    v_readlane_b32 T0, VRING, 0
     s_cmp_lt_u32 DCODE, 10
-    s_cselect_b32 T0, D0, T5
+    s_cselect_b32 T0, T0, T5
     s_cselect_b32 T1, 2, 8
     s_sub_u32 T1, DCODE, T1
     s_lshr_b32 T1, T1, 1
@@ -1759,6 +1761,7 @@
     ds_read_b64 VIAC, VT0
     s_waitcnt lgkmcnt(0)
     v_lshl_add_u32 VIACB, VIACB, 1, T3                  // folded bases (LOOKUP2F)
+    TO_COUNTS VIACL, VT1
     s_branch .Lcmd_ticked
 .Lx_r0_bail:                                            // insert&copy block count exhausted and not switched here (or poisoned)
     s_mov_b32 IBLEN, 0
@@ -1841,7 +1844,8 @@
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 CMDW, VT2
     s_mov_b64 exec, -1
-    v_lshlrev_b32 VT3, 3, VLANE
+    v_lshrrev_b32 VT3, 1, VLANE                         // lane 2k (and 2k + 1) = context k
+    v_lshlrev_b32 VT3, 3, VT3
     v_lshrrev_b32 VT3, VT3, CMDW
     v_and_b32 VT3, 0xff, VT3
     v_lshlrev_b32 VT3, 2, VT3
@@ -1849,7 +1853,7 @@
     s_waitcnt lgkmcnt(0)
     s_mov_b64 exec, XLOOP
     s_mov_b32 T2, 0xc0000000
-    v_writelane_b32 VDH4, T2, 4                         // "tree" of an implicit distance code 0
+    v_writelane_b32 VDH4, T2, 8                         // "tree" of an implicit distance code 0
     s_nop 0                                             // (a VALU-written VGPR needs one wait state before v_readlane)
 #ifdef BRX_DIST_RESIDENT
     s_call_b64 LINKB, .Lload_dtrees
@@ -1882,14 +1886,14 @@
     s_add_u32 T2, T2, SYMOFF
     s_waitcnt lgkmcnt(0)
     v_lshl_add_u32 VBASE, VBASE, 2, T2
-    s_lshl_b32 T2, T3, 1
-    s_set_gpr_idx_on T2, 8                              // VGPR index mode, destination + T2
+    TO_COUNTS VLIM, VT0
+    s_set_gpr_idx_on T3, 8                              // VGPR index mode, destination + T3
     v_mov_b32 VDTREES, VLIM
     v_mov_b32 VDTREES1, VBASE
     s_set_gpr_idx_off
 .Lld_next:
-    s_add_u32 T3, T3, 1
-    s_cmp_lt_u32 T3, 4
+    s_add_u32 T3, T3, 2
+    s_cmp_lt_u32 T3, 8
     s_cbranch_scc1 .Lld_loop
     s_setpc_b64 LINKB
 #endif
@@ -1948,19 +1952,17 @@
     ds_write_b32 VZERO, VT0 offset:LDS_ST+40
     v_mov_b32 VT0, VFL
     ds_write_b32 VZERO, VT0 offset:LDS_ST+48
-    v_mov_b32 v20, D0
-    v_mov_b32 v21, VD1
-    v_mov_b32 v22, VD2
-    v_mov_b32 v23, VD3
-    ds_write_b64 VZERO, v[20:21] offset:LDS_ST+56
-    ds_write_b64 VZERO, v[22:23] offset:LDS_ST+64
+    v_lshlrev_b32 VT0, 2, VLANE
+    s_mov_b64 exec, 15
+    ds_write_b32 VT0, VRING offset:LDS_ST+56
+    s_mov_b64 exec, XLOOP
     v_mov_b32 VT0, LBLEN
     ds_write_b32 VZERO, VT0 offset:LDS_MBW+60
     v_mov_b32 VT0, IBLEN
     ds_write_b32 VZERO, VT0 offset:LDS_MBW+84
     v_mov_b32 VT0, DBLEN
     ds_write_b32 VZERO, VT0 offset:LDS_MBW+108
-    s_cmp_eq_u32 DCTX, 4
+    s_cmp_eq_u32 DCTX, 8
     s_cselect_b32 IZ, 1, 0
     s_sub_u32 MBLEFT, MBEND, POS
     v_mov_b32 v20, MBLEFT

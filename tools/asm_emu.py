@@ -58,7 +58,7 @@ def disassemble(src):
     return prog
 
 
-_MODS = re.compile(r"\s+(offset:\d+|offen|off|glc|slc|sc0|sc1|nt|lds|gds)\b")
+_MODS = re.compile(r"\s+(offset:\d+|offen|off|glc|slc|sc0|sc1|nt|lds|gds|row_shr:\d+|row_mask:0x[0-9a-f]+|bank_mask:0x[0-9a-f]+|bound_ctrl:\d+)\b")
 
 
 def parse_operand(tok):
@@ -119,6 +119,9 @@ def decode_program(prog):
             for m in _MODS.findall(" " + args):
                 if m.startswith("offset:"):
                     i.mods["offset"] = int(m[7:])
+                elif m.startswith(("row_shr:", "row_mask:", "bank_mask:", "bound_ctrl:")):
+                    k_, v_ = m.split(":")
+                    i.mods[k_] = int(v_, 0)
                 else:
                     i.mods[m] = True
             core = _MODS.sub("", " " + args).strip()
@@ -558,6 +561,18 @@ class Wave:
             m_ = self.exec_mask()
             lane = 0 if m_ is None or not m_.any() else int(np.argmax(m_))
             self.sset(ops[0][1], int(self.V[ops[1][1]][lane]))
+        elif op == "v_mov_b32_dpp":
+            # row_shr:n: lane l of each row of 16 takes lane l - n of the same row; lanes with no source keep the
+            # destination (bound_ctrl off); all rows and banks enabled
+            if i.mods.get("row_mask", 15) != 15 or i.mods.get("bank_mask", 15) != 15 or i.mods.get("bound_ctrl") or "row_shr" not in i.mods:
+                raise EmuError("dpp form? " + i.text)
+            n_ = i.mods["row_shr"]
+            src_, old_ = self.vsrc(ops[1]).copy(), self.V[ops[0][1]].copy()
+            m_ = self.exec_mask()
+            for l in range(64):
+                if (m_ is None or m_[l]) and (l & 15) >= n_ and (m_ is None or m_[l - n_]):
+                    old_[l] = src_[l - n_]
+            self.V[ops[0][1]] = old_
         elif op == "v_readlane_b32":
             self.cycles += LAT["cross"]
             self.sset(ops[0][1], int(self.V[ops[1][1]][self.ssrc(ops[2]) & 63]))
@@ -718,7 +733,7 @@ def load_tables():
     for sym in range(704):
         cell = sym >> 6
         ic, cc = cell_ins[cell] + ((sym >> 3) & 7), cell_cpy[cell] + (sym & 7)
-        iac[4 * sym:4 * sym + 4] = [ins_base[ic], cpy_base[cc], 4 if sym < 128 else min(cc, 3), ins_extra[ic] | (cpy_extra[cc] << 8)]
+        iac[4 * sym:4 * sym + 4] = [ins_base[ic], cpy_base[cc], 2 * (4 if sym < 128 else min(cc, 3)), ins_extra[ic] | (cpy_extra[cc] << 8)]
     off = 0
     for n in range(25):
         iac[2816 + n] = off | (ndbits[n] << 24)

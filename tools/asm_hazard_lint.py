@@ -8,6 +8,7 @@ disassembly in fall-through order and reports the gfx940+/gfx950 data hazards th
   R2  VALU writes an SGPR                                                   ->  v_readlane / v_writelane lane select: 4
   R3  VALU writes an SGPR                                                   ->  VMEM uses it (address / resource): 5
   R4  VALU writes a VGPR                                                    ->  v_readlane / v_readfirstlane reads it: 1
+  R5  VALU writes a VGPR                                                    ->  a DPP instruction reads it: 2
 
 A wait state = any instruction issued in between (s_nop N counts N + 1).  Sequences are cut at unconditional control
 transfers; paths that ENTER a sequence through a taken branch are not modelled (the branch itself costs wait states).
@@ -88,6 +89,12 @@ def main():
                 for r in regs(srcs[0], "v"):
                     if r in last_vgpr and pos - last_vgpr[r] - 1 < 1:
                         found.append("R4: #%d %s %s reads v%d written by the previous VALU instruction" % (n, op, args, r))
+            if base.endswith("_dpp"):
+                for t in srcs:
+                    for r in regs(t, "v"):
+                        if r in last_vgpr and pos - last_vgpr[r] - 1 < 2:
+                            found.append("R5: #%d %s %s reads v%d through DPP %d slot(s) after a VALU wrote it (needs 2 between)"
+                                         % (n, op, args, r, pos - last_vgpr[r]))
         if vmem:
             for t in toks:
                 for r in regs(t, "s"):
