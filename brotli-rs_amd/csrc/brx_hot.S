@@ -78,6 +78,7 @@
 #define RSRC s[48:51]
 #define RSRC2 s[16:19]           // the host-visible mirror of the output slot (Dec::mirror), or a resource without records
 #define POS s52
+#define DSPEC s57               // bit 2k: distance context k has a one-symbol tree; bit 8 (implicit distance 0): always
 #define SKEW s53
 #define VFL s54
 #define FLUSHAT s55
@@ -283,12 +284,13 @@
     s_cbranch_scc1 .Lrf_stub_\rid
 .Lrf_back_\rid:
 .endm
-.macro TAKE_EXTRA dst, base, n, rid, shift=0
+.macro TAKE_EXTRA dst, base, n, rid, mul=0                // (\mul: an SGPR with the factor of the extra bits, \base then a VGPR)
     v_bfe_u32 VEX, VWINLO, 0, \n
-    .ifnc \shift,0
-    v_lshlrev_b32 VEX, \shift, VEX
-    .endif
+    .ifnc \mul,0
+    v_mad_u32_u24 VEX, VEX, \mul, \base                 // (at most 24 extra bits, a factor of at most 8)
+    .else
     v_add_u32 VEX, \base, VEX
+    .endif
     TAKE \n, \rid
     v_readfirstlane_b32 \dst, VEX
 .endm
@@ -541,6 +543,9 @@
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 FLAGS, v36
     v_readfirstlane_b32 NPOST, v20
+#ifndef BRX_WIN_SGPR
+    s_lshl_b32 NPOST, 1, NPOST                          // (this build multiplies: TAKE_EXTRA)
+#endif
     v_readfirstlane_b32 T0, v22                         // cmode_w
     v_readfirstlane_b32 T1, v23                         // cml
     v_readfirstlane_b32 T2, v24                         // cmd
@@ -844,8 +849,8 @@
 .Lr1:
     PROF_MARK s23                                       // insert&copy symbol (+ extras; + entry)
     // the distance tree depends on the copy code only: request its limits / bases now, use them after the literals
-    v_readlane_b32 DTREE, VDH4, DCTX
 #ifndef BRX_DIST_RESIDENT
+    v_readlane_b32 DTREE, VDH4, DCTX
     s_nop 1
     v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
     ds_read_b64 VDH, VT0
@@ -854,7 +859,11 @@
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
 .Lno_lits:
     PROF_MARK s29                                       // R1 dispatch + literals
+#ifdef BRX_DIST_RESIDENT
+    s_bitcmp1_b32 DSPEC, DCTX                           // (the trees are resident: no descriptor needed on the common path)
+#else
     s_cmp_lt_i32 DTREE, 0
+#endif
     s_cbranch_scc1 .Ldist_special                       // implicit distance 0, or a one-symbol tree
     // ---- distance symbol (reference parse_distance_code :1367-1410)
     s_sub_u32 DBLEN, DBLEN, 1
@@ -886,7 +895,7 @@
     TAKE_EXTRA DIST, T2, T1, 6, NPOST                      // base + (extra << NPOSTFIX)
 #else
     v_lshrrev_b32 VT0, 5, DCODE                         // (the base stays on the vector side)
-    TAKE_EXTRA DIST, VT0, T1, 6, NPOST                     // base + (extra << NPOSTFIX)
+    TAKE_EXTRA DIST, VT0, T1, 6, NPOST                     // base + extra * (1 << NPOSTFIX)
 #endif
 .Ldist_push:
     PROF_MARK s30                                       // distance symbol
@@ -954,6 +963,9 @@
     s_branch .Lcopy_end
 
 .Ldist_special:
+#ifdef BRX_DIST_RESIDENT
+    v_readlane_b32 DTREE, VDH4, DCTX
+#endif
     s_bitcmp1_b32 DTREE, 30
     s_cbranch_scc0 .Ldist_single
 .Ldist_zero:
@@ -1005,6 +1017,7 @@
     s_sub_u32 LBLEN, LBLEN, RUN
     s_add_u32 POS, POS, RUN
     s_sub_u32 RUN, RUN, 1
+    v_and_b32 VPA, RMASK, VPA                           // (the run before may have ended at the ring's end)
 .endm
 .macro LIT_RUN_END again, flush_stub
     s_cmp_ge_u32 POS, FLUSHAT
@@ -1127,12 +1140,11 @@
     LOOKUP2X \rid
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
-    v_and_b32 VT0, RMASK, VPA
-    v_add_u32 VPA, 1, VPA
-    v_mov_b32 VE, T0
-    ds_write_b8 VT0, VE
     s_bfe_u32 T1, T0, 0x6000a                           // context info of this literal >> 2
     s_and_b32 T1, T1, MA2
+    v_mov_b32 VE, T0                                    // (two instructions behind the v_readlane: VALU-written SGPR)
+    ds_write_b8 VPA, VE                                 // (VPA is a ring address and a run ends at the flush block's end at the latest)
+    v_add_u32 VPA, 1, VPA
     s_or_b32 T4, T1, T5                                 // context id of the next one
     s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
 .endm
@@ -1166,20 +1178,19 @@
 .Lhave_lits1:
     s_call_b64 LINKB, .Lland
     s_add_u32 T0, POS, SKEW
-    v_mov_b32 VPA, T0
+    v_bfe_u32 VPA, T0, 0, 11
     LIT_RUN_FAST .Llit1_run
     s_branch .Llit1
 .Llit1_run:
     LIT_RUN_SETUP .Lflush_stub_lit1, .Llsw_7
 .Llit1:
     LOOKUP2F VLITL, VLITB, 1, ds_read_u16, 7
-    v_and_b32 VT0, RMASK, VPA
-    v_add_u32 VPA, 1, VPA
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN
     s_nop 1
     v_mov_b32 VE, T0
-    ds_write_b8 VT0, VE
+    ds_write_b8 VPA, VE
+    v_add_u32 VPA, 1, VPA
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc0 .Llit1
     s_cmp_lg_u32 INS, 0
@@ -1316,7 +1327,7 @@
     LAND_BODY
 .Lland_ctx_ring:
     s_add_u32 T6, POS, SKEW
-    v_mov_b32 VPA, T6                                   // ring address of the next literal (masked when used)
+    v_bfe_u32 VPA, T6, 0, 11                            // ring address of the next literal (RMASK; a run never wraps: LIT_RUN_SETUP)
     v_add_u32 VT0, -1, VPA                              // (address arithmetic on the vector side: the scalar ALU is the
     v_add_u32 VT1, -2, VPA                              // unit all 16 waves of a CU share)
     v_and_b32 VT0, RMASK, VT0
@@ -1340,7 +1351,7 @@
 // can be pending with fewer than 2 bytes of output
 .Lland_ctx_start:
     s_add_u32 T6, POS, SKEW
-    v_mov_b32 VPA, T6
+    v_bfe_u32 VPA, T6, 0, 11
     v_mov_b32 VT0, 0
     v_mov_b32 VT1, 0
     s_cmp_eq_u32 POS, 0
@@ -1877,10 +1888,11 @@
 // v87..v94.  A one-symbol tree (descriptor < 0) has no header: its pair is never used (.Ldist_special).  Clobbers T2, T3, VT0, VLB.
 .Lload_dtrees:
     s_mov_b32 T3, 0
+    s_mov_b32 DSPEC, 0x100
 .Lld_loop:
     v_readlane_b32 T2, VDH4, T3
     s_cmp_lt_i32 T2, 0
-    s_cbranch_scc1 .Lld_next
+    s_cbranch_scc1 .Lld_single
     v_add_u32 VT0, T2, VLANE8
     ds_read_b64 VLB, VT0
     s_add_u32 T2, T2, SYMOFF
@@ -1896,6 +1908,9 @@
     s_cmp_lt_u32 T3, 8
     s_cbranch_scc1 .Lld_loop
     s_setpc_b64 LINKB
+.Lld_single:
+    s_bitset1_b32 DSPEC, T3
+    s_branch .Lld_next
 #endif
 
 // ======================================================================================================== exits

@@ -521,6 +521,10 @@ class Wave:
             self.vset(ops[0], self.vsrc(ops[1]) | self.vsrc(ops[2]) | self.vsrc(ops[3]))
         elif op == "v_add3_u32":
             self.vset(ops[0], self.vsrc(ops[1]) + self.vsrc(ops[2]) + self.vsrc(ops[3]))
+        elif op == "v_mad_u32_u24":
+            m24 = U32(0xffffff)
+            self.vset(ops[0], ((self.vsrc(ops[1]) & m24).astype(np.uint64) * (self.vsrc(ops[2]) & m24).astype(np.uint64)
+                               + self.vsrc(ops[3]).astype(np.uint64)).astype(np.uint32))
         elif op == "v_bfe_u32":
             a, off, wid = self.vsrc(ops[1]), self.vsrc(ops[2]) & U32(31), self.vsrc(ops[3]) & U32(31)
             self.vset(ops[0], (a >> off) & ((U32(1) << wid) - U32(1)))
