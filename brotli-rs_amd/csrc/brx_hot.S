@@ -78,7 +78,8 @@
 #define RSRC s[48:51]
 #define RSRC2 s[16:19]           // the host-visible mirror of the output slot (Dec::mirror), or a resource without records
 #define POS s52
-#define DSPEC s57               // bit 2k: distance context k has a one-symbol tree; bit 8 (implicit distance 0): always
+#define DSPEC s57               // bit 16 + 2k: distance context k has a one-symbol tree; bit 24 (implicit distance 0): always;
+                                // bit 2k: context k does not take the direct lookup (k < 3, or its tree is special)
 #define SKEW s53
 #define VFL s54
 #define FLUSHAT s55
@@ -123,6 +124,12 @@
 #define T6 s90
 #define T7 s91
 #define CLEN s96
+#ifndef BRX_PROF
+#define LITJ s[20:21]           // where an insert's literals go (.Lhave_lits): the loop of the meta-block's literal mode
+#define LITJLO s20
+#define LITJHI s21
+#define BFEBI s22               // BFEB for a bare context-info byte (offset - 8)
+#endif
 #define LINKB s[98:99]
 #define LINKC s[100:101]
 // FLAGS bits: 0 = block counters poisoned (near the end of the input), 3 = one literal tree, resident in VLITL / VLITB,
@@ -192,6 +199,8 @@
 // (profiles/r03_ab.txt; each build at its own best position).  The serial-fetch A/B build (BRX_NO_SPEC) keeps the LDS form.
 #define VDTREES v87
 #define VDTREES1 v88
+#define VD3L v93                // (the pair of distance context 3 by name)
+#define VD3B v94
 #ifndef BRX_NO_SPEC
 #define BRX_DIST_RESIDENT
 #endif
@@ -798,6 +807,21 @@
     s_cselect_b32 BFEB, 0x20008, BFEB                   // mode 2: info bits 1:0
     s_cmp_eq_u32 MB, 0x1c
     s_cselect_b32 BFEB, 0x3000a, BFEB                   // mode 3: info bits 4:2
+#ifndef BRX_PROF
+    s_sub_u32 BFEBI, BFEB, 8
+    s_cmp_eq_u32 BFEB, 0
+    s_cselect_b32 BFEBI, 0, BFEBI
+    // one indirect branch per insert instead of the chain of FLAGS tests
+    s_getpc_b64 LITJ
+.Llitj_base:
+    s_mov_b32 T0, .Llit_entry_g-.Llitj_base
+    s_bitcmp1_b32 FLAGS, 5
+    s_cselect_b32 T0, .Llit_r_entry-.Llitj_base, T0
+    s_bitcmp1_b32 FLAGS, 3
+    s_cselect_b32 T0, .Lhave_lits1-.Llitj_base, T0
+    s_add_u32 LITJLO, LITJLO, T0
+    s_addc_u32 LITJHI, LITJHI, 0
+#endif
     s_mov_b32 MAXA, 0
     s_mov_b64 exec, XLOOP
     s_branch .Lr1
@@ -809,7 +833,7 @@
 // offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
 #ifndef PIN_NOPS
 #ifdef BRX_WIN_SGPR
-#define PIN_NOPS 5                                      // (the sparse-launch build: profiles/r03_ab.txt)
+#define PIN_NOPS 7                                      // (the sparse-launch build: profiles/r03_ab.txt)
 #else
 #define PIN_NOPS 11
 #endif
@@ -860,26 +884,23 @@
 .Lno_lits:
     PROF_MARK s29                                       // R1 dispatch + literals
 #ifdef BRX_DIST_RESIDENT
-    s_bitcmp1_b32 DSPEC, DCTX                           // (the trees are resident: no descriptor needed on the common path)
+    // (the trees are resident: no descriptor needed on the common path.)  Five commands in six have a copy of 5 bytes or more,
+    // distance context 3: its tree pair is looked up by name -- the two scalar instructions of the VGPR index mode are
+    // the dearest ones here (DESIGN.md 4.1) -- the other contexts and the special trees go out of line (.Ldist_other)
+    s_bitcmp1_b32 DSPEC, DCTX
+    s_cbranch_scc1 .Ldist_other
 #else
     s_cmp_lt_i32 DTREE, 0
-#endif
     s_cbranch_scc1 .Ldist_special                       // implicit distance 0, or a one-symbol tree
+#endif
     // ---- distance symbol (reference parse_distance_code :1367-1410)
     s_sub_u32 DBLEN, DBLEN, 1
     s_cbranch_scc1 .Lx_dist_switch
-.Ldist_ticked:                                          // (back from a distance block switch)
 #ifdef BRX_DIST_RESIDENT
-    v_bfrev_b32 VR, WSRC
-    v_lshrrev_b32 VI, VSH, VR
-    s_set_gpr_idx_on DCTX, 6                            // SRC1 | SRC2 + 2 * context
-    v_cmp_lt_u32 vcc, VI, VDTREES
-    v_lshl_add_u32 VI, VI, 2, VDTREES1
-    s_set_gpr_idx_off
-    ds_read_b32 VS, VI
-    s_ff1_i32_b32 CLEN, vcc_lo
-    TAKE CLEN, 5
+    LOOKUP2F VD3L, VD3B, 2, ds_read_b32, 5
+.Ldist_have:
 #else
+.Ldist_ticked:                                          // (back from a distance block switch)
     s_waitcnt lgkmcnt(0)
     LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF, 5
 #endif
@@ -962,6 +983,25 @@
     s_cbranch_scc0 .Lcmd_pre
     s_branch .Lcopy_end
 
+#ifdef BRX_DIST_RESIDENT
+.Ldist_other:
+    s_add_u32 T0, DCTX, 16
+    s_bitcmp1_b32 DSPEC, T0
+    s_cbranch_scc1 .Ldist_special
+    s_sub_u32 DBLEN, DBLEN, 1
+    s_cbranch_scc1 .Lx_dist_switch
+.Ldist_ticked:                                          // (back from a distance block switch, too: any context)
+    v_bfrev_b32 VR, WSRC
+    v_lshrrev_b32 VI, VSH, VR
+    s_set_gpr_idx_on DCTX, 6                            // SRC1 | SRC2 + 2 * context
+    v_cmp_lt_u32 vcc, VI, VDTREES
+    v_lshl_add_u32 VI, VI, 2, VDTREES1
+    s_set_gpr_idx_off
+    ds_read_b32 VS, VI
+    s_ff1_i32_b32 CLEN, vcc_lo
+    TAKE CLEN, 15
+    s_branch .Ldist_have
+#endif
 .Ldist_special:
 #ifdef BRX_DIST_RESIDENT
     v_readlane_b32 DTREE, VDH4, DCTX
@@ -1060,11 +1100,28 @@
     s_branch .Lrf_back_\general_id
 .endm
 
+// (LAND_BODY: see "helpers" below, .Lland)
+.macro LAND_BODY
+    s_add_u32 T6, PBASE, SKEW
+    s_bfm_b64 exec, PFREE, 0
+    v_add_u32 VT1, T6, VLANE
+    v_and_b32 VT1, RMASK, VT1
+    PROF_WAIT_VM
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    ds_write_b8 VT1, VPEND
+    s_mov_b64 exec, XLOOP
+    s_mov_b32 PFREE, 0
+    s_mov_b32 PBASE, POS
+.endm
 // ---- literals (reference parse_insert_literals :1286-1365)
 .Lhave_lits:
     s_sub_u32 MBLEFT, MBEND, POS
     s_cmp_gt_u32 INS, MBLEFT
     s_cbranch_scc1 .Lexit                               // :2036, raised by the C++ side
+#ifndef BRX_PROF
+    s_setpc_b64 LITJ
+.Llit_entry_g:
+#endif
     s_bitcmp1_b32 FLAGS, 3
     s_cbranch_scc1 .Lhave_lits1
     s_call_b64 LINKB, .Lland_ctx                        // pending bytes into the ring, context of the first literal, VPA
@@ -1127,12 +1184,46 @@
 // resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway; the same on the vector side --
 // three uniform VALU instructions + v_readfirstlane for four SALU -- measured slower at every loop position, profiles/r03_ab.txt),
 // tree pair through the VGPR index mode
+#ifndef BRX_PROF
+// (.Lhave_lits jumps here) pending bytes into the ring, then the context of the first literal straight into the scalar
+// registers of this loop -- .Lland_ctx + .Llit_r_start without the detour through the vector-side form
+.Llit_r_entry:
+    s_cmp_lt_u32 POS, 2
+    s_cbranch_scc1 .Llit_r_entry_start
+    s_cmp_eq_u32 PFREE, 0
+    s_cbranch_scc1 .Llit_r_entry_ring
+    LAND_BODY
+.Llit_r_entry_ring:
+    s_add_u32 T6, POS, SKEW
+    v_bfe_u32 VPA, T6, 0, 11
+    v_add_u32 VT0, -1, VPA
+    v_add_u32 VT1, -2, VPA
+    v_and_b32 VT0, RMASK, VT0
+    v_and_b32 VT1, RMASK, VT1
+    ds_read_u8 VT0, VT0
+    ds_read_u8 VT1, VT1
+    s_waitcnt lgkmcnt(0)
+    ds_read_u8 VT3, VT0 offset:LDS_ITAB                 // info(p1)
+    ds_read_u8 VT4, VT1 offset:LDS_ITAB                 // info(p2)
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T6, VT3
+    v_readfirstlane_b32 T7, VT4
+    s_bfe_u32 T1, T6, 0x60002
+    s_and_b32 T1, T1, MA2
+    s_bfe_u32 T5, T6, BFEBI                             // p1's share as a later p2
+    s_bfe_u32 T7, T7, BFEBI
+    s_or_b32 T4, T1, T7                                 // context id of the first literal
+    s_branch .Llit_r_go
+.Llit_r_entry_start:                                    // (the first two bytes of a stream)
+    s_call_b64 LINKB, .Lland_ctx
+#endif
 .Llit_r_start:
     v_lshrrev_b32 VT0, 2, VC                            // (this loop works on the context id itself, not id * 4)
     v_lshrrev_b32 VT1, 2, VB4
     s_nop 0
     v_readfirstlane_b32 T4, VT0                         // context id of the first literal
     v_readfirstlane_b32 T5, VT1                         // p1's share as a later p2
+.Llit_r_go:
 // A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
 // LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
 .macro LIT_R_BODY rid
@@ -1277,18 +1368,6 @@
 // literals never sit between pending copies: a literal run lands everything first).  One masked byte store.
 // Clobbers T6, VT1.  .Lland_ctx also derives the literal context from the last two bytes of the stream (VC = id * 4,
 // VB4 = p1's share as a future p2) and requests the tree descriptor of the first literal.
-.macro LAND_BODY
-    s_add_u32 T6, PBASE, SKEW
-    s_bfm_b64 exec, PFREE, 0
-    v_add_u32 VT1, T6, VLANE
-    v_and_b32 VT1, RMASK, VT1
-    PROF_WAIT_VM
-    s_waitcnt vmcnt(0) lgkmcnt(0)
-    ds_write_b8 VT1, VPEND
-    s_mov_b64 exec, XLOOP
-    s_mov_b32 PFREE, 0
-    s_mov_b32 PBASE, POS
-.endm
 .macro FLUSH_BODY lbl
     s_mov_b64 exec, -1
 \lbl:
@@ -1443,6 +1522,9 @@
     REFILL_STUB 12
     REFILL_STUB 13
     REFILL_STUB 14
+#ifdef BRX_DIST_RESIDENT
+    REFILL_STUB 15
+#endif
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
@@ -1888,7 +1970,7 @@
 // v87..v94.  A one-symbol tree (descriptor < 0) has no header: its pair is never used (.Ldist_special).  Clobbers T2, T3, VT0, VLB.
 .Lload_dtrees:
     s_mov_b32 T3, 0
-    s_mov_b32 DSPEC, 0x100
+    s_mov_b32 DSPEC, 0x01000115
 .Lld_loop:
     v_readlane_b32 T2, VDH4, T3
     s_cmp_lt_i32 T2, 0
@@ -1910,6 +1992,8 @@
     s_setpc_b64 LINKB
 .Lld_single:
     s_bitset1_b32 DSPEC, T3
+    s_add_u32 T2, T3, 16
+    s_bitset1_b32 DSPEC, T2
     s_branch .Lld_next
 #endif
 

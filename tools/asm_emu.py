@@ -459,6 +459,12 @@ class Wave:
             self.sset64(ops[0][1], i.addr + 4)
             nxt = self.index[i.target]
             self.cycles += LAT["branch_taken"]
+        elif op == "s_getpc_b64":
+            self.sset64(ops[0][1], i.addr + 4)
+        elif op == "s_addc_u32":
+            r = self.ssrc(ops[1]) + self.ssrc(ops[2]) + self.scc
+            self.scc = 1 if r > MASK32 else 0
+            self.sset(ops[0][1], r)
         elif op == "s_setpc_b64":
             nxt = self.index[self.s64(ops[0][1])]
             self.cycles += LAT["branch_taken"]
