@@ -816,7 +816,10 @@
 .Llitj_base:
     s_mov_b32 T0, .Llit_entry_g-.Llitj_base
     s_bitcmp1_b32 FLAGS, 5
-    s_cselect_b32 T0, .Llit_r_entry-.Llitj_base, T0
+    s_cselect_b32 T0, .Llit_r_entry_mx-.Llitj_base, T0
+    s_cselect_b32 T1, 0x1c, -1                          // (... of context mode 3: MB = 0x1c)
+    s_cmp_eq_u32 T1, MB
+    s_cselect_b32 T0, .Llit_r_entry_m3-.Llitj_base, T0
     s_bitcmp1_b32 FLAGS, 3
     s_cselect_b32 T0, .Lhave_lits1-.Llitj_base, T0
     s_add_u32 LITJLO, LITJLO, T0
@@ -833,9 +836,9 @@
 // offset that measured best (-DPIN_NOPS=n: n dwords; the default puts .Lcmd where rounds 2 and 3 measured it best).
 #ifndef PIN_NOPS
 #ifdef BRX_WIN_SGPR
-#define PIN_NOPS 7                                      // (the sparse-launch build: profiles/r03_ab.txt)
+#define PIN_NOPS 5                                      // (the sparse-launch build: profiles/r03_ab.txt)
 #else
-#define PIN_NOPS 11
+#define PIN_NOPS 7
 #endif
 #endif
     .p2align 8
@@ -1184,39 +1187,7 @@
 // resident trees: context arithmetic on the scalar side (the entry arrives in an SGPR anyway; the same on the vector side --
 // three uniform VALU instructions + v_readfirstlane for four SALU -- measured slower at every loop position, profiles/r03_ab.txt),
 // tree pair through the VGPR index mode
-#ifndef BRX_PROF
-// (.Lhave_lits jumps here) pending bytes into the ring, then the context of the first literal straight into the scalar
-// registers of this loop -- .Lland_ctx + .Llit_r_start without the detour through the vector-side form
-.Llit_r_entry:
-    s_cmp_lt_u32 POS, 2
-    s_cbranch_scc1 .Llit_r_entry_start
-    s_cmp_eq_u32 PFREE, 0
-    s_cbranch_scc1 .Llit_r_entry_ring
-    LAND_BODY
-.Llit_r_entry_ring:
-    s_add_u32 T6, POS, SKEW
-    v_bfe_u32 VPA, T6, 0, 11
-    v_add_u32 VT0, -1, VPA
-    v_add_u32 VT1, -2, VPA
-    v_and_b32 VT0, RMASK, VT0
-    v_and_b32 VT1, RMASK, VT1
-    ds_read_u8 VT0, VT0
-    ds_read_u8 VT1, VT1
-    s_waitcnt lgkmcnt(0)
-    ds_read_u8 VT3, VT0 offset:LDS_ITAB                 // info(p1)
-    ds_read_u8 VT4, VT1 offset:LDS_ITAB                 // info(p2)
-    s_waitcnt lgkmcnt(0)
-    v_readfirstlane_b32 T6, VT3
-    v_readfirstlane_b32 T7, VT4
-    s_bfe_u32 T1, T6, 0x60002
-    s_and_b32 T1, T1, MA2
-    s_bfe_u32 T5, T6, BFEBI                             // p1's share as a later p2
-    s_bfe_u32 T7, T7, BFEBI
-    s_or_b32 T4, T1, T7                                 // context id of the first literal
-    s_branch .Llit_r_go
-.Llit_r_entry_start:                                    // (the first two bytes of a stream)
-    s_call_b64 LINKB, .Lland_ctx
-#endif
+#ifdef BRX_PROF
 .Llit_r_start:
     v_lshrrev_b32 VT0, 2, VC                            // (this loop works on the context id itself, not id * 4)
     v_lshrrev_b32 VT1, 2, VB4
@@ -1258,6 +1229,158 @@
     LIT_RUN_END .Llit_r_run, .Lflush_stub_lit_r
     LIT_RUN_STUBS 9, .Llit_r_run, .Lflush_stub_lit_r
     LIT_RUN_FAST_STUB 10, 9
+#else
+// Two variants of these loops, picked at entry through LITJ:
+//   m3  context mode 3 (signed): id = lut2(p1) << 3 | lut2(p2), and a literal's share as p1 and as p2 is the same 3-bit value --
+//       one s_bfe + one s_lshl3_add_u32 per literal, the loop unrolled twice so that "this" and "previous" swap registers
+//       (T7 / T5: both survive a refill and .Lspecial; T1 does not in the sparse-launch build) instead of being copied
+//   mx  the other modes: the six bits of the p1 share need no mask there (MA2 = 0x3f)
+// (.Lhave_lits jumps to .Llit_r_entry_*) pending bytes into the ring, then the context of the first literal straight into the
+// scalar registers of the loop -- .Lland_ctx without the detour through the vector-side form
+.macro LIT_CTX_ENTRY v
+.Llit_r_entry_\v:
+    s_cmp_lt_u32 POS, 2
+    s_cbranch_scc1 .Llit_r_entry_start_\v
+    s_cmp_eq_u32 PFREE, 0
+    s_cbranch_scc1 .Llit_r_entry_ring_\v
+    LAND_BODY
+.Llit_r_entry_ring_\v:
+    s_add_u32 T6, POS, SKEW
+    v_bfe_u32 VPA, T6, 0, 11
+    v_add_u32 VT0, -1, VPA
+    v_add_u32 VT1, -2, VPA
+    v_and_b32 VT0, RMASK, VT0
+    v_and_b32 VT1, RMASK, VT1
+    ds_read_u8 VT0, VT0
+    ds_read_u8 VT1, VT1
+    s_waitcnt lgkmcnt(0)
+    ds_read_u8 VT3, VT0 offset:LDS_ITAB                 // info(p1)
+    ds_read_u8 VT4, VT1 offset:LDS_ITAB                 // info(p2)
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T6, VT3
+    v_readfirstlane_b32 T7, VT4
+    s_bfe_u32 T1, T6, 0x60002
+    s_and_b32 T1, T1, MA2
+    s_bfe_u32 T5, T6, BFEBI                             // p1's share as a later p2
+    s_bfe_u32 T7, T7, BFEBI
+    s_or_b32 T4, T1, T7                                 // context id of the first literal
+    s_branch .Llit_r_go_\v
+.Llit_r_entry_start_\v:                                 // (the first two bytes of a stream)
+    s_call_b64 LINKB, .Lland_ctx
+.ifc \v,mx
+.Llit_r_start:
+.endif
+    v_lshrrev_b32 VT0, 2, VC                            // (this loop works on the context id itself, not id * 4)
+    v_lshrrev_b32 VT1, 2, VB4
+    s_nop 0
+    v_readfirstlane_b32 T4, VT0                         // context id of the first literal
+    v_readfirstlane_b32 T5, VT1                         // p1's share as a later p2
+.Llit_r_go_\v:
+.endm
+// A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
+// LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
+// One literal: T4 = its context id.  \cur = register that takes this literal's share, \prev = the one holding the previous one's.
+.macro LIT_R_HEAD rid
+    v_readlane_b32 T6, VCMAP, T4                        // 2 * tree index
+    LOOKUP2X \rid
+    s_waitcnt lgkmcnt(0)
+    v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
+.endm
+.macro LIT_R_STORE
+    v_mov_b32 VE, T0                                    // (two instructions behind the v_readlane: VALU-written SGPR)
+    ds_write_b8 VPA, VE                                 // (VPA is a ring address and a run ends at the flush block's end at the latest)
+    v_add_u32 VPA, 1, VPA
+.endm
+.macro LIT_R_BODY_M3 rid, cur, prev
+    LIT_R_HEAD \rid
+    s_bfe_u32 \cur, T0, 0x3000d                         // lut2 of this literal (context info bits 7:5 = bits 4:2)
+    s_lshl3_add_u32 T4, \cur, \prev                     // context id of the next one
+    LIT_R_STORE
+.endm
+.macro LIT_R_BODY_MX rid
+    LIT_R_HEAD \rid
+    s_bfe_u32 T1, T0, 0x6000a                           // context info of this literal >> 2: its share as p1
+    s_or_b32 T4, T1, T5                                 // context id of the next one
+    LIT_R_STORE
+    s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
+.endm
+.macro LIT_RF_STUB id, back_id                          // (the refill part of LIT_RUN_STUBS / LIT_RUN_FAST_STUB)
+.Lrf_stub_\id:
+    REFILL_CORE
+    s_cbranch_scc1 .Lrf_back_\id
+    s_add_u32 INS, INS, RUN                             // the run ends with the literal in progress (its bits are taken):
+    s_add_u32 LBLEN, LBLEN, RUN                         // RUN = the literals behind it
+    s_sub_u32 POS, POS, RUN
+    s_mov_b32 RUN, 0
+    s_call_b64 LINKA, .Lspecial
+    s_branch .Lrf_back_\back_id
+.endm
+.macro LIT_RUN_TAIL_FAST
+    s_mov_b32 PBASE, POS
+    s_cmp_eq_u32 POS, MBEND
+    s_cbranch_scc0 .Lno_lits
+    s_branch .Lexit
+.endm
+.macro LIT_RUN_AUX v                                    // (the out-of-line parts of LIT_RUN_STUBS that are not refills)
+.Llsw_\v:                                               // the literal block is used up at a run's start: switch, set the run up again
+    s_call_b64 LINKB, .Lsw_L
+    s_branch .Llit_r_run_\v
+.Lflush_stub_lit_r_\v:
+    s_call_b64 LINKC, .Lflush
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc1 .Llit_r_run_\v
+    s_branch .Lafter_lits
+.endm
+// ---- m3
+    LIT_CTX_ENTRY m3
+    LIT_RUN_FAST .Llit_r_run_m3
+.Llit_rf_m3:
+    LIT_R_BODY_M3 40, T7, T5
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc1 .Lafter_lits_fast_m3
+    LIT_R_BODY_M3 41, T5, T7
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc0 .Llit_rf_m3
+.Lafter_lits_fast_m3:
+    LIT_RUN_TAIL_FAST
+.Llit_r_run_m3:
+    LIT_RUN_SETUP .Lflush_stub_lit_r_m3, .Llsw_m3
+.Llit_r_m3:
+    LIT_R_BODY_M3 42, T7, T5
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc1 .Llit_r_m3_odd
+    LIT_R_BODY_M3 43, T5, T7
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc0 .Llit_r_m3
+.Llit_r_m3_end:
+    LIT_RUN_END .Llit_r_run_m3, .Lflush_stub_lit_r_m3
+.Llit_r_m3_odd:                                         // (the next run starts with the previous share in T5 again)
+    s_mov_b32 T5, T7
+    s_branch .Llit_r_m3_end
+    LIT_RUN_AUX m3
+    LIT_RF_STUB 40, 42
+    LIT_RF_STUB 41, 43
+    LIT_RF_STUB 42, 42
+    LIT_RF_STUB 43, 43
+// ---- mx
+    LIT_CTX_ENTRY mx
+    LIT_RUN_FAST .Llit_r_run_mx
+.Llit_rf_mx:
+    LIT_R_BODY_MX 44
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc0 .Llit_rf_mx
+    LIT_RUN_TAIL_FAST
+.Llit_r_run_mx:
+    LIT_RUN_SETUP .Lflush_stub_lit_r_mx, .Llsw_mx
+.Llit_r_mx:
+    LIT_R_BODY_MX 45
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc0 .Llit_r_mx
+    LIT_RUN_END .Llit_r_run_mx, .Lflush_stub_lit_r_mx
+    LIT_RUN_AUX mx
+    LIT_RF_STUB 44, 45
+    LIT_RF_STUB 45, 45
+#endif
 .Lafter_lits:
     s_mov_b32 INS, 0
     s_mov_b32 PBASE, POS                                // (nothing is pending here)

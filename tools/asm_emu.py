@@ -459,6 +459,10 @@ class Wave:
             self.sset64(ops[0][1], i.addr + 4)
             nxt = self.index[i.target]
             self.cycles += LAT["branch_taken"]
+        elif op in ("s_lshl1_add_u32", "s_lshl2_add_u32", "s_lshl3_add_u32", "s_lshl4_add_u32"):
+            r = (self.ssrc(ops[1]) << int(op[6])) + self.ssrc(ops[2])
+            self.scc = 1 if r > MASK32 else 0
+            self.sset(ops[0][1], r)
         elif op == "s_getpc_b64":
             self.sset64(ops[0][1], i.addr + 4)
         elif op == "s_addc_u32":
