@@ -90,7 +90,9 @@ def test_assembly_loop_passes_the_wait_state_lint():
     assembler inserts no wait states into hand-written code)."""
     import subprocess
     import sys
-    for defs in ("", "BRX_WIN_SGPR"):  # both builds of the loop
+    # both builds of the loop, then the build-time switches kept for A/B and bring-up (serial symbol fetch; in-loop timers):
+    # they have their own copies of the lookups / the literal dispatch and must keep assembling
+    for defs in ("", "BRX_WIN_SGPR", "BRX_NO_SPEC", "BRX_NO_SPEC BRX_WIN_SGPR", "BRX_PROF"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py")], capture_output=True, text=True,
                            env=dict(os.environ, ASM_DEFS=defs))
         assert r.returncode == 0, r.stdout + r.stderr

@@ -463,6 +463,8 @@ class Wave:
             r = (self.ssrc(ops[1]) << int(op[6])) + self.ssrc(ops[2])
             self.scc = 1 if r > MASK32 else 0
             self.sset(ops[0][1], r)
+        elif op == "s_brev_b32":
+            self.sset(ops[0][1], int("{:032b}".format(self.ssrc(ops[1]) & MASK32)[::-1], 2))
         elif op == "s_getpc_b64":
             self.sset64(ops[0][1], i.addr + 4)
         elif op == "s_addc_u32":
