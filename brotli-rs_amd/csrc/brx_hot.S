@@ -940,19 +940,18 @@
 #ifndef BRX_NO_SPEC
     LOOKUP2F_EARLY VIACL, VIACB, 1, ds_read_u16         // the NEXT command's insert&copy symbol (.Lcmd_pre)
 #endif
-    s_add_u32 T3, PFREE, CPY
+    s_bfm_b64 exec, CPY, PFREE                          // the copy's lanes (only scalar instructions up to the address: the mask is
+    s_add_u32 PFREE, PFREE, CPY                         // made while PFREE is still the old one, PFREE moves in place: .Lcopy_slow_undo)
     s_min_u32 T0, DIST, 63
-    s_cmp_gt_u32 T3, T0
-    s_cbranch_scc1 .Lcopy_slow
+    s_cmp_gt_u32 PFREE, T0
+    s_cbranch_scc1 .Lcopy_slow_undo
     s_sub_u32 T2, PBASE, DIST                           // + lane = position of this lane's source byte  (PBASE = POS - PFREE)
     s_cmp_gt_u32 DIST, RING
     s_cbranch_scc0 .Lcopy_near
     // older than the ring: final in HBM (never pending bytes: what is pending is younger than one flush block)
-    s_bfm_b64 exec, CPY, PFREE
     v_add_u32 VT0, T2, VLANE
     buffer_load_ubyte VPEND, VT0, RSRC, 0 offen
     s_mov_b64 exec, XLOOP
-    s_mov_b32 PFREE, T3
     s_add_u32 POS, POS, CPY
 .Lcopy_tail_pre:
     s_cmp_ge_u32 POS, MBEND
@@ -975,12 +974,10 @@
 // ---- source inside the ring (final bytes: the test above keeps it clear of the pending ones)
 .Lcopy_near:
     s_add_u32 T2, T2, SKEW
-    s_bfm_b64 exec, CPY, PFREE
     v_add_u32 VT0, T2, VLANE
     v_and_b32 VT0, RMASK, VT0
     ds_read_u8 VPEND, VT0
     s_mov_b64 exec, XLOOP
-    s_mov_b32 PFREE, T3
     s_add_u32 POS, POS, CPY
     s_cmp_ge_u32 POS, MBEND
     s_cbranch_scc0 .Lcmd_pre
@@ -1104,7 +1101,7 @@
 .endm
 
 // (LAND_BODY: see "helpers" below, .Lland)
-.macro LAND_BODY
+.macro LAND_BODY pbase=1
     s_add_u32 T6, PBASE, SKEW
     s_bfm_b64 exec, PFREE, 0
     v_add_u32 VT1, T6, VLANE
@@ -1114,7 +1111,9 @@
     ds_write_b8 VT1, VPEND
     s_mov_b64 exec, XLOOP
     s_mov_b32 PFREE, 0
+    .if \pbase
     s_mov_b32 PBASE, POS
+    .endif
 .endm
 // ---- literals (reference parse_insert_literals :1286-1365)
 .Lhave_lits:
@@ -1239,11 +1238,9 @@
 // scalar registers of the loop -- .Lland_ctx without the detour through the vector-side form
 .macro LIT_CTX_ENTRY v
 .Llit_r_entry_\v:
-    s_cmp_lt_u32 POS, 2
-    s_cbranch_scc1 .Llit_r_entry_start_\v
     s_cmp_eq_u32 PFREE, 0
-    s_cbranch_scc1 .Llit_r_entry_ring_\v
-    LAND_BODY
+    s_cbranch_scc1 .Llit_r_entry_nopend_\v               // (out of line, LIT_CTX_ENTRY_AUX: only there can this be the stream's start)
+    LAND_BODY 0                                         // (PBASE: the run's end sets it, nothing reads it in between)
 .Llit_r_entry_ring_\v:
     s_add_u32 T6, POS, SKEW
     v_bfe_u32 VPA, T6, 0, 11
@@ -1264,9 +1261,13 @@
     s_bfe_u32 T5, T6, BFEBI                             // p1's share as a later p2
     s_bfe_u32 T7, T7, BFEBI
     s_or_b32 T4, T1, T7                                 // context id of the first literal
-    s_branch .Llit_r_go_\v
-.Llit_r_entry_start_\v:                                 // (the first two bytes of a stream)
-    s_call_b64 LINKB, .Lland_ctx
+.Llit_r_go_\v:
+.endm
+.macro LIT_CTX_ENTRY_AUX v
+.Llit_r_entry_nopend_\v:
+    s_cmp_lt_u32 POS, 2                                 // (a copy is at least 2 bytes long: nothing is pending at the stream's start)
+    s_cbranch_scc0 .Llit_r_entry_ring_\v
+    s_call_b64 LINKB, .Lland_ctx                        // the first two bytes of a stream
 .ifc \v,mx
 .Llit_r_start:
 .endif
@@ -1275,7 +1276,7 @@
     s_nop 0
     v_readfirstlane_b32 T4, VT0                         // context id of the first literal
     v_readfirstlane_b32 T5, VT1                         // p1's share as a later p2
-.Llit_r_go_\v:
+    s_branch .Llit_r_go_\v
 .endm
 // A run = literals up to the end of the insert, of the literal block, or of the flush block, whichever is first: INS,
 // LBLEN and POS move once per run, the loop itself counts RUN down (one behind: to the borrow).
@@ -1358,6 +1359,7 @@
     s_mov_b32 T5, T7
     s_branch .Llit_r_m3_end
     LIT_RUN_AUX m3
+    LIT_CTX_ENTRY_AUX m3
     LIT_RF_STUB 40, 42
     LIT_RF_STUB 41, 43
     LIT_RF_STUB 42, 42
@@ -1378,6 +1380,7 @@
     s_cbranch_scc0 .Llit_r_mx
     LIT_RUN_END .Llit_r_run_mx, .Lflush_stub_lit_r_mx
     LIT_RUN_AUX mx
+    LIT_CTX_ENTRY_AUX mx
     LIT_RF_STUB 44, 45
     LIT_RF_STUB 45, 45
 #endif
@@ -1651,6 +1654,9 @@
 
 // ---- the uncommon copies.  Pending lanes used up: land and take the common path; otherwise the copy overlaps its
 // source, is longer than 64 bytes or runs past the meta-block.
+.Lcopy_slow_undo:
+    s_sub_u32 PFREE, PFREE, CPY
+    s_mov_b64 exec, XLOOP
 .Lcopy_slow:
     s_sub_u32 MBLEFT, MBEND, POS
     s_min_u32 T0, DIST, 63
