@@ -17,6 +17,7 @@ N = 1 `copy_path` (the LZ77 copy path against the physical HBM roofline: far cop
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -133,6 +134,54 @@ def kernel_source_id():
     for f in ("brx_hot.S", "brx_lens.S", "brx_kernels.hip", "brx_device.h"):
         h.update(open(os.path.join(ROOT, "brotli-rs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def under_profiler():
+    """True when this process already runs under rocprofv3 (the profiles/ passes): no nested profiler then."""
+    return any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def measured_traffic(workload, streams):
+    """HBM-side bytes of one launch, measured in this run: two child passes of this script under `rocprofv3 --kernel-trace
+    --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not share a pass, MI355X_MICROARCH.md), 2 launches each, no other trace
+    domain.  Per launch = the regular kernel + the wider instances behind it.  Counter unit KiB; fetch bytes = 2 x FETCH_SIZE
+    (64 counted per 128-byte memory-side request in every access pattern of this kernel, profiles/r03_fetchcal.txt),
+    WRITE_SIZE exact.  Returns (total_bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="brx_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            tot, launches = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "brx_decode" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        tot += float(row["Counter_Value"])
+                        if row["Kernel_Name"].startswith("brx_decode_kernel("):
+                            launches.add(row["Dispatch_Id"])
+            if not launches:
+                return None, "rocprofv3 --pmc %s: no counter rows (rc %d)" % (counter, r.returncode)
+            got[counter] = tot / len(launches) * 1024.0
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    detail = {"fetch_size_counter_bytes": int(got["FETCH_SIZE"]), "fetch_bytes": int(2 * got["FETCH_SIZE"]),
+              "write_bytes": int(got["WRITE_SIZE"])}
+    return int(2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]), detail
 
 
 def libbrotlidec_rate(comp, expect, seconds=3.0):
@@ -296,6 +345,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-path", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic from the committed file)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also time the ragged gather of the outputs to rank 0 (N>1: always)")
@@ -475,24 +525,32 @@ def main():
         alg_launch = batch.byte_model("alg")
         kms = sorted(kernel_ms)[len(kernel_ms) // 2] if kernel_ms else float("nan")
         achieved = alg_launch / (kavg * 1e-3) / 1e9
-        # HBM-side bytes per launch: PMC counters cannot be read from inside this process; they are collected by
-        # tools/gpu_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command) and
-        # committed as profiles/hbm_traffic.json.  null when this workload has no committed measurement.
-        # A measurement of another kernel version is not reported: traffic = null, traffic_source says "stale".
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if tj.get("kernel_source_id") == kernel_source_id():
-                traffic = tj["workloads"][args.workload]["total_bytes"]
-                traffic_src = "profiles/hbm_traffic.json (%s)" % tj.get("round", "?")
+        # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so two short child passes of
+        # this script run under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; measured_traffic) after the timed region.  When
+        # that is not possible (--no-traffic, already under a profiler, no rocprofv3) the committed measurement
+        # profiles/hbm_traffic.json is used -- only if it is of THIS kernel (kernel_source_id), else traffic = null.
+        traffic, traffic_src, traffic_detail = None, None, None
+        if not args.no_traffic and world == 1 and not under_profiler() and not STUB:
+            traffic, traffic_detail = measured_traffic(args.workload, args.streams)
+            if traffic is not None:
+                traffic_src = "in-run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes, 2 launches each)"
             else:
-                traffic_src = "stale: profiles/hbm_traffic.json (%s) measured kernel %s, this is %s" % (
-                    tj.get("round", "?"), tj.get("kernel_source_id", "?"), kernel_source_id())
-        except (OSError, KeyError, ValueError):
-            pass
+                traffic_src, traffic_detail = "in-run passes failed (%s); " % traffic_detail, None
+        if traffic is None:
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                if tj.get("kernel_source_id") == kernel_source_id():
+                    traffic = tj["workloads"][args.workload]["total_bytes"]
+                    traffic_src = (traffic_src or "") + "profiles/hbm_traffic.json (%s)" % tj.get("round", "?")
+                else:
+                    traffic_src = (traffic_src or "") + "stale: profiles/hbm_traffic.json (%s) measured kernel %s, this is %s" % (
+                        tj.get("round", "?"), tj.get("kernel_source_id", "?"), kernel_source_id())
+            except (OSError, KeyError, ValueError):
+                pass
         res["roofline"] = {"bound": "hbm", "kernel": "brx_decode_kernel", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_source": traffic_src,
+                           **({"traffic_detail": traffic_detail} if traffic_detail else {}),
                            "algorithmic_bytes_per_launch": alg_launch,
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
         model = PHYSICAL_MODEL.get(args.workload)

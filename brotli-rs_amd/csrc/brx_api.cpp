@@ -91,6 +91,10 @@ struct brx_ctx {
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
     BrxSlabPool pool = {nullptr, nullptr, 0};
     unsigned max_grid = 0;
+    unsigned grid_cap = 0;
+    bool no_overlap = false;                      // BRX_NO_OVERLAP: the wider kernels strictly behind the regular one (A/B)
+    hipStream_t s_wide = nullptr;                 // the wider kernels' own stream (launch(): "overlap")
+    hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING] = {};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
     hipEvent_t ev_in[BRX_MAX_CHUNKS] = {}, ev_k[BRX_MAX_CHUNKS] = {};
@@ -157,6 +161,7 @@ static void ctx_release(brx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &q : c->s_chunk)
         if (q) (void)hipStreamSynchronize(q);
+    if (c->s_wide) (void)hipStreamSynchronize(c->s_wide);
     if (c->ev_last && c->any_launch) (void)hipEventSynchronize(c->ev_last);
     (void)hipFree(c->d_dict);
     (void)hipFree(c->d_lut);
@@ -180,6 +185,11 @@ static void ctx_release(brx_ctx *c) {
     for (auto &ev : c->ev_k)
         if (ev) (void)hipEventDestroy(ev);
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    for (auto &ev : c->ev_fork)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_join)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->s_wide) (void)hipStreamDestroy(c->s_wide);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto &q : c->s_chunk)
         if (q) (void)hipStreamDestroy(q);
@@ -199,6 +209,8 @@ static int ctx_init(brx_ctx *c, int device) {
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
         c->no_order = getenv("BRX_NO_ORDER") != nullptr;
         c->no_defer = getenv("BRX_NO_DEFER") != nullptr;
+        if ((e = getenv("BRX_GRID_CAP")) != nullptr) c->grid_cap = (unsigned)atoi(e);
+        c->no_overlap = getenv("BRX_NO_OVERLAP") != nullptr;
         if ((e = getenv("BRX_TINY_BYTES")) != nullptr) c->tiny_bytes = (uint32_t)atoi(e);
         c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
         if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
@@ -214,6 +226,7 @@ static int ctx_init(brx_ctx *c, int device) {
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &q : c->s_chunk) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_wide, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
@@ -273,6 +286,8 @@ static int ctx_init(brx_ctx *c, int device) {
     for (auto &ev : c->ev_in) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto &ev : c->ev_k) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+    for (auto &ev : c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return BRX_SUCCESS;
 }
 
@@ -392,7 +407,7 @@ static int ensure_order(brx_ctx *c, uint32_t n) {
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
                   const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr,
-                  uint8_t *d_out_mirror = nullptr) {
+                  uint8_t *d_out_mirror = nullptr, bool may_overlap = false) {
     BrxKernelArgs a;
     a.out_mirror = d_out_mirror;
     a.order = d_order;
@@ -405,6 +420,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.n = n;
     a.debug_stop = c->debug_stop;
     unsigned grid = n < c->max_grid ? n : c->max_grid;
+    if (c->grid_cap != 0u && grid > c->grid_cap) grid = c->grid_cap; // (A/B knob BRX_GRID_CAP: fewer resident waves, more rounds)
     a.pool = d_own_pool;
     if (!d_own_pool) {
         int rc = ensure_pool(c, grid);
@@ -444,16 +460,39 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 32, st));
+    // The level-1 kernel next to the regular one instead of behind it ("overlap"): in a mixed batch the streams handed up
+    // (listed within their first header) would otherwise wait for the longest stream of the regular kernel before they even
+    // start.  The level-1 kernel goes to the context's second HIP stream; its waves become resident as waves of the regular
+    // kernel retire (LDS), take a list entry as soon as it is there and leave once word 8 of the counter line says the
+    // regular kernel is complete -- written in stream order behind it.  Its LDS demand (12 x 12.5 KiB per CU) stays below a
+    // CU's 160 KiB, so the regular kernel always has waves resident whatever order the two get dispatched in.  Levels 2 and
+    // 3 follow on the second stream as before; the caller's stream joins at the end.
+    const bool overlap = a.defer != nullptr && may_overlap && !c->no_overlap;
+    a.overlap = overlap ? 1u : 0u;
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
+    if (overlap) {
+        HIP_TRY(hipMemsetAsync(a.defer, 0xff, (size_t)std::min<size_t>(n, c->defer_cap) * 4u, st)); // "no entry yet"
+        HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
+    }
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
     if (a.defer != nullptr) { // the wider kernels (12 / 8 / 4 waves per CU): their waves leave at once when nothing was listed
         const unsigned per_cu = c->max_grid / 16u;
-        brx_launch_decode_l1(a, std::min(n, per_cu * 12u), st);
-        brx_launch_decode_l2(a, std::min(n, per_cu * 8u), st);
-        brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
+        hipStream_t sw = st;
+        if (overlap) {
+            sw = c->s_wide;
+            HIP_TRY(hipMemsetAsync(a.work_counter + 8, 0x01, 4, st)); // behind the regular kernel: "complete"
+            HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
+        }
+        brx_launch_decode_l1(a, std::min(n, per_cu * 12u), sw);
+        brx_launch_decode_l2(a, std::min(n, per_cu * 8u), sw);
+        brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
         HIP_TRY(hipGetLastError());
+        if (overlap) {
+            HIP_TRY(hipEventRecord(c->ev_join[ring_slot], sw));
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_join[ring_slot], 0));
+        }
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));
@@ -587,7 +626,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
         const uint64_t i0 = in_off[a] - in_lo, i1 = in_off[b] - in_lo;
         if (i1 > i0 && !in_dev) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, sk));
         rc = launch(c, sk, timing && nchunks == 1, in_dev ? in_dev : c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a, d_out_len + a,
-                    d_status + a, d_order + a, nullptr, nullptr, mirror);
+                    d_status + a, d_order + a, nullptr, nullptr, mirror, nchunks == 1);
         if (rc) return rc;
     }
     for (unsigned k = 0; k < nchunks; k++) { // copy out (a second loop: a pageable copy blocks the host until it is done)
@@ -629,7 +668,7 @@ static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in
             d_order = slot;
         }
         if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order);
+        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order, nullptr, nullptr, nullptr, true);
         if (rc) return rc;
         if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));

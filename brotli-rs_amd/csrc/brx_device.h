@@ -86,7 +86,7 @@ struct BrxKernelArgs {
     uint32_t n;
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
-    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..7 zeroed in-stream before the launch:
+    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..15 zeroed in-stream before the launch:
                             // [k] work counter of the level-k kernel, [4 + k] streams listed for level k (k = 1..3)
     uint32_t *defer;        // nullptr, or 3 lists of defer_cap stream indices (list of level k at (k - 1) * defer_cap): a
                             // kernel lists for the next level the streams whose tables spill its LDS table memory (and
@@ -102,6 +102,9 @@ struct BrxKernelArgs {
     BrxResume *resume;      // nullptr, or one record per stream: resumable mode (see BrxResume)
     uint8_t *out_mirror;    // nullptr, or the device-visible address of pinned host memory laid out like `out`: output bytes are
                             // stored to both (the D2H copy fused into the decode)
+    uint32_t overlap;       // 1: the level-1 kernel runs NEXT TO the regular one (its own HIP stream): list entries start as
+                            // 0xffffffff, a level-1 wave waits for its entry, and word 8 of the counter line turns non-zero
+                            // (in stream order behind the regular kernel) once no further entry can come
     uint32_t loop_build;    // which build of the assembly loop: 0 = bit window in VGPRs (full CUs), 1 = in SGPRs (sparse launch)
     BrxDeviceTables t;
 };

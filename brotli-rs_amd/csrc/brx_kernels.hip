@@ -1899,6 +1899,22 @@ __device__ __noinline__ void seg_finish() {
 #define BRX_LAUNCH_NAME brx_launch_decode_l3
 #define BRX_WAVES_PER_SIMD 1
 #endif
+#if BRX_LEVEL == 1
+// BrxKernelArgs::overlap: wait until the regular kernel has filled this list slot (returns the stream index) or is complete
+// with the slot still empty (returns 0xffffffff).  Device-scope loads (the writer is on another XCD), naps that double up to
+// ~55 us so that thousands of waiting waves do not crowd the memory channel of the two words they watch.
+FI u32 wait_for_entry(const u32 *entry, const u32 *complete) {
+    u32 naps = 1u;
+    for (;;) {
+        u32 v = rfl(__hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v != 0xffffffffu) return v;
+        if (rfl(__hip_atomic_load(complete, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+            return rfl(__hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); // everything it listed is in memory now
+        for (u32 k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(127);
+        naps = naps < 16u ? naps * 2u : 16u;
+    }
+}
+#endif
 __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(BrxKernelArgs a) {
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
@@ -1907,11 +1923,13 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #define generic_commands(m_) generic_commands((m_), wc.v_ic, wc.v_lut0, wc.v_lut1, wc.v_lut2)
     u32 *const counter = a.work_counter + BRX_LEVEL;
 #if BRX_LEVEL > 0
-    const u32 n_streams = rfl(a.defer != nullptr ? __builtin_nontemporal_load(&a.work_counter[4 + BRX_LEVEL]) : 0u);
+    // (level 1 next to the regular kernel, BrxKernelArgs::overlap: the list is still growing -- its length is not known yet, at most all n streams)
+    const bool overlap = BRX_LEVEL == 1 && a.overlap != 0u;
+    const u32 n_streams = rfl(a.defer == nullptr ? 0u : overlap ? a.n : __builtin_nontemporal_load(&a.work_counter[4 + BRX_LEVEL]));
     if (n_streams == 0u) return;
     const u32 *const my_list = a.defer + (size_t)(BRX_LEVEL - 1) * a.defer_cap;
     // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
-    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
+    const bool sw_loop = a.loop_build != 0u || (!overlap && n_streams <= a.sw_threshold) || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
 #else
     const u32 n_streams = a.n;
     const bool sw_loop = a.loop_build != 0u;
@@ -1935,6 +1953,12 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
         }
         if (sid >= n_streams) break;
+#if BRX_LEVEL == 1
+        if (overlap) {
+            sid = wait_for_entry(&my_list[sid], &a.work_counter[8]);
+            if (sid == 0xffffffffu) break; // the regular kernel is complete and left nothing in this slot
+        } else
+#endif
 #if BRX_LEVEL > 0
         sid = rfl(my_list[sid]); // the streams the level below left to this one
 #else
@@ -2128,7 +2152,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #if BRX_LEVEL < BRX_LEVELS - 1
         if (deferred) { // no status, no length: the next level decodes the stream from its start (same bytes, same slots)
             const u32 slot = rdl(atomicAdd(a.work_counter + 5 + BRX_LEVEL, lane == 0u ? 1u : 0u), 0);
-            if (lane == 0u) a.defer[(size_t)BRX_LEVEL * a.defer_cap + slot] = sid;
+            // (device-scope store: with BrxKernelArgs::overlap a level-1 wave on another XCD is waiting for this entry)
+            if (lane == 0u) __hip_atomic_store(&a.defer[(size_t)BRX_LEVEL * a.defer_cap + slot], sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
 #endif

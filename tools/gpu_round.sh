@@ -10,13 +10,13 @@ echo "== bench"; timeout 600 python bench.py --steps ${STEPS:-10} --warmup 2 ${B
 if [ "${PROF:-1}" = "1" ]; then
   cd /tmp && export TMPDIR=/tmp
   echo "== rocprofv3 kernel-trace"
-  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | tail -3
+  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-traffic 2>&1 | tail -3
   if [ -n "${PMC:-}" ]; then
     i=0
     for set in "$PMC" ${PMC2:+"$PMC2"} ${PMC3:+"$PMC3"}; do
       i=$((i+1))
       echo "== rocprofv3 pmc pass $i: $set"
-      timeout 600 rocprofv3 --kernel-trace --pmc $set -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify 0 2>&1 | tail -2
+      timeout 600 rocprofv3 --kernel-trace --pmc $set -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --verify 0 2>&1 | tail -2
     done
   fi
   cd $GRAFT_REPO_ROOT

@@ -9,10 +9,10 @@ cd /tmp && export TMPDIR=/tmp
 for wl in ${WORKLOADS:-alice29x4096 quickfox_repeatedx8192 backward65536x4096}; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
-    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --verify 0 > /tmp/pmc_$c.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --verify 0 > /tmp/pmc_$c.log 2>&1
   done
   rm -rf /tmp/kt
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o t -- python $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --verify 0 > /tmp/kt.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o t -- python $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --verify 0 > /tmp/kt.log 2>&1
   tail -1 /tmp/kt.log > $R/gpurun_out/bench_${TAG}_${wl}_under_rocprof.json
   f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/gpurun_out/${TAG}_${wl}_kernel_stats.csv
   python3 - $wl $TAG <<'PY'
