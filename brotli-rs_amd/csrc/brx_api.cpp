@@ -92,7 +92,9 @@ struct brx_ctx {
     BrxSlabPool pool = {nullptr, nullptr, 0};
     unsigned max_grid = 0;
     unsigned grid_cap = 0;
+    bool force_overlap = false;                   // BRX_FORCE_OVERLAP: also on contexts that never handed a stream up (A/B)
     bool no_overlap = false;                      // BRX_NO_OVERLAP: the wider kernels strictly behind the regular one (A/B)
+    uint32_t *h_handed = nullptr, *d_handed = nullptr; // pinned host word (and its device address): BrxKernelArgs::handed_seq
     hipStream_t s_wide = nullptr;                 // the wider kernels' own stream (launch(): "overlap")
     hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING] = {};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -168,6 +170,7 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->d_xforms);
     (void)hipFree(c->d_iac);
     (void)hipFree(c->d_counters);
+    if (c->h_handed) (void)hipHostFree(c->h_handed);
     (void)hipFree(c->d_defer);
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_pool);
@@ -211,6 +214,7 @@ static int ctx_init(brx_ctx *c, int device) {
         c->no_defer = getenv("BRX_NO_DEFER") != nullptr;
         if ((e = getenv("BRX_GRID_CAP")) != nullptr) c->grid_cap = (unsigned)atoi(e);
         c->no_overlap = getenv("BRX_NO_OVERLAP") != nullptr;
+        c->force_overlap = getenv("BRX_FORCE_OVERLAP") != nullptr;
         if ((e = getenv("BRX_TINY_BYTES")) != nullptr) c->tiny_bytes = (uint32_t)atoi(e);
         c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
         if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
@@ -226,11 +230,14 @@ static int ctx_init(brx_ctx *c, int device) {
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &q : c->s_chunk) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->s_wide, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->s_wide, hipStreamNonBlocking)); // (never a high-priority one: its waiting waves would take the CUs first)
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
     HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 64u));
+    HIP_TRY(hipHostMalloc((void **)&c->h_handed, 64, hipHostMallocMapped));
+    *c->h_handed = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->d_handed, c->h_handed, 0));
     HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 64u));
     HIP_TRY(hipMalloc(&c->d_pool, sizeof(BrxSlabPool)));
     HIP_TRY(hipMemset(c->d_pool, 0, sizeof(BrxSlabPool)));
@@ -467,7 +474,14 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     // regular kernel is complete -- written in stream order behind it.  Its LDS demand (12 x 12.5 KiB per CU) stays below a
     // CU's 160 KiB, so the regular kernel always has waves resident whatever order the two get dispatched in.  Levels 2 and
     // 3 follow on the second stream as before; the caller's stream joins at the end.
-    const bool overlap = a.defer != nullptr && may_overlap && !c->no_overlap;
+    // Only for contexts that handed streams up within their last 8 launches (the regular kernel notes it in a pinned host word,
+    // read here without any API call): the second stream's fork and join cost ~30 us per launch, which batches of short
+    // streams would pay for nothing.
+    a.launch_seq = (uint32_t)c->launch_seq; // (already advanced: >= 1)
+    a.handed_seq = c->d_handed;
+    const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
+    const bool lately = c->force_overlap || (seen != 0u && a.launch_seq - seen <= 8u);
+    const bool overlap = a.defer != nullptr && may_overlap && !c->no_overlap && lately;
     a.overlap = overlap ? 1u : 0u;
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
     if (overlap) {

@@ -1942,15 +1942,28 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     bool first = true;
     for (;;) {
         u32 sid;
+#if BRX_LEVEL == 1
+        if (first && !overlap) {
+#else
         if (first) {
+#endif
             first = false;
             sid = blockIdx.x;
         } else {
+#if BRX_LEVEL == 1
+            if (!overlap)
+#endif
             if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
             // Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right behind the
             // lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63 around both
             // across the back edge -- they then spin in their own loop and never meet lane 0 again.
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
+#if BRX_LEVEL == 1
+            // next to the regular kernel every slot comes from the counter: a workgroup is resident where and when waves of the
+            // regular kernel have retired (a whole XCD may be busy with long streams to the end) -- slots tied to workgroup
+            // indices would leave listed streams waiting for exactly those workgroups
+            if (overlap) sid -= gridDim.x;
+#endif
         }
         if (sid >= n_streams) break;
 #if BRX_LEVEL == 1
@@ -2154,6 +2167,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             const u32 slot = rdl(atomicAdd(a.work_counter + 5 + BRX_LEVEL, lane == 0u ? 1u : 0u), 0);
             // (device-scope store: with BrxKernelArgs::overlap a level-1 wave on another XCD is waiting for this entry)
             if (lane == 0u) __hip_atomic_store(&a.defer[(size_t)BRX_LEVEL * a.defer_cap + slot], sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if BRX_LEVEL == 0
+            if (lane == 0u && a.handed_seq != nullptr) *a.handed_seq = a.launch_seq; // (pinned host word: "this context meets such streams")
+#endif
             continue;
         }
 #endif

@@ -606,6 +606,76 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     assert outs[2] == _read("lcet10.txt")
 
 
+def test_level1_kernel_next_to_the_regular_one(ctx):
+    """A mixed full-chip batch on the device path: alice29 / asyoulik / plrabn12 fill the regular kernel, every fourth stream is
+    lcet10 (tables spill: listed for level 1 within its first header), a few mapsdatazrh go on to level 2.  The level-1 kernel
+    runs on the context's second HIP stream NEXT TO the regular one: its waves wait for list entries while the regular kernel
+    is still decoding and leave when it is complete.  Bytes, lengths and statuses are the reference files'; every lcet10 and
+    mapsdatazrh went through the wide kernels."""
+    import torch
+    dev = torch.device("cuda:0")
+    names = ["alice29.txt", "lcet10.txt", "asyoulik.txt", "plrabn12.txt"]
+    fx = [(_read(n_ + ".compressed"), _read(n_)) for n_ in names]
+    maps = (_read("mapsdatazrh.compressed"), _read("mapsdatazrh"))
+    n = 4400  # more streams than resident waves: the ticket queue of the regular kernel is in play as well
+    pick = [maps if i % 400 == 7 else fx[i % 4] for i in range(n)]
+    cap = (max(len(e) for _, e in fx) + 15) & ~15
+    lens = np.array([len(c) for c, _ in pick], dtype=np.int64)
+    in_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=in_off[1:])
+    uniq = {id(p_): torch.frombuffer(bytearray(p_[0]), dtype=torch.uint8).to(dev) for p_ in fx + [maps]}
+    blob = torch.cat([uniq[id(p_)] for p_ in pick]).contiguous()
+    in_off_d = torch.from_numpy(in_off).to(dev)
+    out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap).contiguous()
+    out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):  # (the first launch of a fresh context runs the kernels one behind the other and notes the hand-overs)
+        out.zero_(); status.fill_(-1); out_len.zero_()
+        torch.cuda.synchronize()
+        ctx.decode_batch_device(blob.data_ptr(), in_off_d.data_ptr(), n, out.data_ptr(), out_off.data_ptr(),
+                                out_len.data_ptr(), status.data_ptr())
+        ctx.synchronize()
+        assert bool((status == 0).all().item()), status.cpu().tolist()[:16]
+        want_len = torch.tensor([len(e) for _, e in pick], dtype=torch.int64, device=dev)
+        assert bool((out_len == want_len).all().item())
+        rows = out.view(n, cap)
+        for c, e in fx + [maps]:
+            idx = torch.tensor([i for i, p_ in enumerate(pick) if p_[0] is c], dtype=torch.int64, device=dev)
+            want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(dev)
+            assert bool((rows[idx][:, :len(e)] == want.unsqueeze(0)).all().item()), len(e)
+        n_wide = sum(1 for p_ in pick if p_ is maps or p_ is fx[1])
+        assert ctx.last_wide_streams() == n_wide, (ctx.last_wide_streams(), n_wide)
+        assert ctx.last_wide_streams(2) == sum(1 for p_ in pick if p_ is maps)
+    # a batch smaller than the level-1 grid, the two kernels next to each other (this context has handed streams up by now):
+    # every level-1 wave takes its list slots from the counter and stays until the regular kernel is complete
+    m = 300
+    out.zero_(); status.fill_(-1); out_len.zero_()
+    torch.cuda.synchronize()
+    ctx.decode_batch_device(blob.data_ptr(), in_off_d.data_ptr(), m, out.data_ptr(), out_off.data_ptr(),
+                            out_len.data_ptr(), status.data_ptr())
+    ctx.synchronize()
+    assert bool((status[:m] == 0).all().item()) and bool((status[m:] == -1).all().item())
+    assert bool((out_len[:m] == want_len[:m]).all().item())
+    for c, e in fx + [maps]:
+        idx = torch.tensor([i for i, p_ in enumerate(pick[:m]) if p_[0] is c], dtype=torch.int64, device=dev)
+        want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(dev)
+        assert bool((out.view(n, cap)[idx][:, :len(e)] == want.unsqueeze(0)).all().item()), len(e)
+    assert ctx.last_wide_streams() == sum(1 for p_ in pick[:m] if p_ is maps or p_ is fx[1])
+
+
+def test_wide_kernels_strictly_behind_the_regular_one():
+    """BRX_NO_OVERLAP=1: the level-1 kernel on the caller's stream behind the regular one (how every launch ran before the
+    two overlapped) -- same parity subset, fresh process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BRX_NO_OVERLAP="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_farcopy_streams(ctx):
     """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
     streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
