@@ -499,9 +499,17 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
             HIP_TRY(hipMemsetAsync(a.work_counter + 8, 0x01, 4, st)); // behind the regular kernel: "complete"
             HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
         }
-        brx_launch_decode_l1(a, std::min(n, per_cu * 12u), sw);
-        brx_launch_decode_l2(a, std::min(n, per_cu * 8u), sw);
-        brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
+        if (lately || c->debug_stats) {
+            a.src_list = 0u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), sw);
+            a.src_list = 1u; brx_launch_decode_l2(a, std::min(n, per_cu * 8u), sw);
+            a.src_list = 2u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
+        } else {
+            // A context that has not handed a stream up lately (most never do): ONE wider launch instead of three -- the
+            // level-3 kernel, whose table memory holds whatever levels 1 and 2 hold, takes the regular kernel's list directly.
+            // An empty launch costs ~5 us; three of them were a tenth of a 4096 x backward65536 batch.  Should streams
+            // spill after all they run 4 per CU this once, and the next launches of the context get the full chain again.
+            a.src_list = 0u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
+        }
         HIP_TRY(hipGetLastError());
         if (overlap) {
             HIP_TRY(hipEventRecord(c->ev_join[ring_slot], sw));

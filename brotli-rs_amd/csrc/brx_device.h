@@ -105,6 +105,8 @@ struct BrxKernelArgs {
     uint32_t overlap;       // 1: the level-1 kernel runs NEXT TO the regular one (its own HIP stream): list entries start as
                             // 0xffffffff, a level-1 wave waits for its entry, and word 8 of the counter line turns non-zero
                             // (in stream order behind the regular kernel) once no further entry can come
+    uint32_t src_list;      // wider kernels: which list this launch decodes (level k normally list k - 1; the level-3 kernel
+                            // launched alone behind the regular one takes list 0, see launch())
     uint32_t launch_seq;    // sequence number of this launch on its context, and
     volatile uint32_t *handed_seq; // nullptr, or a pinned host word that takes launch_seq whenever the regular kernel hands a
                             // stream up: the host turns `overlap` on only for contexts that met such streams lately

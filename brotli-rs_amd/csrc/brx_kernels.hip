@@ -1925,9 +1925,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #if BRX_LEVEL > 0
     // (level 1 next to the regular kernel, BrxKernelArgs::overlap: the list is still growing -- its length is not known yet, at most all n streams)
     const bool overlap = BRX_LEVEL == 1 && a.overlap != 0u;
-    const u32 n_streams = rfl(a.defer == nullptr ? 0u : overlap ? a.n : __builtin_nontemporal_load(&a.work_counter[4 + BRX_LEVEL]));
+    const u32 n_streams = rfl(a.defer == nullptr ? 0u : overlap ? a.n : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
     if (n_streams == 0u) return;
-    const u32 *const my_list = a.defer + (size_t)(BRX_LEVEL - 1) * a.defer_cap;
+    const u32 *const my_list = a.defer + (size_t)a.src_list * a.defer_cap;
     // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
     const bool sw_loop = a.loop_build != 0u || (!overlap && n_streams <= a.sw_threshold) || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
 #else

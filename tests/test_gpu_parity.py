@@ -589,6 +589,7 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     want = [oracle.decode(s_, 0, cap=1 << 20) for s_ in streams]
     caps = [len(w[1]) + 1 + (i % 5) if w[0] == 0 else 1 << 17 for i, w in enumerate(want)]
     want = [oracle.decode(s_, 0, cap=c_) for s_, c_ in zip(streams, caps)]
+    ctx.decode_batch([lcet], 1 << 19)  # (a context that has handed a stream up lately runs the full chain of wider kernels)
     outs, status, out_len = ctx.decode_batch(streams, caps)
     wide = ctx.last_wide_streams()
     bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
@@ -630,6 +631,7 @@ def test_level1_kernel_next_to_the_regular_one(ctx):
     out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
     out_len = torch.zeros(n, dtype=torch.int64, device=dev)
     status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx.decode_batch([fx[1][0]], 1 << 19)
     torch.cuda.synchronize()
     for rep in range(3):  # (the first launch of a fresh context runs the kernels one behind the other and notes the hand-overs)
         out.zero_(); status.fill_(-1); out_len.zero_()
@@ -663,6 +665,27 @@ def test_level1_kernel_next_to_the_regular_one(ctx):
         want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(dev)
         assert bool((out.view(n, cap)[idx][:, :len(e)] == want.unsqueeze(0)).all().item()), len(e)
     assert ctx.last_wide_streams() == sum(1 for p_ in pick[:m] if p_ is maps or p_ is fx[1])
+
+
+def test_fresh_context_sends_spilling_streams_straight_to_level_3():
+    """A context that has not handed a stream up lately launches ONE wider kernel behind the regular one (level 3 reading
+    the regular kernel's list) instead of three; streams that spill after all are decoded there, bit-exact, and the next
+    launch of the context runs the full chain (level 2 takes mapsdatazrh again)."""
+    from brotli_rs_amd import brx
+    c2 = brx.Context(0)
+    try:
+        lcet, maps, alice = _read("lcet10.txt.compressed"), _read("mapsdatazrh.compressed"), _read("alice29.txt.compressed")
+        streams = [alice, lcet, maps, _read("monkey.compressed"), lcet, bytes.fromhex("a103")] * 9
+        want = [oracle.decode(s_, 0, cap=1 << 19) for s_ in streams]
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, 1 << 19)
+            bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if w[0] != st or (st == 0 and o != w[1])]
+            assert not bad, (rep, bad[:8])
+            assert c2.last_wide_streams() == 27
+            if "BRX_FORCE_OVERLAP" not in os.environ:  # (that switch also forces the full chain from the first launch)
+                assert c2.last_wide_streams(2) == (0 if rep == 0 else 9), (rep, c2.last_wide_streams(2))
+    finally:
+        c2.close()
 
 
 def test_wide_kernels_strictly_behind_the_regular_one():
