@@ -467,13 +467,16 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    // The level-1 kernel next to the regular one instead of behind it ("overlap"): in a mixed batch the streams handed up
-    // (listed within their first header) would otherwise wait for the longest stream of the regular kernel before they even
-    // start.  The level-1 kernel goes to the context's second HIP stream; its waves become resident as waves of the regular
-    // kernel retire (LDS), take a list entry as soon as it is there and leave once word 8 of the counter line says the
-    // regular kernel is complete -- written in stream order behind it.  Its LDS demand (12 x 12.5 KiB per CU) stays below a
-    // CU's 160 KiB, so the regular kernel always has waves resident whatever order the two get dispatched in.  Levels 2 and
-    // 3 follow on the second stream as before; the caller's stream joins at the end.
+    // The level-1 kernel next to the regular one ("overlap"): in a mixed batch the streams handed up (listed within their
+    // first header) would otherwise wait for the longest stream of the regular kernel before they even start.  Level 1 is
+    // launched twice: EARLY on the context's second HIP stream (forked in front of the regular kernel) -- its workgroups
+    // become resident where and when waves of the regular kernel retire, take a list slot only when one is listed
+    // (compare-and-swap on the slot counter) and do not stay with nothing to do (brx_kernels.hip, early_slot) -- and LATE on
+    // the caller's stream behind the regular kernel, where the list is final, for whatever the early one left (usually
+    // nothing: an empty launch).  Correctness never depends on the early launch, nor on which kernel the dispatcher serves
+    // first; a first version whose waves WAITED for the regular kernel to complete took 2 x the time whenever they got the
+    // LDS before the regular kernel's workgroups did (one step in ten), and 58 s on a high-priority stream.
+    // Levels 2 and 3 stay behind level 1; the caller's stream joins the second one in front of level 2.
     // Only for contexts that handed streams up within their last 8 launches (the regular kernel notes it in a pinned host word,
     // read here without any API call): the second stream's fork and join cost ~30 us per launch, which batches of short
     // streams would pay for nothing.
@@ -482,10 +485,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
     const bool lately = c->force_overlap || (seen != 0u && a.launch_seq - seen <= 8u);
     const bool overlap = a.defer != nullptr && may_overlap && !c->no_overlap && lately;
-    a.overlap = overlap ? 1u : 0u;
+    a.overlap = 0u;
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
     if (overlap) {
-        HIP_TRY(hipMemsetAsync(a.defer, 0xff, (size_t)std::min<size_t>(n, c->defer_cap) * 4u, st)); // "no entry yet"
+        HIP_TRY(hipMemsetAsync(a.defer, 0xff, (size_t)std::min<size_t>(n, c->defer_cap) * 4u, st)); // "not stored yet"
         HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -493,28 +496,27 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     HIP_TRY(hipGetLastError());
     if (a.defer != nullptr) { // the wider kernels (12 / 8 / 4 waves per CU): their waves leave at once when nothing was listed
         const unsigned per_cu = c->max_grid / 16u;
-        hipStream_t sw = st;
         if (overlap) {
-            sw = c->s_wide;
             HIP_TRY(hipMemsetAsync(a.work_counter + 8, 0x01, 4, st)); // behind the regular kernel: "complete"
-            HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
+            HIP_TRY(hipStreamWaitEvent(c->s_wide, c->ev_fork[ring_slot], 0));
+            a.src_list = 0u; a.overlap = 1u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), c->s_wide);
+            HIP_TRY(hipEventRecord(c->ev_join[ring_slot], c->s_wide));
+            a.overlap = 2u;
         }
         if (lately || c->debug_stats) {
-            a.src_list = 0u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), sw);
-            a.src_list = 1u; brx_launch_decode_l2(a, std::min(n, per_cu * 8u), sw);
-            a.src_list = 2u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
+            a.src_list = 0u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), st);
+            a.overlap = 0u;
+            if (overlap) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[ring_slot], 0)); // (both level-1 launches list for level 2)
+            a.src_list = 1u; brx_launch_decode_l2(a, std::min(n, per_cu * 8u), st);
+            a.src_list = 2u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
         } else {
             // A context that has not handed a stream up lately (most never do): ONE wider launch instead of three -- the
             // level-3 kernel, whose table memory holds whatever levels 1 and 2 hold, takes the regular kernel's list directly.
             // An empty launch costs ~5 us; three of them were a tenth of a 4096 x backward65536 batch.  Should streams
             // spill after all they run 4 per CU this once, and the next launches of the context get the full chain again.
-            a.src_list = 0u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), sw);
+            a.src_list = 0u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
         }
         HIP_TRY(hipGetLastError());
-        if (overlap) {
-            HIP_TRY(hipEventRecord(c->ev_join[ring_slot], sw));
-            HIP_TRY(hipStreamWaitEvent(st, c->ev_join[ring_slot], 0));
-        }
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));

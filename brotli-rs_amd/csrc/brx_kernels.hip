@@ -1900,18 +1900,45 @@ __device__ __noinline__ void seg_finish() {
 #define BRX_WAVES_PER_SIMD 1
 #endif
 #if BRX_LEVEL == 1
-// BrxKernelArgs::overlap: wait until the regular kernel has filled this list slot (returns the stream index) or is complete
-// with the slot still empty (returns 0xffffffff).  Device-scope loads (the writer is on another XCD), naps that double up to
-// ~55 us so that thousands of waiting waves do not crowd the memory channel of the two words they watch.
-FI u32 wait_for_entry(const u32 *entry, const u32 *complete) {
+// Level 1 next to the regular kernel (BrxKernelArgs::overlap, launch() in brx_api.cpp).  Two launches share one list and one
+// slot counter: the EARLY one on the context's second HIP stream while the regular kernel is still running (overlap == 1),
+// the LATE one behind the regular kernel on the caller's stream (overlap == 2) for whatever is left.
+FI u32 ld_dev(const u32 *p) { return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+// Early launch: a wave first claims a permit -- `claimed` counts the claims, a claim numbered below the count of listed
+// streams holds (so never more permits than listed streams), one at or beyond it is taken back -- and only with a permit
+// takes the next slot number from the counter the late launch uses as well.  Every step is one add (linear under
+// contention; a compare-and-swap on the slot counter took 10 x the time of 4096 x lcet10 when 3 000 waves arrived at once).
+// No slot is taken in vain before the regular kernel is complete, so none is lost: whatever number the early waves have
+// not taken, the late launch takes.  With nothing listed a wave stays for at most ~1 ms after its start and only while the
+// regular kernel is running (word 8 of the counter line is written behind it in stream order) -- it holds LDS that
+// workgroups of the regular kernel may be waiting for if the dispatcher served this launch first.
+// Returns the slot or 0xffffffff (leave).
+FI u32 early_slot(u32 *head, u32 *claimed, const u32 *listed, const u32 *complete, unsigned long long t_start) {
+    const u32 one = threadIdx.x == 0u ? 1u : 0u; // every lane executes the atomics (see the work queue below), lane 0 counts
     u32 naps = 1u;
     for (;;) {
-        u32 v = rfl(__hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v != 0xffffffffu) return v;
-        if (rfl(__hip_atomic_load(complete, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
-            return rfl(__hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); // everything it listed is in memory now
+        if (ld_dev(claimed) < ld_dev(listed)) {
+            const u32 p = rdl(atomicAdd(claimed, one), 0);
+            if (p < ld_dev(listed)) {
+                const u32 t = rdl(atomicAdd(head, one), 0);
+                // (beyond the list only once the late launch is taking numbers too: the regular kernel is complete)
+                return t < ld_dev(listed) ? t : 0xffffffffu;
+            }
+            (void)atomicSub(claimed, one);
+        }
+        if (ld_dev(complete) != 0u) return 0xffffffffu;
+        if (__builtin_amdgcn_s_memrealtime() - t_start > 100000ull) return 0xffffffffu; // 1 ms of the 100 MHz clock
         for (u32 k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(127);
-        naps = naps < 16u ? naps * 2u : 16u;
+        naps = naps < 8u ? naps * 2u : 8u;
+    }
+}
+// The slot is listed (its number is below the count) but its entry may be a few hundred ns behind: the regular kernel's wave
+// takes the number, then stores the stream index (entries start as 0xffffffff).
+FI u32 listed_entry(const u32 *entry) {
+    for (;;) {
+        const u32 v = ld_dev(entry);
+        if (v != 0xffffffffu) return v;
+        __builtin_amdgcn_s_sleep(8);
     }
 }
 #endif
@@ -1923,10 +1950,15 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #define generic_commands(m_) generic_commands((m_), wc.v_ic, wc.v_lut0, wc.v_lut1, wc.v_lut2)
     u32 *const counter = a.work_counter + BRX_LEVEL;
 #if BRX_LEVEL > 0
-    // (level 1 next to the regular kernel, BrxKernelArgs::overlap: the list is still growing -- its length is not known yet, at most all n streams)
+    // (level 1 next to the regular kernel, BrxKernelArgs::overlap: early launch = the list is still growing; late launch =
+    // the list is final, the early one may have taken any part of it)
     const bool overlap = BRX_LEVEL == 1 && a.overlap != 0u;
-    const u32 n_streams = rfl(a.defer == nullptr ? 0u : overlap ? a.n : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
+    const bool early = BRX_LEVEL == 1 && a.overlap == 1u;
+    const u32 n_streams = rfl(a.defer == nullptr ? 0u : early ? a.n : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
     if (n_streams == 0u) return;
+#if BRX_LEVEL == 1
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const u32 *const my_list = a.defer + (size_t)a.src_list * a.defer_cap;
     // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
     const bool sw_loop = a.loop_build != 0u || (!overlap && n_streams <= a.sw_threshold) || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
@@ -1943,7 +1975,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     for (;;) {
         u32 sid;
 #if BRX_LEVEL == 1
-        if (first && !overlap) {
+        if (early) {
+            sid = early_slot(counter, &a.work_counter[9], &a.work_counter[5], &a.work_counter[8], t_start);
+            if (sid == 0xffffffffu) break;
+        } else if (first && !overlap) {
 #else
         if (first) {
 #endif
@@ -1962,15 +1997,13 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             // next to the regular kernel every slot comes from the counter: a workgroup is resident where and when waves of the
             // regular kernel have retired (a whole XCD may be busy with long streams to the end) -- slots tied to workgroup
             // indices would leave listed streams waiting for exactly those workgroups
-            if (overlap) sid -= gridDim.x;
+            if (overlap) sid -= gridDim.x; // (the late launch: what the early one left)
 #endif
         }
         if (sid >= n_streams) break;
 #if BRX_LEVEL == 1
-        if (overlap) {
-            sid = wait_for_entry(&my_list[sid], &a.work_counter[8]);
-            if (sid == 0xffffffffu) break; // the regular kernel is complete and left nothing in this slot
-        } else
+        if (overlap) sid = listed_entry(&my_list[sid]);
+        else
 #endif
 #if BRX_LEVEL > 0
         sid = rfl(my_list[sid]); // the streams the level below left to this one

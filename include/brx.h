@@ -102,8 +102,8 @@ typedef struct brx_ctx brx_ctx; /* one per (process, GPU): device tables, spill-
  *  - BRX_MEM_DEVICE with hip_stream == NULL runs on the context's own NON-BLOCKING stream: it is not ordered after
  *    work on the caller's streams (not even the NULL stream).  Either pass the stream that produced the buffers in
  *    opts->hip_stream, or synchronise before the call.
- *  - A context that met streams whose prefix-code tables exceed the regular kernel's LDS runs the wider kernel for them on
- *    a second HIP stream of its own, next to the regular kernel (forked from and joined back into the stream of the call
+ *  - A context that met streams whose prefix-code tables exceed the regular kernel's LDS also launches the wider kernel for
+ *    them on a second HIP stream of its own, next to the regular kernel (forked from and joined back into the stream of the call
  *    with events: the call's stream order is unchanged, work enqueued behind the call sees all of its results).
  *  - Offset tables: in_off / out_off must be non-decreasing.  Host tables are checked (BRX_ERR_INVALID_ARGUMENT);
  *    in device memory a decreasing pair gives that stream an empty input (status 24) or zero capacity (status 25).
