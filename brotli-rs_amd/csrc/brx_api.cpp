@@ -489,9 +489,12 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
     if (overlap) {
         HIP_TRY(hipMemsetAsync(a.defer, 0xff, (size_t)std::min<size_t>(n, c->defer_cap) * 4u, st)); // "not stored yet"
-        HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
+    // (the fork directly in front of the regular kernel, nothing in between: the second stream still has to see the event and
+    // dispatch, by then the regular kernel's workgroups are placed -- an early launch that gets the CUs first finds nothing
+    // listed, leaves, and that step runs as if there had been none)
+    if (overlap) HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
     if (a.defer != nullptr) { // the wider kernels (12 / 8 / 4 waves per CU): their waves leave at once when nothing was listed
