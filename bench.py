@@ -55,6 +55,8 @@ WORKLOADS = {
     "gen_c5x1024": (["gen:%d" % k for k in range(64)], 1024),
     # a MIXED batch of the reference's texts (rows of different length and statistics side by side)
     "mixed_textx4096": (["alice29.txt", "asyoulik.txt", "plrabn12.txt", "lcet10.txt"], 4096),
+    # ... and a wider mix: 1 MiB multi-meta-block streams, texts that need the level-1 and the level-2 kernel, tiny streams
+    "mixed_allx4096": (["alice29.txt", "c5_0", "lcet10.txt", "monkey", "asyoulik.txt", "mapsdatazrh", "plrabn12.txt", "c5_1"], 4096),
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic
