@@ -221,6 +221,11 @@ class Context:
         the LDS table memory of the levels below.  Level 1 = every stream that left the regular kernel."""
         return int(self._lib.brx_last_timing(self._h, 1 + level))
 
+    def last_lean_listed(self):
+        """Streams of the most recent launch that the lean instance (short streams, 32 waves per CU) left to the regular kernel:
+        the ones larger than its limit plus the short ones it gave up on (errors, block switches, large tables)."""
+        return int(self._lib.brx_last_timing(self._h, 5))
+
     def synchronize(self, hip_stream=None):
         rc = self._lib.brx_synchronize(self._h, hip_stream)
         if rc != 0:

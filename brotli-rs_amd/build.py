@@ -9,8 +9,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
-DEPS = SOURCES + ["brx_device.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
+SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
+DEPS = SOURCES + ["brx_device.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
 
@@ -68,12 +68,13 @@ def _build_locked(verbose):
             f.write('R"BRXASM(\n' + hot + ')BRXASM"\n')
     # the code-length symbol loop of the header path (brx_lens.S): one asm statement WITH operands -- `@n@` in the source is
     # operand n, local labels get the statement's unique suffix
-    for level, grow in ((0, 0), (1, 2560), (2, 10240), (3, 30720)):
-        txt = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp", "-DLDS_LENS=%d" % (8960 + grow),
+    # (LDS_LENS = offset of Lds::lens: behind the ring and the table memory; "s" = the lean instance, brx_small.h)
+    for level, lens_at in ((0, 8960), (1, 8960 + 2560), (2, 8960 + 10240), (3, 8960 + 30720), ("s", 2048 + 2048)):
+        txt = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp", "-DLDS_LENS=%d" % lens_at,
                                        os.path.join(CSRC, "brx_lens.S")]).decode()
         assert ")BRXASM" not in txt and "%" not in txt and "{" not in txt and "$" not in txt
         txt = re.sub(r"@(\d+)@", r"%\1", txt).replace(".Lls_", ".Lls%=_")
-        with open(os.path.join(CSRC, "_gen", "brx_lens_asm%s.h" % ("_l%d" % level if level else "")), "w") as f:
+        with open(os.path.join(CSRC, "_gen", "brx_lens_asm%s.h" % ("_s" if level == "s" else "_l%d" % level if level else "")), "w") as f:
             f.write("// generated from brx_lens.S by build.py -- do not edit\n")
             f.write('R"BRXASM(\n' + txt + ')BRXASM"\n')
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]

@@ -87,6 +87,7 @@ struct brx_ctx {
     const uint32_t *last_counter = nullptr; // counter line of the most recent launch (brx_last_timing(ctx, 2))
     uint32_t tiny_bytes = BRX_TINY_STREAM_BYTES; // bring-up / A-B: BRX_TINY_BYTES
     bool no_defer = false; // bring-up / A-B (BRX_NO_DEFER=1): spilled meta-blocks stay in the regular kernel's C++ loop
+    uint32_t small_bytes = BRX_SMALL_STREAM_BYTES; // streams up to this size go to the lean instance first (0: there is none)
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
     BrxSlabPool pool = {nullptr, nullptr, 0};
@@ -390,7 +391,7 @@ static int ensure_defer(brx_ctx *c, uint32_t n) {
     c->defer_cap = 0;
     size_t cap = 4096;
     while (cap < n) cap <<= 1;
-    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * (BRX_LEVELS - 1) * BRX_COUNTER_RING);
+    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_LEVELS * BRX_COUNTER_RING); // (levels 1..3 + the lean kernel's list)
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e);
     c->defer_cap = cap;
     return BRX_SUCCESS;
@@ -414,7 +415,7 @@ static int ensure_order(brx_ctx *c, uint32_t n) {
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
                   const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr,
-                  uint8_t *d_out_mirror = nullptr, bool may_overlap = false) {
+                  uint8_t *d_out_mirror = nullptr, bool may_overlap = false, uint32_t n_large = 0xffffffffu) {
     BrxKernelArgs a;
     a.out_mirror = d_out_mirror;
     a.order = d_order;
@@ -448,8 +449,31 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS) {
         int rc = ensure_defer(c, n);
         if (rc) return rc;
-        a.defer = c->d_defer + ring_slot * (BRX_LEVELS - 1) * c->defer_cap;
+        a.defer = c->d_defer + ring_slot * BRX_LEVELS * c->defer_cap;
         a.defer_cap = (uint32_t)c->defer_cap;
+    }
+    // The lean instance in front (brx_small.h; 32 waves per CU): it decodes the streams of at most BRX_SMALL_STREAM_BYTES
+    // compressed bytes and lists the rest -- and what it gives up on -- for the regular kernel (BrxKernelArgs::s_list).  With a
+    // queue order from the host (longest first) the small streams are the order's tail: `n_large` says where it starts, the
+    // regular kernel keeps the head as its own queue.  Without one the lean kernel classifies all n streams itself and the
+    // regular kernel's whole queue is that list.
+    a.s_list = nullptr;
+    a.small_bytes = c->small_bytes;
+    a.classify = 0u;
+    a.n_total = n;
+    bool lean = false, lean_tail = false;
+    if (c->small_bytes != 0u && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS && (d_order == nullptr || n_large < n || n_large == 0xffffffffu)) {
+        int rc = ensure_defer(c, n);
+        if (rc) return rc;
+        a.s_list = c->d_defer + (ring_slot * BRX_LEVELS + (BRX_LEVELS - 1)) * c->defer_cap;
+        lean_tail = d_order != nullptr && n_large <= n; // (else: the lean kernel classifies, the regular one takes the list)
+        if (lean_tail) {
+            a.n = n_large;
+        } else {
+            a.order = nullptr;
+            a.n = 0u;
+        }
+        lean = true;
     }
     a.debug = nullptr;
     a.dump = nullptr;
@@ -494,6 +518,17 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     // (the fork directly in front of the regular kernel, nothing in between: the second stream still has to see the event and
     // dispatch, by then the regular kernel's workgroups are placed -- an early launch that gets the CUs first finds nothing
     // listed, leaves, and that step runs as if there had been none)
+    if (lean) {
+        BrxKernelArgs as = a;
+        if (lean_tail) { // the order's tail
+            as.order = d_order + n_large;
+            as.n = n - n_large;
+        } else {
+            as.n = n;
+            as.classify = 1u;
+        }
+        brx_launch_decode_s(as, std::min(as.n, c->max_grid * 2u), st);
+    }
     if (overlap) HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
     brx_launch_decode(a, grid, st);
     HIP_TRY(hipGetLastError());
@@ -523,7 +558,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));
-    c->last_counter = a.defer != nullptr ? a.work_counter : nullptr;
+    c->last_counter = (a.defer != nullptr || lean) ? a.work_counter : nullptr;
     c->any_launch = true;
 #ifdef BRX_BRINGUP
     if (a.dump) { // bring-up: parked decoder states for tools/asm_emu.py
@@ -652,8 +687,13 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
         if (k) HIP_TRY(hipStreamWaitEvent(sk, c->ev_in[0], 0));
         const uint64_t i0 = in_off[a] - in_lo, i1 = in_off[b] - in_lo;
         if (i1 > i0 && !in_dev) HIP_TRY(hipMemcpyAsync(c->st_in + i0, in + in_lo + i0, (size_t)(i1 - i0), hipMemcpyHostToDevice, sk));
+        uint32_t n_large = 0xffffffffu; // sorted longest first: the streams for the lean instance are the order's tail
+        if (!c->no_order) {
+            n_large = 0;
+            for (uint32_t i = a; i < b; i++) n_large += in_off[i + 1] - in_off[i] > (uint64_t)c->small_bytes ? 1u : 0u;
+        }
         rc = launch(c, sk, timing && nchunks == 1, in_dev ? in_dev : c->st_in, d_in_off + a, b - a, c->st_out, d_out_off + a, d_out_len + a,
-                    d_status + a, d_order + a, nullptr, nullptr, mirror, nchunks == 1);
+                    d_status + a, d_order + a, nullptr, nullptr, mirror, nchunks == 1, n_large);
         if (rc) return rc;
     }
     for (unsigned k = 0; k < nchunks; k++) { // copy out (a second loop: a pageable copy blocks the host until it is done)
@@ -680,6 +720,7 @@ static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in
     if (flags & BRX_MEM_DEVICE) {
         hipStream_t st = (opts && opts->hip_stream) ? (hipStream_t)opts->hip_stream : c->stream;
         const uint32_t *d_order = nullptr;
+        uint32_t n_large = 0xffffffffu;
         if (flags & BRX_OPT_ORDER) { // longest compressed stream first, from a copy of the device table
             std::vector<uint64_t> h((size_t)n + 1);
             HIP_TRY(hipMemcpyAsync(h.data(), in_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -693,9 +734,11 @@ static int decode_batch_locked(brx_ctx *c, const uint8_t *in, const uint64_t *in
             HIP_TRY(hipMemcpyAsync(slot, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st)); // (`order` is a local)
             d_order = slot;
+            n_large = 0;
+            for (uint32_t i = 0; i < n; i++) n_large += h[i + 1] - h[i] > (uint64_t)c->small_bytes ? 1u : 0u;
         }
         if (timing) HIP_TRY(hipEventRecord(c->ev[0], st));
-        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order, nullptr, nullptr, nullptr, true);
+        int rc = launch(c, st, timing, in, in_off, n, out, out_off, out_len, status, d_order, nullptr, nullptr, nullptr, true, n_large);
         if (rc) return rc;
         if (timing) HIP_TRY(hipEventRecord(c->ev[1], st));
         if (!(opts && opts->hip_stream)) HIP_TRY(hipStreamSynchronize(st));
@@ -719,12 +762,13 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (which >= 2 && which <= 4) { // streams of the most recent launch listed for level which - 1 (waits for that launch)
+    if (which >= 2 && which <= 5) { // streams of the most recent launch listed for level which - 1 (waits for that launch);
+                                    // 5: streams the lean instance left to the regular kernel (large ones + given up)
         if (!c->any_launch) return -1.0;
         if (!c->last_counter) return 0.0;
         uint32_t v = 0;
         if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
-        if (hipMemcpy(&v, c->last_counter + 3 + which, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        if (hipMemcpy(&v, c->last_counter + (which == 5 ? 10 : 3 + which), 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
         return (double)v; // every stream that left level 0 (levels 2 and 3 take theirs out of these)
     }
     if (!c->have_timing) return -1.0;

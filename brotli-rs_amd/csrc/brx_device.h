@@ -29,8 +29,19 @@
 #else
 #define BRX_LDS_GROW 30720u
 #endif
+// A fifth, LEAN instance (brx_kernels_s.hip, BRX_SMALL): 5 120 B of LDS per wave and <= 64 VGPRs = 32 waves per CU, for
+// streams of at most BRX_SMALL_STREAM_BYTES compressed bytes (a batch of short messages, the RLE-like fills of BASELINE
+// configs 3 / 4): the whole input staged across the lanes once, a straight-line header for one block type per category, a
+// command loop of its own, no assembly loop, no parked state.  It decodes what is valid and plain and LISTS everything
+// else -- larger streams, any error, block switches, tables beyond its 512 words -- for the regular kernel behind it.
+#ifdef BRX_SMALL
+#define BRX_TM_WORDS 512u
+#define BRX_LENS_BYTES 768u
+#else
 #define BRX_TM_WORDS (1728u + BRX_LDS_GROW / 4u) // LDS table memory (prefix-code tables, context maps): 6 912 B at level 0
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
+#endif
+#define BRX_SMALL_STREAM_BYTES 500u // (+ up to 3 bytes of misalignment: at most 126 staged dwords of the 128)
 #define BRX_TINY_STREAM_BYTES 128u // compressed streams up to this size run their commands in the C++ loop alone
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that
@@ -111,13 +122,27 @@ struct BrxKernelArgs {
     volatile uint32_t *handed_seq; // nullptr, or a pinned host word that takes launch_seq whenever the regular kernel hands a
                             // stream up: the host turns `overlap` on only for contexts that met such streams lately
     uint32_t loop_build;    // which build of the assembly loop: 0 = bit window in VGPRs (full CUs), 1 = in SGPRs (sparse launch)
+    // The lean instance in front of the regular kernel (brx_launch_decode_s): it decodes the streams of at most `small_bytes`
+    // compressed bytes and lists the others (and the small ones it gives up on) in `s_list`, count in word 10 of the counter
+    // line; the regular kernel then takes queue slots [0, n) from `order` / the identity as before and slots beyond from that
+    // list.  Device-pointer path: n = 0 for the regular kernel, the lean one classifies all streams (`classify`: the listing of
+    // the large ones is done 64 streams per atomic by its first waves).  s_list == nullptr: no lean kernel in this launch.
+    uint32_t *s_list;
+    uint32_t small_bytes;
+    uint32_t classify;
+    uint32_t n_total;       // streams of the batch (bound of s_list)
     BrxDeviceTables t;
 };
 
+#ifdef BRX_SMALL
+#define BRX_LDS_BYTES 5120u
+#else
 #define BRX_LDS_BYTES (10240u + BRX_LDS_GROW)
+#endif
 #define BRX_DUMP_WORDS (16u + BRX_LDS_BYTES / 4u)
 
 void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
 void brx_launch_decode_l1(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // the wider instances (args.defer set)
 void brx_launch_decode_l2(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
 void brx_launch_decode_l3(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
+void brx_launch_decode_s(const BrxKernelArgs &args, unsigned grid, void *hip_stream);  // the lean instance (args.s_list set)

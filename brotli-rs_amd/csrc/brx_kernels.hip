@@ -52,6 +52,16 @@ enum {
 
 enum { LK_OK = 0, LK_NONE = 1, LK_EOF = 2 };
 
+#ifdef BRX_SMALL
+struct __attribute__((aligned(16))) Lds { // the lean instance (brx_device.h): ring, 512 words of tables, code-length scratch
+    u8 ring[BRX_RING_BYTES];
+    u32 tm[BRX_TM_WORDS];
+    u8 lens[BRX_LENS_BYTES];         // code lengths of one alphabet (<= 704) + build_code's histogram; during the command loop:
+                                     // context id -> literal tree handle (64 x u16)
+    u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
+    u32 pad[48];
+};
+#else
 struct __attribute__((aligned(16))) Lds {
     u8 ring[BRX_RING_BYTES];
     u32 tm[BRX_TM_WORDS];
@@ -62,6 +72,7 @@ struct __attribute__((aligned(16))) Lds {
     u32 pad[16];                     // bring-up counters (BRX_DEBUG_STATS)
     u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
 };
+#endif
 
 static_assert(sizeof(Lds) == BRX_LDS_BYTES, "Lds layout");
 // One Lds per workgroup (= per wave).  File scope, so the out-of-line segments address it as LDS directly (a
@@ -234,6 +245,20 @@ FI void scratch_release(const BrxSlabPool *pool, const u32 *slab) {
     if (threadIdx.x == 0u) atomicAnd(&pool->bitmap[idx >> 5], ~(1u << (idx & 31u)));
 }
 // Objects never straddle the LDS / HBM boundary.
+#ifdef BRX_SMALL
+// The lean instance has no slab: an object that does not fit sets the overflow mark (Dec::scr_top != 0) and gets address 0 --
+// whatever is then written there stays inside the wave's own LDS (the largest object, a 704-symbol code of 32-bit entries,
+// is 736 words; behind tm[] lie 3 072 bytes of the same wave), and the caller lists the stream for the regular kernel.
+FI u32 tm_alloc(Dec &d, u32 nwords) {
+    if (d.lds_top + nwords <= BRX_TM_WORDS) {
+        const u32 r = d.lds_top;
+        d.lds_top += nwords;
+        return r;
+    }
+    d.scr_top = 1u;
+    return 0u;
+}
+#else
 FI u32 tm_alloc(Dec &d, u32 nwords) {
     if (d.lds_top + nwords <= BRX_TM_WORDS) {
         u32 r = d.lds_top;
@@ -245,6 +270,7 @@ FI u32 tm_alloc(Dec &d, u32 nwords) {
     d.scr_top += nwords;
     return r;
 }
+#endif
 
 // ---- bit input (reference: src/bitreader/mod.rs:21-303) -------------------------------------------------
 // Branch-free on purpose (clamped index + select): a per-lane branch here makes LLVM's uniformity analysis
@@ -331,6 +357,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define MBW_DISTBAD 37
 #define MBW_EXIT 38
 
+#ifndef BRX_SMALL
 // ---- parking the decoder state in LDS ------------------------------------------------------------------
 // The cold parts of the decoder (meta-block header parsing with its code builders; the table-memory command
 // loop for oversized meta-blocks) are real out-of-line functions so that their register needs do not leak
@@ -389,6 +416,8 @@ FI void dec_store_in(const Dec &d, Lds &s) {
     put64(s, 3, d.bitpos);
     s.st[18] = d.lds_top; s.st[19] = d.scr_top; put64(s, 20, (u64)(uintptr_t)d.scratch);
 }
+
+#endif // !BRX_SMALL
 
 // ---- prefix codes ----------------------------------------------------------------------------------------
 // Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols in (length, symbol)
@@ -668,7 +697,9 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
         u64 win = d.win;
         u32 nav = d.nav, ww = d.ww, cbase = d.cbase, cha = d.chunkA, chb = d.chunkB;
         asm volatile(
-#if BRX_LEVEL == 0
+#ifdef BRX_SMALL
+#include "_gen/brx_lens_asm_s.h"
+#elif BRX_LEVEL == 0
 #include "_gen/brx_lens_asm.h"
 #elif BRX_LEVEL == 1
 #include "_gen/brx_lens_asm_l1.h"
@@ -1267,6 +1298,7 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
 
 FI u32 lut8(u32 vec, u32 b) { return (rdl(vec, b >> 2) >> ((b & 3u) * 8u)) & 0xffu; }
 
+#ifndef BRX_SMALL
 // ---- command loop ------------------------------------------------------------------------------------------
 struct MB { // per-meta-block scalars the command loop needs
     u32 mlen, npostfix, ndirect, cmode_w, cml, cmd, hl, hi, hd, ntl, ntd;
@@ -1748,6 +1780,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
     }
     return rc;
 }
+#endif // !BRX_SMALL
 // per-lane constant vectors of the C++ command loop, loaded once per wave by the kernel (wave_consts) and passed by value
 struct WaveConsts { u32 v_ic, v_lut0, v_lut1, v_lut2; };
 FI WaveConsts wave_consts(const u32 *t_lut) {
@@ -1759,6 +1792,7 @@ FI WaveConsts wave_consts(const u32 *t_lut) {
     c.v_lut0 = t_lut[lane]; c.v_lut1 = t_lut[64u + lane]; c.v_lut2 = t_lut[128u + lane];
     return c;
 }
+#ifndef BRX_SMALL
 __device__ __noinline__ u32 generic_commands(u32 mode_in, u32 v_ic, u32 v_lut0, u32 v_lut1, u32 v_lut2) {
     Lds &s = g_lds;
     Dec d;
@@ -1954,7 +1988,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     // the list is final, the early one may have taken any part of it)
     const bool overlap = BRX_LEVEL == 1 && a.overlap != 0u;
     const bool early = BRX_LEVEL == 1 && a.overlap == 1u;
-    const u32 n_streams = rfl(a.defer == nullptr ? 0u : early ? a.n : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
+    const u32 n_streams = rfl(a.defer == nullptr ? 0u : early ? a.n_total : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
     if (n_streams == 0u) return;
 #if BRX_LEVEL == 1
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -1963,7 +1997,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
     const bool sw_loop = a.loop_build != 0u || (!overlap && n_streams <= a.sw_threshold) || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
 #else
-    const u32 n_streams = a.n;
+    // (behind the lean instance, BrxKernelArgs::s_list: queue slots [0, n) are this launch's own, the slots beyond are the
+    // streams the lean kernel listed -- the large ones and the small ones it gave up on)
+    const u32 n_streams = a.n + (a.s_list != nullptr ? rfl(__builtin_nontemporal_load(&a.work_counter[10])) : 0u);
+    if (n_streams == 0u) return;
     const bool sw_loop = a.loop_build != 0u;
 #endif
     // Work queue.  A wave's FIRST stream is its workgroup index, no atomic: 4096 waves adding to one address from eight
@@ -2008,7 +2045,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #if BRX_LEVEL > 0
         sid = rfl(my_list[sid]); // the streams the level below left to this one
 #else
-        if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
+        if (sid >= a.n) sid = rfl(a.s_list[sid - a.n]);        // listed by the lean kernel
+        else if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
 #endif
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
@@ -2213,7 +2251,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             a.debug[(size_t)sid * 10u + 9] = s.st[19];
         }
 #ifdef BRX_BRINGUP
-        if (prof_on && lane < 32u) a.debug[(size_t)a.n * 10u + (size_t)sid * 32u + lane] = g_prof[lane];
+        if (prof_on && lane < 32u) a.debug[(size_t)a.n_total * 10u + (size_t)sid * 32u + lane] = g_prof[lane];
 #endif
         if (lane == 0u) {
             a.status[sid] = (int)st;
@@ -2227,3 +2265,6 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 void BRX_LAUNCH_NAME(const BrxKernelArgs &args, unsigned grid, void *hip_stream) {
     hipLaunchKernelGGL(BRX_KERNEL_NAME, dim3(grid), dim3(BRX_WAVE), 0, (hipStream_t)hip_stream, args);
 }
+#else // BRX_SMALL: the lean instance
+#include "brx_small.h"
+#endif
