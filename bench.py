@@ -386,7 +386,8 @@ def main():
     ctx = None
     if not STUB:
         from brotli_rs_amd import brx
-        ctx = brx.Context(local_rank)
+        import brx_knobs  # (A/B knobs of the tools/gpu_*.sh scripts: explicit brx_ctx_set_option calls, reported in the line as `options`)
+        ctx = brx_knobs.context(local_rank)
 
     fixtures, n = WORKLOADS[args.workload]
     if args.streams:
@@ -495,6 +496,8 @@ def main():
                           "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
                "bit_exact": ok, "kernel_ms_per_rank": [round(v, 4) for v in kavg_ranks]}
+        if not STUB and brx_knobs.options_from_env():
+            res["options"] = brx_knobs.options_from_env()  # (non-default library options of this run, tests/brx_knobs.py)
         if STUB:
             res["stub"] = "BRX_BENCH_STUB=1: launcher test on CPU, the decode is a stand-in -- `value` means nothing"
             res["data"] = "STUB"

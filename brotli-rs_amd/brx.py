@@ -52,6 +52,8 @@ def load_library():
     L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     L.brx_ctx_create.restype = ctypes.c_int
     L.brx_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    L.brx_ctx_set_option.restype = ctypes.c_int
+    L.brx_ctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64]
     L.brx_ctx_destroy.restype = None
     L.brx_ctx_destroy.argtypes = [ctypes.c_void_p]
     L.brx_decode_batch.restype = ctypes.c_int
@@ -90,17 +92,23 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
-                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch"]
+                    "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch",
+                    "brx_ctx_set_option"]
 
 
 def status_str(code: int) -> str:
     return load_library().brx_status_str(int(code)).decode("utf-8")
 
 
-class Context:
-    """One brx_ctx: a GPU, its tables, scratch and stream."""
+# brx_ctx_set_option (include/brx.h, BRX_OPTION_*): explicit knobs -- neither the library nor this module reads the environment
+OPTIONS = {"command_loop": 1, "loop_build": 2, "queue_order": 3, "hand_up": 4, "overlap": 5, "tiny_bytes": 6,
+           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10}
 
-    def __init__(self, device: int = 0):
+
+class Context:
+    """One brx_ctx: a GPU, its tables, scratch and stream.  `options`: {name: value} of OPTIONS, applied at creation."""
+
+    def __init__(self, device: int = 0, options=None):
         self._lib = load_library()
         h = ctypes.c_void_p()
         rc = self._lib.brx_ctx_create(ctypes.byref(h), device)
@@ -108,6 +116,13 @@ class Context:
             raise BrxError("brx_ctx_create failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
         self._h = h
         self.device = device
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        rc = self._lib.brx_ctx_set_option(self._h, OPTIONS[name], int(value))
+        if rc != 0:
+            raise BrxError("brx_ctx_set_option(%s, %d) failed: %s" % (name, value, self._lib.brx_last_error().decode()))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -88,6 +88,7 @@ struct brx_ctx {
     uint32_t tiny_bytes = BRX_TINY_STREAM_BYTES; // bring-up / A-B: BRX_TINY_BYTES
     bool no_defer = false; // bring-up / A-B (BRX_NO_DEFER=1): spilled meta-blocks stay in the regular kernel's C++ loop
     uint32_t small_bytes = BRX_SMALL_STREAM_BYTES; // streams up to this size go to the lean instance first (0: there is none)
+    uint32_t small_waves_per_cu = 32;              // grid of the lean instance (A/B)
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
     BrxSlabPool pool = {nullptr, nullptr, 0};
@@ -206,19 +207,13 @@ static int ctx_init(brx_ctx *c, int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     // 16 single-wave workgroups per CU: 4 per SIMD, bounded by the ~10 KiB of LDS each one declares.
     c->max_grid = (unsigned)prop.multiProcessorCount * 16u;
+#ifdef BRX_BRINGUP // (build.py with BRX_BRINGUP=1 only: statistics and LDS dumps for the emulator; the shipped library reads no environment)
     {
-        const char *e = getenv("BRX_DEBUG_STOP");
-        c->debug_stop = e ? (uint32_t)atoi(e) : 0u;
+        const char *e;
         c->debug_stats = getenv("BRX_DEBUG_STATS") != nullptr;
         c->debug_stats_all = getenv("BRX_DEBUG_STATS_ALL") != nullptr;
-        c->no_order = getenv("BRX_NO_ORDER") != nullptr;
-        c->no_defer = getenv("BRX_NO_DEFER") != nullptr;
-        if ((e = getenv("BRX_GRID_CAP")) != nullptr) c->grid_cap = (unsigned)atoi(e);
-        c->no_overlap = getenv("BRX_NO_OVERLAP") != nullptr;
-        c->force_overlap = getenv("BRX_FORCE_OVERLAP") != nullptr;
-        if ((e = getenv("BRX_TINY_BYTES")) != nullptr) c->tiny_bytes = (uint32_t)atoi(e);
-        c->no_mirror = getenv("BRX_NO_MIRROR") != nullptr; // bring-up / A-B: always copy the output back after the decode
-        if ((e = getenv("BRX_LOOP_BUILD")) != nullptr) c->loop_build = atoi(e); // bring-up: force one build of the loop
+        if ((e = getenv("BRX_DEBUG_STOP")) != nullptr) c->debug_stop = (uint32_t)atoi(e);
+        if ((e = getenv("BRX_SMALL_BYTES")) != nullptr) c->small_bytes = std::min<uint32_t>((uint32_t)atoi(e), BRX_SMALL_MAX_BYTES);
         if ((e = getenv("BRX_DEBUG_DUMP")) != nullptr) {
             unsigned iv = 0, mx = 0;
             char path[400];
@@ -229,6 +224,7 @@ static int ctx_init(brx_ctx *c, int device) {
             }
         }
     }
+#endif
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &q : c->s_chunk) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->s_wide, hipStreamNonBlocking)); // (never a high-priority one: its waiting waves would take the CUs first)
@@ -324,6 +320,35 @@ extern "C" int brx_ctx_create(brx_ctx **out, int device) {
 }
 
 static void stream_detach(brx_stream *s);
+
+extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
+    if (!c) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: ctx is NULL");
+    std::lock_guard<std::mutex> lk(c->mu);
+    switch (option) {
+    case BRX_OPTION_COMMAND_LOOP:
+        if (value != 0 && value != 7 && value != 8) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: command loop is 0, 7 or 8");
+        c->debug_stop = (uint32_t)value;
+        break;
+    case BRX_OPTION_LOOP_BUILD:
+        if (value < -1 || value > 1) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: loop build is -1, 0 or 1");
+        c->loop_build = (int)value;
+        break;
+    case BRX_OPTION_QUEUE_ORDER: c->no_order = value == 0; break;
+    case BRX_OPTION_HAND_UP: c->no_defer = value == 0; break;
+    case BRX_OPTION_OVERLAP:
+        if (value < 0 || value > 2) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: overlap is 0, 1 or 2");
+        c->no_overlap = value == 0;
+        c->force_overlap = value == 2;
+        break;
+    case BRX_OPTION_TINY_BYTES: c->tiny_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); break;
+    case BRX_OPTION_HOST_IN_PLACE: c->no_mirror = value == 0; break;
+    case BRX_OPTION_GRID_CAP: c->grid_cap = (unsigned)std::max<int64_t>(value, 0); break;
+    case BRX_OPTION_SMALL_BYTES: c->small_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), BRX_SMALL_MAX_BYTES); break;
+    case BRX_OPTION_SMALL_WAVES: c->small_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 32); break;
+    default: return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: unknown option");
+    }
+    return BRX_SUCCESS;
+}
 
 extern "C" void brx_ctx_destroy(brx_ctx *c) {
     if (!c) return;
@@ -527,7 +552,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
             as.n = n;
             as.classify = 1u;
         }
-        brx_launch_decode_s(as, std::min(as.n, c->max_grid * 2u), st);
+        brx_launch_decode_s(as, std::min(as.n, c->max_grid / 16u * c->small_waves_per_cu), st);
     }
     if (overlap) HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
     brx_launch_decode(a, grid, st);
@@ -935,6 +960,8 @@ struct brx_stream {
 #define BRX_BOUNDED_CHUNK (4u << 20)   // output decoded per slice
 #define BRX_BOUNDED_SLACK ((1u << 20) + 65536u) // room for the command that crosses the slice end
 #define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
+#define BRX_BOUNDED_SLIDE_MIN (1u << 20)        // the window slides only once it is over by this much (see bounded_step)
+#define BRX_BOUNDED_BUFSIZE ((size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK)
 
 static void bounded_release(brx_stream *s) {
     if (!s->d_buf && !s->d_in) return;
@@ -956,7 +983,7 @@ static void bounded_release(brx_stream *s) {
 static int bounded_init(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bufsize = (size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK;
+    const size_t bufsize = BRX_BOUNDED_BUFSIZE;
     HIP_TRY(hipMalloc(&s->d_in, s->in.size() + 16));
     HIP_TRY(hipMalloc(&s->d_buf, bufsize));
     HIP_TRY(hipMalloc(&s->d_rec, sizeof(BrxResume)));
@@ -977,14 +1004,17 @@ static int bounded_init(brx_stream *s) {
 static int bounded_step(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bufsize = (size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK;
-    if (s->pos - s->shift >= (uint64_t)BRX_BOUNDED_WINDOW + 16u) {
+    const size_t bufsize = BRX_BOUNDED_BUFSIZE;
+    if (s->pos - s->shift >= (uint64_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN) {
         // slide the window: keep the last BRX_BOUNDED_WINDOW bytes (every back-reference reaches at most that far); the
-        // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged.  The kernel
-        // pauses at an arbitrary command boundary, so the window may be over by 1..15 bytes: then nothing moves (a move by
-        // zero bytes would never end -- ADVICE r2) and cap_abs below leaves the slice that much less slack.
+        // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged.  The move is
+        // an overlapping one, done forward in pieces no longer than the distance moved -- so the window slides only once it
+        // is over by BRX_BOUNDED_SLIDE_MIN (the buffer has that much more room): at most ~17 copies per slide.  (The kernel
+        // pauses at an arbitrary command boundary: sliding as soon as the window was over by 16 bytes made the FIRST slide of
+        // every stream a move of 16 MiB in 16 .. 200-byte pieces, 10^5 copies -- ADVICE r3; over by 1..15 bytes it never ended,
+        // ADVICE r2.)
         const uint64_t new_shift = (s->pos - BRX_BOUNDED_WINDOW) & ~15ull;
-        const uint64_t delta = new_shift - s->shift, keep = s->pos - new_shift; // delta >= 16
+        const uint64_t delta = new_shift - s->shift, keep = s->pos - new_shift; // delta >= BRX_BOUNDED_SLIDE_MIN - 15
         for (uint64_t done = 0; done < keep; done += delta) { // forward, in pieces no longer than the move: no overlap
             const size_t piece = (size_t)std::min<uint64_t>(delta, keep - done);
             HIP_TRY(hipMemcpyAsync(s->d_buf + done, s->d_buf + delta + done, piece, hipMemcpyDeviceToDevice, c->stream));

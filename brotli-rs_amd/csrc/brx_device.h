@@ -41,7 +41,10 @@
 #define BRX_TM_WORDS (1728u + BRX_LDS_GROW / 4u) // LDS table memory (prefix-code tables, context maps): 6 912 B at level 0
 #define BRX_LENS_BYTES 1280u     // LDS: code-length scratch (768 B) + parked decoder state (512 B)
 #endif
-#define BRX_SMALL_STREAM_BYTES 500u // (+ up to 3 bytes of misalignment: at most 126 staged dwords of the 128)
+#define BRX_SMALL_MAX_BYTES 500u    // what the lean instance can stage (+ up to 3 bytes of misalignment: 126 of its 128 dwords)
+#define BRX_SMALL_STREAM_BYTES 128u // what it is given by default: its compiled command loop beats the regular kernel's hand-overs
+                                    // on a handful of commands (ukkonooa, 69 B: 0.76 -> 0.26 ms per 16 384), not on the 89 commands
+                                    // and 381 literals of monkey (425 B: 0.97 -> 1.74 ms) -- profiles/r04_lean.txt
 #define BRX_TINY_STREAM_BYTES 128u // compressed streams up to this size run their commands in the C++ loop alone
 #define BRX_FLUSH_BLOCK 1024u    // ring -> HBM flush granule: 64 lanes x 16 B, address aligned
 #define BRX_FLUSH_LAG 0u         // a block is flushed once the write cursor is this far past its end (everything that

@@ -9,7 +9,7 @@
 //   * prefix codes are canonical first-code tables in LDS; a symbol is resolved by ONE ballot: lane L
 //     compares the bit-reversed 15-bit window against limit[L], the first set bit of the ballot is the
 //     code length                                         (reference: src/huffman/, src/huffman/tree/)
-//   * the last 4 KiB of output live in an LDS ring (the sliding window of src/ringbuffer/); literals,
+//   * the last 2 KiB of output live in an LDS ring (the sliding window of src/ringbuffer/); literals,
 //     LZ77 copies and transformed dictionary words are produced into the ring by all 64 lanes and leave
 //     for HBM in address-aligned 1 KiB blocks of 16 B per lane; back-references older than the ring are
 //     read back from the stream's own HBM output          (reference: copy_literals, src/lib.rs:1483-1542)
@@ -484,10 +484,18 @@ FI u32 decode_sym_wide(Dec &d, const Lds &s, u32 h, u32 &sym) {
 // bits it consumes, never by the ones it only peeks at.  So up to the first read that crosses the end both readers see the
 // same bits and make the same decisions; the exact reader then stops with UnexpectedEOF; this one runs on over zeros
 // (every loop of the header is bounded by an alphabet size or a declared count) and finds cursor > end afterwards.
+#ifdef BRX_SMALL
+// (the lean instance: the whole input -- at most 128 dwords -- was staged once, the bits behind the stream's end masked off)
+FI u32 hb_word(Dec &d, u32 w) {
+    const u32 v = rfl(w < 64u ? rdl(d.chunkA, w & 63u) : rdl(d.chunkB, w & 63u));
+    return w < 128u ? v : 0u;
+}
+#else
 FI u32 hb_word(Dec &d, u32 w) {
     const u32 v = in_word(d, w); // (0 from the stream's last dword on)
     return w == d.hb_lastw ? v & d.hb_lastmask : v;
 }
+#endif
 FI void hb_begin(Dec &d) { // from the exact reader's cursor d.bitpos
     const u32 w = (u32)(d.bitpos >> 5), sh = (u32)d.bitpos & 31u;
     d.hb_lastw = (u32)((d.bitend - 1ull) >> 5);
@@ -694,8 +702,10 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
         // the loop below in hand-written assembly (brx_lens.S: same reader, same rules, ~22 instructions per length instead of
         // the ~60 the compiler makes of it); the one-symbol code-length code (no bits at all, Q5) stays with the C++ form
         u32 stat, nz_a, i_a, dirty_a, cur_a, vt0, vt1;
-        u64 win = d.win;
-        u32 nav = d.nav, ww = d.ww, cbase = d.cbase, cha = d.chunkA, chb = d.chunkB;
+        // (readfirstlane on everything the statement takes in SGPRs: values LLVM's uniformity analysis gives up on would be an
+        // "illegal VGPR to SGPR copy")
+        u64 win = (u64)rfl((u32)d.win) | ((u64)rfl((u32)(d.win >> 32)) << 32);
+        u32 nav = rfl(d.nav), ww = rfl(d.ww), cbase = rfl(d.cbase), cha = d.chunkA, chb = d.chunkB;
         asm volatile(
 #ifdef BRX_SMALL
 #include "_gen/brx_lens_asm_s.h"
@@ -962,12 +972,31 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
     const u32 base = d.pos - P + d.a;                      // skewed ring coordinate of the period's first byte
     u32 o = (16u * d.lane) % P;                            // this lane's unit inside the period, for the first block
     const u32 step = 1024u % P;
-    for (u32 k = 0; k < nblocks; k++) {
-        const u32x4 q = *(const u32x4 *)&s.ring[(base + o) & RMASK];
-        OUT_STORE128(q, d.pos + 16u * d.lane);
-        d.pos += 1024u;
-        o += step;
-        o = o >= P ? o - P : o;
+    // The loop is the fill itself (64 blocks per backward65536 stream, 172 per quickfox_repeated): the next block's unit is
+    // read while this one is stored (no LDS round trip inside an iteration), a period that divides 1 KiB (every power of two,
+    // e.g. the period-1 fill) is read once, and the store to the host mirror is issued only where there is one.
+    {
+        u32x4 q = *(const u32x4 *)&s.ring[(base + o) & RMASK];
+        u32 off = d.pos + 16u * d.lane;
+        if (step == 0u) {
+            if (d.mirror == nullptr) {
+                for (u32 k = 0; k < nblocks; k++) { __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0); off += 1024u; }
+            } else {
+                for (u32 k = 0; k < nblocks; k++) { OUT_STORE128(q, off); off += 1024u; }
+            }
+        } else {
+            const bool both = d.mirror != nullptr;
+            for (u32 k = 0; k < nblocks; k++) {
+                o += step;
+                o = o >= P ? o - P : o;
+                const u32x4 qn = *(const u32x4 *)&s.ring[(base + o) & RMASK]; // (one read more than needed at the end)
+                __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0);
+                if (both) __builtin_amdgcn_raw_buffer_store_b128(q, d.out2_rsrc, off, 0, 0);
+                off += 1024u;
+                q = qn;
+            }
+        }
+        d.pos += nblocks << 10;
     }
     d.vfl = d.pos + d.a;
     // Re-seed the ring with the last 2 KiB of the output = the last two blocks of the fill: their units are still in LDS
@@ -1098,6 +1127,11 @@ FI u32 dict_word(Dec &d, u32 copy_len, u32 word_id, u32 &wl, u32 &wbyte) {
     if (tid > 120u) return ST_INVALID_TRANSFORM_ID;
     const u8 *wp = d.t_dict + K_DOFFSET[copy_len] + index * copy_len;
     u32 w = (u32)wp[d.lane < copy_len ? d.lane : copy_len - 1u]; // clamped, lanes >= copy_len are never selected
+    if (tid == 0u) { // the identity (Appendix B, transform 0: no prefix, no suffix): what encoders use most (alice29: all 721)
+        wl = copy_len;
+        wbyte = w;
+        return ST_OK;
+    }
     const BrxTransform *x = d.t_xforms + tid;
     u32 plen = rfl(x->plen), slen = rfl(x->slen), op = rfl(x->op);
     u32 from = 0, mlen = copy_len, xm = 0;
@@ -1264,11 +1298,16 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
             const u32 cnt = len - base < 64u ? len - base : 64u;
             const u32 ba = cm + base + (lane < cnt ? lane : 0u);
             u32 vec = cm < TM_BYTES ? tm_ld8<true>(d, s, ba) : tm_ld8<false>(d, s, ba);
-            for (u32 k = 0; k < cnt; k++) {
-                const u32 idx = rdl(vec, k);
-                if (idx == 0u) {
-                    vec = wrl(rdl(m0, 0), k, vec);
-                } else if (idx < 64u) { // the front of the list: m0 alone moves (one DPP wave shift)
+            // Only the NON-ZERO entries change the list (and most entries of a map are zeros: runs).  They are taken one by
+            // one; a zero entry's value is the front of the list at its place = the value of the last non-zero entry in
+            // front of it (or the front the chunk started with), fetched for all zero lanes at once behind the loop.
+            const u32 front_in = rdl(m0, 0);
+            const u64 nzmask = ballot(lane < cnt && vec != 0u);
+            const u32 idxv = vec;
+            for (u64 todo = nzmask; todo != 0ull; todo &= todo - 1ull) {
+                const u32 k = (u32)__builtin_ctzll(todo);
+                const u32 idx = rdl(idxv, k);
+                if (idx < 64u) { // the front of the list: m0 alone moves (one DPP wave shift)
                     const u32 value = rdl(m0, idx);
                     const u32 up = (u32)__builtin_amdgcn_update_dpp((int)m0, (int)m0, 0x138, 0xf, 0xf, false); // wave_shr:1
                     m0 = lane == 0u ? value : (lane <= idx ? up : m0);
@@ -1287,6 +1326,12 @@ FI u32 read_context_map_body(Dec &d, Lds &s, u32 h, u32 rlemax, u32 cm, u32 len)
                     if (lane + 128u <= idx) m2 = s2;
                     if (lane + 192u <= idx) m3 = s3;
                 }
+            }
+            {
+                const u64 below = nzmask & ((1ull << lane) - 1ull);
+                const u32 src = below != 0ull ? 63u - (u32)__builtin_clzll(below) : 0u;
+                const u32 fill = (u32)__shfl((int)vec, (int)src);
+                vec = idxv != 0u ? vec : (below != 0ull ? fill : front_in);
             }
             if (cm < TM_BYTES) { if (lane < cnt) tm_st8<true>(d, s, cm + base + lane, vec); }
             else { if (lane < cnt) tm_st8<false>(d, s, cm + base + lane, vec); }

@@ -18,6 +18,7 @@
 // anything but BRX_OK, and parity of every other status stays where it was.
 
 #define SM_DEFER 0xffffu // "not for this kernel": list the stream for the regular one
+FI u64 rfl64(u64 v) { return (u64)rfl((u32)v) | ((u64)rfl((u32)(v >> 32)) << 32); }
 
 struct SmTabs { // the header's results (what Lds::mbw carries in the regular kernel)
     u32 npostfix, ndirect, cmode, ntl, ntd, cml, cmd, hl, hi, hd;
@@ -115,6 +116,7 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
     const u32 h_d0 = rfl(s.tm[t.hd]);
     const u32 hv_d0 = s.tm[h_d0 + (lane & 31u)];
     u32 mb_left = mlen;
+    PT_BEGIN(pc); // (bring-up build: cycles per part of a command -- slots 3 insert&copy, 4 literals, 13 distance, 14 copy)
     for (;;) {
         if (hb_over(d)) return SM_DEFER; // a read went beyond the input: UnexpectedEOF somewhere behind us
         // ---- insert&copy symbol + extra bits (parse_insert_and_copy_length :1179-1224)
@@ -125,6 +127,7 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
         { const u32 n = rec.w & 0xffu; if (n) insert_len += hb_bits(d, n); }
         { const u32 n = rec.w >> 8; if (n) copy_len += hb_bits(d, n); }
         if (insert_len > mb_left) return SM_DEFER; // :2036
+        PT_ADD(3, pc);
         // ---- literals (parse_insert_literals :1286-1365)
         if (insert_len) {
             u32 lit;
@@ -150,6 +153,7 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
             maybe_flush(d, s);
             if (mb_left == 0u) return 0u; // :2069: the copy part of the last command is ignored
         }
+        PT_ADD(4, pc);
         // ---- distance (parse_distance_code :1367-1410, decode_distance :1412-1481)
         u32 distance;
         const u32 max_allowed = d.pos < d.window ? d.pos : d.window;
@@ -187,6 +191,7 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
                 d.dist3 = d.dist2; d.dist2 = d.dist1; d.dist1 = d.dist0; d.dist0 = distance;
             }
         }
+        PT_ADD(13, pc);
         // ---- copy_literals :1483-1542
         if (distance <= max_allowed) {
             if (copy_len > mb_left) return SM_DEFER; // :2105
@@ -211,6 +216,7 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
             mb_left -= wl;
             maybe_flush(d, s);
         }
+        PT_ADD(14, pc);
         if (mb_left == 0u) return 0u;
     }
 }
@@ -218,10 +224,16 @@ FI u32 sm_commands(Dec &d, Lds &s, const SmTabs &t, const u32 mlen, const uint4 
 // One whole stream.  Returns 0 (decoded, flushed) or SM_DEFER.
 FI u32 sm_stream(Dec &d, Lds &s, const uint4 *__restrict__ iac, const WaveConsts &wc) {
     const u32 lane = d.lane;
+    PT_BEGIN(ps); // (bring-up build: slots 0 staging + framing, 1 header, 2 commands, 5 final flush)
     // the whole input across the lanes of two registers, once (at most 128 dwords)
-    d.cbase = 0u;
-    d.chunkA = in_load_chunk(d, 0u);
-    d.chunkB = in_load_chunk(d, 64u);
+    // (the bits behind the stream's end -- the next stream's first bytes -- are masked off here, once: hb_word just reads lanes)
+    {
+        const u32 lastw = (u32)((d.bitend - 1ull) >> 5), r = (u32)d.bitend & 31u;
+        const u32 lastmask = r ? (1u << r) - 1u : 0xffffffffu;
+        d.cbase = 0u;
+        d.chunkA = in_load_chunk(d, 0u) & (lane == lastw ? lastmask : 0xffffffffu);
+        d.chunkB = in_load_chunk(d, 64u) & (lane + 64u == lastw ? lastmask : 0xffffffffu);
+    }
     hb_begin(d);
     // parse_wbits :412-418 over the fixed tree :89-119
     u32 wbits;
@@ -266,9 +278,12 @@ FI u32 sm_stream(Dec &d, Lds &s, const uint4 *__restrict__ iac, const WaveConsts
             hb_begin(d);
         } else {
             SmTabs t;
+            PT_ADD(0, ps);
             if (sm_header(d, s, t)) return SM_DEFER;
             if (hb_over(d)) return SM_DEFER;
+            PT_ADD(1, ps);
             if (sm_commands(d, s, t, mlen, iac, wc)) return SM_DEFER;
+            PT_ADD(2, ps);
         }
         if (is_last) break; // MetaBlockEnd :2146-2153
     }
@@ -278,7 +293,9 @@ FI u32 sm_stream(Dec &d, Lds &s, const uint4 *__restrict__ iac, const WaveConsts
         if (k && hb_bits(d, 8u - k) != 0u) return SM_DEFER;
         if (hb_pos(d) != d.bitend) return SM_DEFER;
     }
+    PT_ADD(0, ps);
     if (d.vfl < d.pos + d.a) flush_range(d, s, d.vfl, d.pos + d.a);
+    PT_ADD(5, ps);
     return 0u;
 }
 
@@ -308,9 +325,11 @@ __global__ __launch_bounds__(BRX_WAVE, 8) void brx_decode_kernel_s(BrxKernelArgs
     const WaveConsts wc = wave_consts((const u32 *)a.t.context_lut);
     const uint4 *__restrict__ iac = (const uint4 *)a.t.iac;
     for (u32 slot = blockIdx.x; slot < a.n; slot += gridDim.x) {
-        const u32 sid = a.order != nullptr ? rfl(a.order[slot]) : slot;
-        const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
-        const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
+        // (everything that becomes decoder state goes through readfirstlane: values LLVM cannot prove wave-uniform would put the
+        // buffer resources into VGPRs and a waterfall loop around every store)
+        const u32 sid = rfl(a.order != nullptr ? a.order[slot] : slot);
+        const u64 i0 = rfl64(a.in_off[sid]), i1 = rfl64(a.in_off[sid + 1u]);
+        const u64 o0 = rfl64(a.out_off[sid]), o1 = rfl64(a.out_off[sid + 1u]);
         const bool big = i1 < i0 || i1 - i0 > (u64)a.small_bytes;
         u32 rc = SM_DEFER;
         if (!big) {
@@ -341,7 +360,17 @@ __global__ __launch_bounds__(BRX_WAVE, 8) void brx_decode_kernel_s(BrxKernelArgs
             d.t_dict = a.t.dict;
             d.t_xforms = a.t.xforms;
             d.t_lut = (const u32 *)a.t.context_lut;
+#ifdef BRX_BRINGUP
+            if (lane < 32u) g_prof[lane] = 0ull;
+            const unsigned long long t_stream = __builtin_readcyclecounter();
+#endif
             rc = in_len != 0u ? sm_stream(d, s, iac, wc) : SM_DEFER;
+#ifdef BRX_BRINGUP
+            if (a.debug != nullptr && rc == 0u) {
+                if (lane < 32u) a.debug[(size_t)a.n_total * 10u + (size_t)sid * 32u + lane] = g_prof[lane];
+                if (lane == 0u) a.debug[(size_t)sid * 10u + 8] = __builtin_readcyclecounter() - t_stream;
+            }
+#endif
             if (rc == 0u && lane == 0u) {
                 a.status[sid] = (int)ST_OK;
                 a.out_len[sid] = (u64)d.pos;

@@ -115,6 +115,28 @@ typedef struct brx_ctx brx_ctx; /* one per (process, GPU): device tables, spill-
 int brx_ctx_create(brx_ctx **out, int device);
 void brx_ctx_destroy(brx_ctx *ctx);
 
+/* Tuning and A/B knobs of a context: explicit arguments -- the library reads NO environment variable.  Takes effect for the
+ * launches enqueued after the call; unknown options return BRX_ERR_INVALID_ARGUMENT.  The defaults are the measured best; the
+ * test suite uses these to reach every path (the C++-only command loops, both builds of the assembly loop, the wider kernel
+ * instances behind / next to the regular one, the lean instance for short streams). */
+enum {
+    BRX_OPTION_COMMAND_LOOP = 1,  /* 0 = assembly loop with the C++ loop as its safety net (default); 8 = the C++ loop alone, whole
+                                     meta-blocks; 7 = the C++ loop alone, re-entered after every command */
+    BRX_OPTION_LOOP_BUILD = 2,    /* -1 = by occupancy (default); 0 = bit window in VGPRs (full chip); 1 = in SGPRs (sparse launch) */
+    BRX_OPTION_QUEUE_ORDER = 3,   /* 1 = longest compressed stream first on the host path (default); 0 = index order */
+    BRX_OPTION_HAND_UP = 4,       /* 1 = streams whose tables spill a kernel's LDS go to the next wider instance (default); 0 = they
+                                     stay, tables in an HBM slab */
+    BRX_OPTION_OVERLAP = 5,       /* level 1 next to the regular kernel: 0 = never, 1 = for contexts that handed a stream up lately
+                                     (default), 2 = always */
+    BRX_OPTION_TINY_BYTES = 6,    /* compressed size up to which the regular kernel runs a stream in its C++ loop alone (128) */
+    BRX_OPTION_HOST_IN_PLACE = 7, /* 1 = pinned host buffers are read / written by the kernel itself (default); 0 = staged copies */
+    BRX_OPTION_GRID_CAP = 8,      /* 0 = none (default); else at most this many resident waves of the regular kernel */
+    BRX_OPTION_SMALL_BYTES = 9,   /* compressed size up to which a stream goes to the lean instance first (default 128, at most
+                                     500; 0 = no lean instance) */
+    BRX_OPTION_SMALL_WAVES = 10   /* waves per CU of the lean instance's grid (default 32) */
+};
+int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
+
 /* Decode `n` independent Brotli streams (the batch analogue of constructing n reference Decompressors and
  * calling read_to_end on each: benches/lib.rs:45-46, tests/lib.rs everywhere).
  *   in       concatenated compressed streams; stream i is in[in_off[i] .. in_off[i+1])
@@ -140,7 +162,9 @@ const char *brx_last_error(void);
  * which = 2, 3, 4 (no BRX_OPT_TIMING needed; waits for the most recent launch): how many streams of that launch were
  * handed to the level-1, -2, -3 instance of the kernel.  Streams whose prefix-code tables do not fit the regular 6 912 B
  * of LDS table memory are handed over on the device to kernels with 9 472 / 17 152 / 37 632 B of it (12 / 8 / 4 instead
- * of 16 streams per CU), launched behind the regular one; which = 2 counts every stream that left the regular kernel. */
+ * of 16 streams per CU), launched behind the regular one; which = 2 counts every stream that left the regular kernel.
+ * which = 5: how many streams the lean instance (short streams, 32 per CU, launched in front of the regular kernel) left to the
+ * regular kernel -- the ones above its size limit plus the short ones it gave up on (any error, block switches, large tables). */
 double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
@@ -201,7 +225,7 @@ brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
 /* The same object in BOUNDED mode (brx_stream_new picks it by itself for compressed inputs of 4 MiB and more): the stream
  * is decoded slice by slice -- about 4 MiB of output per brx_stream_read that runs dry -- by a resumable kernel into a
  * sliding window on the device, so the output resident at any time is bounded by the largest Brotli window (16 MiB) plus
- * one slice plus slack (~21 MiB) however large the stream (like the reference's Decompressor, whose state is its window,
+ * one slice plus slack (~22 MiB) however large the stream (like the reference's Decompressor, whose state is its window,
  * src/lib.rs:377-394, 1560-1567).  Reads see decoded bytes as the slices complete; an invalid stream serves everything
  * decoded before the error.  A stream with a single command larger than the slack (a > 1 MiB copy or uncompressed
  * meta-block) falls back to whole-stream decoding. */

@@ -11,6 +11,7 @@ sys.path.insert(0, HERE)
 import crafted_sets  # noqa: E402
 import oracle_py  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
+import brx_knobs  # noqa: E402
 
 
 def main():
@@ -24,7 +25,7 @@ def main():
     streams += [s for _, s, _, _ in crafted_sets.all_sets()]
     cap = 1 << 20
     want = [oracle_py.decode(s, 0, cap=cap) for s in streams]
-    ctx = brx.Context(0)
+    ctx = brx_knobs.context(0)
     outs, status, out_len = ctx.decode_batch(streams, cap)
     bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
            if w[0] != st or (st == 0 and o != w[1])]

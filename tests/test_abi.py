@@ -27,6 +27,21 @@ def test_library_builds_for_gfx950():
     # the three wider-LDS instances of the kernel (brx_device.h, BRX_LEVEL) travel in the same library
     for k in (1, 2, 3):
         assert b"brx_decode_kernel_l%d" % k in blob
+    assert b"brx_decode_kernel_s" in blob  # ... and the lean instance for short streams (brx_small.h)
+
+
+def test_shipped_library_reads_no_environment():
+    """the reference has no environment knobs; here the C ABI takes explicit arguments
+    (brx_ctx_set_option).  The default build of libbrx.so must not name a BRX_* environment variable nor import getenv
+    (the bring-up build, BRX_BRINGUP=1, may)."""
+    import subprocess
+    path = brotli_rs_amd.build_library()
+    blob = open(path, "rb").read()
+    former = [b"BRX_DEBUG_STOP", b"BRX_DEBUG_STATS", b"BRX_DEBUG_DUMP", b"BRX_NO_ORDER", b"BRX_NO_DEFER", b"BRX_GRID_CAP", b"BRX_NO_OVERLAP",
+              b"BRX_FORCE_OVERLAP", b"BRX_TINY_BYTES", b"BRX_NO_MIRROR", b"BRX_LOOP_BUILD", b"BRX_SMALL_BYTES", b"BRX_SMALL_WAVES"]
+    assert not [n for n in former if n in blob]
+    nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
+    assert nm.returncode == 0 and "getenv" not in nm.stdout
 
 
 def test_every_declared_symbol_is_exported():

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_py as oracle
+import brx_knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +28,7 @@ def _read(name):
 @pytest.fixture(scope="module")
 def ctx():
     from brotli_rs_amd import brx
-    c = brx.Context(0)
+    c = brx_knobs.context(0)
     yield c
     c.close()
 
@@ -672,7 +673,7 @@ def test_fresh_context_sends_spilling_streams_straight_to_level_3():
     the regular kernel's list) instead of three; streams that spill after all are decoded there, bit-exact, and the next
     launch of the context runs the full chain (level 2 takes mapsdatazrh again)."""
     from brotli_rs_amd import brx
-    c2 = brx.Context(0)
+    c2 = brx_knobs.context(0)
     try:
         lcet, maps, alice = _read("lcet10.txt.compressed"), _read("mapsdatazrh.compressed"), _read("alice29.txt.compressed")
         streams = [alice, lcet, maps, _read("monkey.compressed"), lcet, bytes.fromhex("a103")] * 9
@@ -987,7 +988,8 @@ def test_device_path_longest_first_order(ctx):
 def test_bounded_window_over_by_less_than_its_slide_granularity(ctx):
     """ADVICE r2 (brx_api.cpp bounded_step): the kernel pauses at an arbitrary command boundary, so the first pause past
     16 MiB can leave the window over by 1..15 bytes -- less than the 16-byte granularity it slides by.  A move by zero
-    bytes used to loop forever.  craft.odd_long_stream drifts its boundaries by 2 bytes per 4 MiB round (pauses at 4 MiB,
+    bytes used to loop forever (r2), a move by a few bytes took 10^5 copies (r3): the window now slides only once it is
+    over by 1 MiB, and no read may stall.  craft.odd_long_stream drifts its boundaries by 2 bytes per 4 MiB round (pauses at 4 MiB,
     8 MiB + 2, 12 MiB + 4, 16 MiB + 6); plus a text-like stream of odd-sized commands when libbrotlienc is present."""
     import sys
     import craft
@@ -1007,12 +1009,17 @@ def test_bounded_window_over_by_less_than_its_slide_granularity(ctx):
             total += len(parts[-1])
         text = b"".join(parts)
         cases.append((brotli_enc.compress(text, quality=2, lgwin=22), text))
+    import time
     buf = (ctypes.c_ubyte * ((1 << 20) + 3))()
     for comp, exp in cases:
         h = L.brx_stream_new_bounded(ctx._h, comp, len(comp))
-        got, total = hashlib.sha256(), 0
+        got, total, slowest, reads = hashlib.sha256(), 0, 0.0, 0
         while True:
+            t0 = time.perf_counter()
             n = L.brx_stream_read(h, buf, len(buf))
+            if reads:  # (the first read allocates the stream's device buffers)
+                slowest = max(slowest, time.perf_counter() - t0)
+            reads += 1
             assert n >= 0, (n, total)
             if n == 0:
                 break
@@ -1020,6 +1027,9 @@ def test_bounded_window_over_by_less_than_its_slide_granularity(ctx):
             total += n
         L.brx_stream_free(h)
         assert total == len(exp) and got.hexdigest() == hashlib.sha256(exp).hexdigest()
+        # the first slide of the window used to be 16 MiB moved in 16 .. 200-byte pieces (10^5 device copies, a
+        # stall of seconds inside one read); a read is one 4 MiB slice (<= ~0.2 s of decoding) + one slide of <= 17 copies
+        assert slowest < 1.0, slowest
 
 
 def test_streams_outlive_their_context_safely():
@@ -1028,7 +1038,7 @@ def test_streams_outlive_their_context_safely():
     from brotli_rs_amd import brx
     L = brx.load_library()
     comp = _read("alice29.txt.compressed")
-    c = brx.Context(0)
+    c = brx_knobs.context(0)
     buf = (ctypes.c_ubyte * 4096)()
     hb = L.brx_stream_new_bounded(c._h, comp, len(comp))
     assert L.brx_stream_read(hb, buf, len(buf)) == 4096  # device buffers of the bounded stream are live
@@ -1039,7 +1049,7 @@ def test_streams_outlive_their_context_safely():
         assert L.brx_stream_read(h, buf, len(buf)) < -900
         L.brx_stream_free(h)
     # the Python facade holds its context
-    d = brx.Decompressor(io.BytesIO(comp), brx.Context(0))
+    d = brx.Decompressor(io.BytesIO(comp), brx_knobs.context(0))
     assert d.read() == _read("alice29.txt")
     d.close()
 

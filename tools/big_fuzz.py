@@ -13,13 +13,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import brotli_enc  # noqa: E402
 import oracle_py  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
+import brx_knobs  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 pool = [open(os.path.join(G, f), "rb").read() for f in ("alice29.txt", "lcet10.txt", "plrabn12.txt", "asyoulik.txt")]
 assert brotli_enc.available()
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 bad = 0
 for r in range(rounds):
     datas, streams = [], []

@@ -2,6 +2,8 @@
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts (tools/ubench/fetchcal.hip) -> gpurun_out/r03_fetchcal.txt
 set -u
 R=$GRAFT_REPO_ROOT
+# (the binary is built here, every time: it is not tracked)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/ubench/fetchcal.hip -o $R/tools/ubench/fetchcal || exit 1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/fc_$c

@@ -10,11 +10,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brotli_rs_amd import brx, shard  # noqa: E402
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import brx_knobs  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 text = open('tests/golden/data/alice29.txt', 'rb').read()
 dev = torch.device("cuda", 0)
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 one = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
 blob = one.repeat(n).contiguous()
 src_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * len(text)).contiguous()

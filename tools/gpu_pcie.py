@@ -10,12 +10,14 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from brotli_rs_amd import brx  # noqa: E402
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import brx_knobs  # noqa: E402
 
 comp = open('tests/golden/data/alice29.txt.compressed', 'rb').read()
 exp = open('tests/golden/data/alice29.txt', 'rb').read()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cap = (len(exp) + 15) & ~15
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 tag = "output copied back after the decode (BRX_NO_MIRROR)" if os.environ.get("BRX_NO_MIRROR") else "output stored to host memory by the kernel"
 for kind in ('pinned', 'pageable'):
     if kind == 'pinned':

@@ -8,9 +8,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from brotli_rs_amd import brx
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import brx_knobs  # noqa: E402
 G = os.path.join(ROOT, "tests", "golden", "data")
 dev = torch.device("cuda:0")
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 for name in ("empty", "x", "10x10y", "64x", "quickfox", "ukkonooa", "backward65536", "quickfox_repeated", "monkey"):
     comp = open(os.path.join(G, name + ".compressed"), "rb").read()
     exp = open(os.path.join(G, name), "rb").read()

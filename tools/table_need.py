@@ -17,6 +17,7 @@ os.environ["BRX_DEBUG_STATS"] = "1"
 os.environ["BRX_DEBUG_STATS_ALL"] = "1"
 import brotli_enc  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
+import brx_knobs  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden", "data")
 rng = random.Random(3)
@@ -35,7 +36,7 @@ for name in ("lcet10.txt", "plrabn12.txt", "alice29.txt", "asyoulik.txt", "mapsd
     streams.append(open(os.path.join(G, name + ".compressed"), "rb").read())
     caps.append(len(open(os.path.join(G, name), "rb").read()) + 16)
     tags.append((name, "fixture"))
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 r, w = os.pipe(); saved = os.dup(2); os.dup2(w, 2)
 outs, status, out_len = ctx.decode_batch(streams, caps)
 os.dup2(saved, 2); os.close(w)

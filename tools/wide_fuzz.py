@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import brotli_enc  # noqa: E402
 import oracle_py  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
+import brx_knobs  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -21,7 +22,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 texts = [open(os.path.join(G, f), "rb").read() for f in ("lcet10.txt", "plrabn12.txt", "alice29.txt", "asyoulik.txt", "mapsdatazrh")]
 corpus = b"".join(texts)
 assert brotli_enc.available()
-ctx = brx.Context(0)
+ctx = brx_knobs.context(0)
 bad = 0
 for r in range(rounds):
     datas, streams = [], []
