@@ -144,11 +144,12 @@ def under_profiler():
 
 
 def measured_traffic(workload, streams):
-    """HBM-side bytes of one launch, measured in this run: two child passes of this script under `rocprofv3 --kernel-trace
-    --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not share a pass, MI355X_MICROARCH.md), 2 launches each, no other trace
-    domain.  Per launch = the regular kernel + the wider instances behind it.  Counter unit KiB; fetch bytes = 2 x FETCH_SIZE
-    (64 counted per 128-byte memory-side request in every access pattern of this kernel, profiles/r03_fetchcal.txt),
-    WRITE_SIZE exact.  Returns (total_bytes, detail) or (None, reason)."""
+    """HBM-side bytes and issued instructions of one launch, measured in this run: three child passes of this script under
+    `rocprofv3 --kernel-trace --pmc <counters>` (FETCH_SIZE and WRITE_SIZE do not share a pass, MI355X_MICROARCH.md; the SQ
+    instruction counters are a third), 2 launches each, no other trace domain.  Per launch = the regular kernel + the other
+    instances around it.  Counter unit KiB; fetch bytes = 2 x FETCH_SIZE (64 counted per 128-byte memory-side request in
+    every access pattern of this kernel, profiles/r03_fetchcal.txt), WRITE_SIZE exact.  SQ_BUSY_CYCLES sums the 32 shader
+    engines' busy cycles (8 XCDs x 4): / 32 = the launch's cycles.  Returns (total_bytes, detail) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -157,33 +158,54 @@ def measured_traffic(workload, streams):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES")):
         d = tempfile.mkdtemp(prefix="brx_pmc_", dir="/tmp")
         try:
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+            cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            tot, launches = 0.0, set()
+            tot, launches = {c: 0.0 for c in counters}, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "brx_decode" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        tot += float(row["Counter_Value"])
+                    if "brx_decode" in row["Kernel_Name"] and row["Counter_Name"] in tot:
+                        tot[row["Counter_Name"]] += float(row["Counter_Value"])
                         if row["Kernel_Name"].startswith("brx_decode_kernel("):
                             launches.add(row["Dispatch_Id"])
             if not launches:
-                return None, "rocprofv3 --pmc %s: no counter rows (rc %d)" % (counter, r.returncode)
-            got[counter] = tot / len(launches) * 1024.0
+                if counters[0].startswith("SQ_"):
+                    continue  # (the instruction counters are an extra: the traffic figure stands without them)
+                return None, "rocprofv3 --pmc %s: no counter rows (rc %d)" % (counters[0], r.returncode)
+            for c in counters:
+                got[c] = tot[c] / len(launches)
         except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
-            return None, "rocprofv3 --pmc %s failed: %s" % (counter, type(e).__name__)
+            if counters[0].startswith("SQ_"):
+                continue
+            return None, "rocprofv3 --pmc %s failed: %s" % (counters[0], type(e).__name__)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    detail = {"fetch_size_counter_bytes": int(got["FETCH_SIZE"]), "fetch_bytes": int(2 * got["FETCH_SIZE"]),
-              "write_bytes": int(got["WRITE_SIZE"])}
-    return int(2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]), detail
+    detail = {"fetch_size_counter_bytes": int(got["FETCH_SIZE"] * 1024.0), "fetch_bytes": int(2 * got["FETCH_SIZE"] * 1024.0),
+              "write_bytes": int(got["WRITE_SIZE"] * 1024.0)}
+    if "SQ_INSTS_SALU" in got:
+        detail["sq"] = {"SQ_INSTS_SALU": int(got["SQ_INSTS_SALU"]), "SQ_INSTS_VALU": int(got["SQ_INSTS_VALU"]),
+                        "SQ_BUSY_CYCLES": int(got["SQ_BUSY_CYCLES"])}
+    return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0), detail
+
+
+def chain_floor(torch, np, dev, ctx, fx, barrier, steps=3, most=8):
+    """What one wavefront = one stream bounds a launch by: ONE stream of the workload decoded alone (a launch of one wave on an
+    otherwise empty chip), kernel time by HIP events -- the slowest of the workload's distinct members (the first `most`)."""
+    worst, which = 0.0, 0
+    for k, f in enumerate(fx[:most]):
+        b = Batch(torch, np, dev, [f], 1)
+        _, kms = timed_pass(ctx, b, steps, 1, barrier)
+        if min(kms) > worst:
+            worst, which = min(kms), k
+        del b
+    return worst, which
 
 
 def libbrotlidec_rate(comp, expect, seconds=3.0):
@@ -558,6 +580,29 @@ def main():
                            **({"traffic_detail": traffic_detail} if traffic_detail else {}),
                            "algorithmic_bytes_per_launch": alg_launch,
                            "kernel_ms_avg": round(kavg, 4), "kernel_ms_median": round(kms, 4)}
+        # The fractions that bind this kernel (one wavefront decodes one stream): the launch against ONE stream alone, the
+        # CU's scalar-ALU issue share, instructions per output byte -- measured in this run.
+        try:
+            def local_sync():
+                ctx.synchronize()
+                torch.cuda.synchronize()
+            floor_ms, floor_k = chain_floor(torch, np, dev, ctx, fx, local_sync)
+            res["roofline"]["chain_floor_ms"] = round(floor_ms, 4)
+            res["roofline"]["frac_of_chain_floor"] = round(floor_ms / kavg, 4)
+            res["roofline"]["chain_floor_what"] = ("one launch of ONE stream of the workload (%s), best of 3, HIP events: the time below which "
+                                                   "no batch of such streams can finish" % (fixtures[floor_k] if K > 1 else fixtures[0]))
+        except Exception as e:
+            res["roofline"]["chain_floor_ms"] = None
+            res["roofline"]["chain_floor_error"] = repr(e)[:200]
+        sq = (traffic_detail or {}).get("sq")
+        if sq:
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            cycles = sq["SQ_BUSY_CYCLES"] / 32.0
+            res["roofline"]["salu_issue_frac"] = round(sq["SQ_INSTS_SALU"] / (cus * cycles), 4)
+            res["roofline"]["valu_issue_frac_per_simd"] = round(sq["SQ_INSTS_VALU"] / (cus * 4 * cycles) * 4.0, 4)
+            res["roofline"]["insts_per_output_byte"] = round((sq["SQ_INSTS_SALU"] + sq["SQ_INSTS_VALU"]) / float(out_bytes_gpu), 3)
+            res["roofline"]["issue_note"] = ("SQ_INSTS_SALU / (CUs x launch cycles): one scalar ALU per CU issues one instruction per cycle for all its "
+                                             "waves; VALU: one wave64 instruction occupies its SIMD for 4 cycles (4 SIMDs per CU); launch cycles = SQ_BUSY_CYCLES / 32 shader engines")
         model = PHYSICAL_MODEL.get(args.workload)
         if model:  # physical HBM bytes known by construction ("report both")
             phys_launch = batch.byte_model(model)

@@ -52,7 +52,7 @@ def test_world_size_mismatch_fails_loudly():
 
 
 def test_in_run_traffic_reads_the_pmc_passes(tmp_path, monkeypatch):
-    """roofline.traffic is measured by the bench itself: two child passes under `rocprofv3 --pmc` (bench.measured_traffic).  Here
+    """roofline.traffic is measured by the bench itself: three child passes under `rocprofv3 --pmc` (bench.measured_traffic).  Here
     a stand-in `rocprofv3` on PATH writes the counter files a real pass leaves; what is tested is the command line (one counter
     per pass, --kernel-trace, no other trace domain, the child told not to recurse), the per-launch sum over the regular
     kernel and the wider instances behind it, the KiB unit and the calibrated x 2 of FETCH_SIZE."""
@@ -61,17 +61,21 @@ def test_in_run_traffic_reads_the_pmc_passes(tmp_path, monkeypatch):
 import os, sys
 a = sys.argv[1:]
 d = a[a.index("-d") + 1]
-c = a[a.index("--pmc") + 1]
+i = a.index("--pmc") + 1
+cs = []
+while not a[i].startswith("--"):
+    cs.append(a[i]); i += 1
 assert "--kernel-trace" in a and "--no-traffic" in a and "--sys-trace" not in a and "-s" not in a and "--hip-trace" not in a
-assert a.count("--pmc") == 1 and a[a.index("--pmc") + 2].startswith("--")  # one counter per pass
-open(os.path.join(os.environ["FAKE_LOG"]), "a").write(c + "\\n")
+assert a.count("--pmc") == 1 and (len(cs) == 1 or all(c.startswith("SQ_") for c in cs))  # FETCH_SIZE / WRITE_SIZE: a pass each
+open(os.path.join(os.environ["FAKE_LOG"]), "a").write("+".join(cs) + "\\n")
 os.makedirs(os.path.join(d, "host", "123"), exist_ok=True)
-v = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 300.0}[c]
 rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
-for disp in (1, 5):  # two launches: the regular kernel + one wider instance behind each, and a kernel that is not ours
-    rows.append('%%d,"brx_decode_kernel(BrxKernelArgs)",%%s,%%f' %% (disp, c, v))
-    rows.append('%%d,"brx_decode_kernel_l3(BrxKernelArgs)",%%s,%%f' %% (disp + 1, c, 24.0))
-    rows.append('%%d,"fill_kernel",%%s,%%f' %% (disp + 2, c, 1e9))
+for c in cs:
+    v = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 300.0, "SQ_INSTS_SALU": 7000.0, "SQ_INSTS_VALU": 5000.0, "SQ_BUSY_CYCLES": 3200.0}[c]
+    for disp in (1, 5):  # two launches: the regular kernel + one wider instance behind each, and a kernel that is not ours
+        rows.append('%%d,"brx_decode_kernel(BrxKernelArgs)",%%s,%%f' %% (disp, c, v))
+        rows.append('%%d,"brx_decode_kernel_l3(BrxKernelArgs)",%%s,%%f' %% (disp + 1, c, 24.0))
+        rows.append('%%d,"fill_kernel",%%s,%%f' %% (disp + 2, c, 1e9))
 open(os.path.join(d, "host", "123", "p_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")
 ''' % sys.executable)
     fake.chmod(0o755)
@@ -80,8 +84,9 @@ open(os.path.join(d, "host", "123", "p_counter_collection.csv"), "w").write("\\n
     sys.path.insert(0, ROOT)
     import bench
     total, detail = bench.measured_traffic("alice29x4096", 0)
-    assert (tmp_path / "log.txt").read_text().split() == ["FETCH_SIZE", "WRITE_SIZE"]
-    assert detail == {"fetch_size_counter_bytes": 1024 * 1024, "fetch_bytes": 2 * 1024 * 1024, "write_bytes": 324 * 1024}
+    assert (tmp_path / "log.txt").read_text().split() == ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_SALU+SQ_INSTS_VALU+SQ_BUSY_CYCLES"]
+    assert detail == {"fetch_size_counter_bytes": 1024 * 1024, "fetch_bytes": 2 * 1024 * 1024, "write_bytes": 324 * 1024,
+                      "sq": {"SQ_INSTS_SALU": 7024, "SQ_INSTS_VALU": 5024, "SQ_BUSY_CYCLES": 3224}}
     assert total == 2 * 1024 * 1024 + 324 * 1024
     assert not bench.under_profiler()
     monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
