@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-path", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic from the committed file)")
+    ap.add_argument("--no-chain-floor", action="store_true", help="skip roofline.chain_floor_ms (the single-stream launches after the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also time the ragged gather of the outputs to rank 0 (N>1: always)")
@@ -583,6 +584,8 @@ def main():
         # The fractions that bind this kernel (one wavefront decodes one stream): the launch against ONE stream alone, the
         # CU's scalar-ALU issue share, instructions per output byte -- measured in this run.
         try:
+            if args.no_chain_floor:
+                raise RuntimeError("--no-chain-floor")
             def local_sync():
                 ctx.synchronize()
                 torch.cuda.synchronize()

@@ -71,6 +71,8 @@ def load_library():
     L.brx_status_str.argtypes = [ctypes.c_int32]
     L.brx_last_error.restype = ctypes.c_char_p
     L.brx_last_timing.restype = ctypes.c_double
+    L.brx_last_trace.restype = ctypes.c_int
+    L.brx_last_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     L.brx_last_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.brx_synchronize.restype = ctypes.c_int
     L.brx_synchronize.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -93,7 +95,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
                     "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch",
-                    "brx_ctx_set_option"]
+                    "brx_ctx_set_option", "brx_last_trace"]
 
 
 def status_str(code: int) -> str:
@@ -101,8 +103,8 @@ def status_str(code: int) -> str:
 
 
 # brx_ctx_set_option (include/brx.h, BRX_OPTION_*): explicit knobs -- neither the library nor this module reads the environment
-OPTIONS = {"command_loop": 1, "loop_build": 2, "queue_order": 3, "hand_up": 4, "overlap": 5, "tiny_bytes": 6,
-           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10}
+OPTIONS = {"command_loop": 1, "loop_build": 2, "queue_order": 3, "hand_up": 4, "levels": 5, "tiny_bytes": 6,
+           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10, "trace": 11}
 
 
 class Context:
@@ -232,9 +234,26 @@ class Context:
         return float(self._lib.brx_last_timing(self._h, which))
 
     def last_wide_streams(self, level=1):
-        """Streams of the most recent launch handed to the level-`level` (1..3) instance of the kernel: their tables spill
-        the LDS table memory of the levels below.  Level 1 = every stream that left the regular kernel."""
+        """Streams of the most recent launch decoded at level >= `level` (1..3) of the kernel: their tables spill the LDS table
+        memory of the levels below.  Level 1 = every stream that left the regular kernel."""
         return int(self._lib.brx_last_timing(self._h, 1 + level))
+
+    def last_late_streams(self):
+        """Streams of the most recent launch handed up at a LATER meta-block with their decoder state (resumed, not restarted)."""
+        return int(self._lib.brx_last_timing(self._h, 6))
+
+    def last_redo_bytes(self):
+        """Output bytes of the most recent launch that were decoded twice because of hand-overs (0: all of them resumed)."""
+        return int(self._lib.brx_last_timing(self._h, 7))
+
+    def last_trace(self, n):
+        """(n, 4) uint64: start, end (100 MHz realtime), HW_ID | level << 32, workgroup | grid << 32 per stream (option trace = 1)."""
+        import numpy as np
+        buf = np.zeros((n, 4), dtype=np.uint64)
+        rc = self._lib.brx_last_trace(self._h, buf.ctypes.data, n)
+        if rc != 0:
+            raise BrxError("brx_last_trace failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        return buf
 
     def last_lean_listed(self):
         """Streams of the most recent launch that the lean instance (short streams, 32 waves per CU) left to the regular kernel:

@@ -94,11 +94,15 @@ struct brx_ctx {
     BrxSlabPool pool = {nullptr, nullptr, 0};
     unsigned max_grid = 0;
     unsigned grid_cap = 0;
-    bool force_overlap = false;                   // BRX_FORCE_OVERLAP: also on contexts that never handed a stream up (A/B)
-    bool no_overlap = false;                      // BRX_NO_OVERLAP: the wider kernels strictly behind the regular one (A/B)
+    bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
+    bool trace_on = false;                        // BRX_OPTION_TRACE: per-stream start / end / place of the most recent launch (brx_last_trace)
+    unsigned long long *d_trace = nullptr;
+    size_t trace_cap = 0, trace_n = 0;
+    bool no_plan_b = false;                       // BRX_OPTION_LEVELS 0: always plan A (the catch-all level-3 launch behind the regular kernel) (A/B)
     uint32_t *h_handed = nullptr, *d_handed = nullptr; // pinned host word (and its device address): BrxKernelArgs::handed_seq
-    hipStream_t s_wide = nullptr;                 // the wider kernels' own stream (launch(): "overlap")
-    hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING] = {};
+    hipStream_t s_wide[3] = {};                   // plan B: the wider kernels' own streams (levels 1..3)
+    hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING][3] = {};
+    uint32_t *d_handup = nullptr;                 // state records of the late lists: BRX_COUNTER_RING x BRX_LATE_CAP x 16 words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
     hipEvent_t ev_in[BRX_MAX_CHUNKS] = {}, ev_k[BRX_MAX_CHUNKS] = {};
@@ -165,7 +169,8 @@ static void ctx_release(brx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &q : c->s_chunk)
         if (q) (void)hipStreamSynchronize(q);
-    if (c->s_wide) (void)hipStreamSynchronize(c->s_wide);
+    for (auto &q : c->s_wide)
+        if (q) (void)hipStreamSynchronize(q);
     if (c->ev_last && c->any_launch) (void)hipEventSynchronize(c->ev_last);
     (void)hipFree(c->d_dict);
     (void)hipFree(c->d_lut);
@@ -174,6 +179,8 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->d_counters);
     if (c->h_handed) (void)hipHostFree(c->h_handed);
     (void)hipFree(c->d_defer);
+    (void)hipFree(c->d_handup);
+    (void)hipFree(c->d_trace);
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_pool);
     (void)hipFree(c->pool.bitmap);
@@ -192,9 +199,11 @@ static void ctx_release(brx_ctx *c) {
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
     for (auto &ev : c->ev_fork)
         if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : c->ev_join)
-        if (ev) (void)hipEventDestroy(ev);
-    if (c->s_wide) (void)hipStreamDestroy(c->s_wide);
+    for (auto &evs : c->ev_join)
+        for (auto &ev : evs)
+            if (ev) (void)hipEventDestroy(ev);
+    for (auto &q : c->s_wide)
+        if (q) (void)hipStreamDestroy(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto &q : c->s_chunk)
         if (q) (void)hipStreamDestroy(q);
@@ -227,12 +236,12 @@ static int ctx_init(brx_ctx *c, int device) {
 #endif
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &q : c->s_chunk) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->s_wide, hipStreamNonBlocking)); // (never a high-priority one: its waiting waves would take the CUs first)
+    for (auto &q : c->s_wide) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
     HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 64u));
-    HIP_TRY(hipHostMalloc((void **)&c->h_handed, 64, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&c->h_handed, 16 + 32 * BRX_COUNTER_RING, hipHostMallocMapped)); // (word 0: handed_seq; from word 4: 8 words per launch slot, plan B's counts)
     *c->h_handed = 0u;
     HIP_TRY(hipHostGetDevicePointer((void **)&c->d_handed, c->h_handed, 0));
     HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 64u));
@@ -291,7 +300,8 @@ static int ctx_init(brx_ctx *c, int device) {
     for (auto &ev : c->ev_k) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
     for (auto &ev : c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    for (auto &ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &evs : c->ev_join)
+        for (auto &ev : evs) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return BRX_SUCCESS;
 }
 
@@ -335,15 +345,16 @@ extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
         break;
     case BRX_OPTION_QUEUE_ORDER: c->no_order = value == 0; break;
     case BRX_OPTION_HAND_UP: c->no_defer = value == 0; break;
-    case BRX_OPTION_OVERLAP:
-        if (value < 0 || value > 2) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: overlap is 0, 1 or 2");
-        c->no_overlap = value == 0;
-        c->force_overlap = value == 2;
+    case BRX_OPTION_LEVELS:
+        if (value < 0 || value > 2) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: levels is 0, 1 or 2");
+        c->no_plan_b = value == 0;
+        c->force_plan_b = value >= 2;
         break;
     case BRX_OPTION_TINY_BYTES: c->tiny_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); break;
     case BRX_OPTION_HOST_IN_PLACE: c->no_mirror = value == 0; break;
     case BRX_OPTION_GRID_CAP: c->grid_cap = (unsigned)std::max<int64_t>(value, 0); break;
     case BRX_OPTION_SMALL_BYTES: c->small_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), BRX_SMALL_MAX_BYTES); break;
+    case BRX_OPTION_TRACE: c->trace_on = value != 0; break;
     case BRX_OPTION_SMALL_WAVES: c->small_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 32); break;
     default: return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: unknown option");
     }
@@ -407,7 +418,7 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 // Batches beyond this many streams keep their spilling streams in the regular kernel (the lists would be 64 x 4 B x n).
 #define BRX_DEFER_MAX_STREAMS (1u << 18)
 
-// Room for one list of n deferred stream indices per launch in flight (grown rarely: nobody may be using the old lists).
+// Room for the lists of n stream indices each of every launch in flight (grown rarely: nobody may be using the old lists).
 static int ensure_defer(brx_ctx *c, uint32_t n) {
     if (c->d_defer && c->defer_cap >= n) return BRX_SUCCESS;
     HIP_TRY(hipDeviceSynchronize());
@@ -416,9 +427,13 @@ static int ensure_defer(brx_ctx *c, uint32_t n) {
     c->defer_cap = 0;
     size_t cap = 4096;
     while (cap < n) cap <<= 1;
-    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_LEVELS * BRX_COUNTER_RING); // (levels 1..3 + the lean kernel's list)
+    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_LIST_REGIONS * BRX_COUNTER_RING); // (brx_device.h: lists 0..2, late, lean, class bytes)
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e);
     c->defer_cap = cap;
+    if (!c->d_handup) {
+        e = hipMalloc(&c->d_handup, (size_t)BRX_COUNTER_RING * BRX_LATE_CAP * 16u * 4u);
+        if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "state-record allocation failed", e);
+    }
     return BRX_SUCCESS;
 }
 
@@ -466,16 +481,28 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.loop_build = c->loop_build >= 0 ? (uint32_t)c->loop_build : (grid <= c->max_grid / 16u * BRX_SW_WAVES_PER_CU ? 1u : 0u);
     const size_t ring_slot = (size_t)(c->launch_seq++ % BRX_COUNTER_RING);
     a.work_counter = c->d_counters + ring_slot * 16u; // one 64-B line per launch
-    // streams whose tables spill the regular LDS table memory go to the wide kernel (not in the resumable and bring-up modes)
+    // streams whose tables spill a kernel's LDS table memory are listed for the level that holds them (not in the resumable and
+    // bring-up modes): BrxKernelArgs::defer
     a.tiny_bytes = c->tiny_bytes;
     a.defer = nullptr;
     a.defer_cap = 0;
+    a.handup = nullptr;
+    a.late_cap = 0;
+    a.cls = nullptr;
+    a.prepass = 0u;
+    a.list_mask = 0u;
+    a.counter_idx = 0u;
+    a.late_only = 0u;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
+    uint32_t *regions = nullptr; // this launch's BRX_LIST_REGIONS regions of defer_cap words
     if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS) {
         int rc = ensure_defer(c, n);
         if (rc) return rc;
-        a.defer = c->d_defer + ring_slot * BRX_LEVELS * c->defer_cap;
+        regions = c->d_defer + ring_slot * BRX_LIST_REGIONS * c->defer_cap;
+        a.defer = regions;
         a.defer_cap = (uint32_t)c->defer_cap;
+        a.handup = c->d_handup + ring_slot * (size_t)BRX_LATE_CAP * 16u;
+        a.late_cap = (uint32_t)std::min<size_t>(c->defer_cap, BRX_LATE_CAP);
     }
     // The lean instance in front (brx_small.h; 32 waves per CU): it decodes the streams of at most BRX_SMALL_STREAM_BYTES
     // compressed bytes and lists the rest -- and what it gives up on -- for the regular kernel (BrxKernelArgs::s_list).  With a
@@ -490,7 +517,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     if (c->small_bytes != 0u && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS && (d_order == nullptr || n_large < n || n_large == 0xffffffffu)) {
         int rc = ensure_defer(c, n);
         if (rc) return rc;
-        a.s_list = c->d_defer + (ring_slot * BRX_LEVELS + (BRX_LEVELS - 1)) * c->defer_cap;
+        a.s_list = c->d_defer + (ring_slot * BRX_LIST_REGIONS + 4u) * c->defer_cap;
         lean_tail = d_order != nullptr && n_large <= n; // (else: the lean kernel classifies, the regular one takes the list)
         if (lean_tail) {
             a.n = n_large;
@@ -501,6 +528,20 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         lean = true;
     }
     a.debug = nullptr;
+    a.trace = nullptr;
+    if (c->trace_on) { // diagnostics: one record per stream
+        if (c->trace_cap < n) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(c->d_trace);
+            c->d_trace = nullptr;
+            c->trace_cap = 0;
+            if (hipMalloc(&c->d_trace, (size_t)n * 32u) != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "trace allocation failed");
+            c->trace_cap = n;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_trace, 0, (size_t)n * 32u, st));
+        a.trace = c->d_trace;
+        c->trace_n = n;
+    }
     a.dump = nullptr;
     a.dump_interval = c->dump_interval;
     a.dump_max = c->dump_max;
@@ -516,33 +557,26 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.t.context_lut = c->d_lut;
     a.t.xforms = c->d_xforms;
     a.t.iac = c->d_iac;
-    // The level-1 kernel next to the regular one ("overlap"): in a mixed batch the streams handed up (listed within their
-    // first header) would otherwise wait for the longest stream of the regular kernel before they even start.  Level 1 is
-    // launched twice: EARLY on the context's second HIP stream (forked in front of the regular kernel) -- its workgroups
-    // become resident where and when waves of the regular kernel retire, take a list slot only when one is listed
-    // (compare-and-swap on the slot counter) and do not stay with nothing to do (brx_kernels.hip, early_slot) -- and LATE on
-    // the caller's stream behind the regular kernel, where the list is final, for whatever the early one left (usually
-    // nothing: an empty launch).  Correctness never depends on the early launch, nor on which kernel the dispatcher serves
-    // first; a first version whose waves WAITED for the regular kernel to complete took 2 x the time whenever they got the
-    // LDS before the regular kernel's workgroups did (one step in ten), and 58 s on a high-priority stream.
-    // Levels 2 and 3 stay behind level 1; the caller's stream joins the second one in front of level 2.
-    // Only for contexts that handed streams up within their last 8 launches (the regular kernel notes it in a pinned host word,
-    // read here without any API call): the second stream's fork and join cost ~30 us per launch, which batches of short
-    // streams would pay for nothing.
+    // Two launch plans for the wider levels (12 / 8 / 4 waves per CU; brx_device.h):
+    //   A  the regular kernel classifies on its way (a stream whose first header spills is listed for the level that holds its
+    //      tables), ONE catch-all level-3 launch behind it takes every list.  An empty launch costs ~5 us, and most batches
+    //      never list anything.
+    //   B  a header-only pre-pass of the regular kernel classifies every stream of its queue first; then levels 3, 2, 1 (their
+    //      own HIP streams, forked behind the pre-pass) and the regular kernel run NEXT TO each other, each on its own complete
+    //      list from its first wave on -- in a mixed batch the streams of the wider levels would otherwise wait for the longest
+    //      stream of the regular kernel before they even start; the caller's stream joins them, and the catch-all takes the late
+    //      list (streams that outgrew their level at a later meta-block: resumed there with their state).
+    // B costs the pre-pass (the first header of every stream is parsed twice), two more launches and the fork / join events
+    // (~30 us), so it is taken only by contexts that listed a stream within their last 64 launches: every kernel that lists one
+    // notes the launch in a pinned host word, read here without any API call.  No kernel ever waits for another one's list, and
+    // correctness does not depend on the plan.
     a.launch_seq = (uint32_t)c->launch_seq; // (already advanced: >= 1)
     a.handed_seq = c->d_handed;
     const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
-    const bool lately = c->force_overlap || (seen != 0u && a.launch_seq - seen <= 8u);
-    const bool overlap = a.defer != nullptr && may_overlap && !c->no_overlap && lately;
-    a.overlap = 0u;
+    const bool lately = c->force_plan_b || (seen != 0u && a.launch_seq - seen <= 64u);
+    const bool plan_b = a.defer != nullptr && may_overlap && !c->no_plan_b && lately;
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
-    if (overlap) {
-        HIP_TRY(hipMemsetAsync(a.defer, 0xff, (size_t)std::min<size_t>(n, c->defer_cap) * 4u, st)); // "not stored yet"
-    }
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
-    // (the fork directly in front of the regular kernel, nothing in between: the second stream still has to see the event and
-    // dispatch, by then the regular kernel's workgroups are placed -- an early launch that gets the CUs first finds nothing
-    // listed, leaves, and that step runs as if there had been none)
     if (lean) {
         BrxKernelArgs as = a;
         if (lean_tail) { // the order's tail
@@ -554,31 +588,58 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         }
         brx_launch_decode_s(as, std::min(as.n, c->max_grid / 16u * c->small_waves_per_cu), st);
     }
-    if (overlap) HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
-    brx_launch_decode(a, grid, st);
+    const unsigned per_cu = c->max_grid / 16u;
+    bool joined[3] = {false, false, false};
+    if (plan_b) {
+        BrxKernelArgs ap = a;
+        ap.cls = (uint8_t *)(regions + 5u * c->defer_cap);
+        ap.prepass = 1u;
+        ap.counter_idx = 9u;
+        brx_launch_decode(ap, grid, st);
+        // The host reads the pre-pass's counts (lists 0..2, and how many streams the lean kernel left to the regular one) and
+        // launches exactly the kernels that have work, with exactly their grids: the call waits here for the pre-pass (a header
+        // per stream: 0.3 .. 1 ms for a full grid).  Workgroups that would only find their list empty are not harmless next
+        // to real ones: a CU's LDS is handed out first-fit, and 10 KiB workgroups that come and go while 20 KiB ones are being
+        // placed leave those at offsets between which nothing of their size fits any more (4096 x mapsdatazrh: 6 instead of 8
+        // level-2 streams per CU for the whole launch, 89 ms instead of 60).
+        uint32_t *hc = c->h_handed + 4u + 8u * (uint32_t)ring_slot;
+        HIP_TRY(hipMemcpyAsync(hc, a.work_counter + 5, 24, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
+        HIP_TRY(hipEventSynchronize(c->ev_fork[ring_slot]));
+        const uint32_t cnt[4] = {0u, std::min<uint32_t>(hc[0], n), std::min<uint32_t>(hc[1], n), std::min<uint32_t>(hc[2], n)};
+        const uint32_t queued = a.n + (a.s_list != nullptr ? std::min<uint32_t>(hc[5], n) : 0u); // the regular kernel's queue
+        const uint32_t wide = cnt[1] + cnt[2] + cnt[3];
+        const uint32_t n0 = queued > wide ? queued - wide : 0u;
+        a.cls = ap.cls;
+        a.late_only = 1u;
+        // widest first (their streams tend to be the long jobs; big workgroups get contiguous LDS while the CUs are empty); the
+        // narrowest kernel with work stays on the caller's stream, the others get their own and are joined below
+        int narrowest = n0 ? 0 : cnt[1] ? 1 : cnt[2] ? 2 : 3;
+        for (int k = 3; k >= 1; k--) {
+            if (cnt[k] == 0u) continue;
+            BrxKernelArgs aw = a;
+            aw.cls = nullptr;
+            aw.list_mask = 1u << (k - 1);
+            aw.counter_idx = (uint32_t)k;
+            const unsigned gk = std::min(cnt[k], per_cu * (k == 1 ? 12u : k == 2 ? 8u : 4u));
+            hipStream_t sw = k == narrowest ? st : c->s_wide[k - 1];
+            if (sw != st) HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
+            if (k == 1) brx_launch_decode_l1(aw, gk, sw); else if (k == 2) brx_launch_decode_l2(aw, gk, sw); else brx_launch_decode_l3(aw, gk, sw);
+            if (sw != st) { HIP_TRY(hipEventRecord(c->ev_join[ring_slot][k - 1], sw)); joined[k - 1] = true; }
+        }
+        if (n0 != 0u) brx_launch_decode(a, std::min<unsigned>(n0, grid), st);
+    } else {
+        brx_launch_decode(a, grid, st);
+    }
     HIP_TRY(hipGetLastError());
-    if (a.defer != nullptr) { // the wider kernels (12 / 8 / 4 waves per CU): their waves leave at once when nothing was listed
-        const unsigned per_cu = c->max_grid / 16u;
-        if (overlap) {
-            HIP_TRY(hipMemsetAsync(a.work_counter + 8, 0x01, 4, st)); // behind the regular kernel: "complete"
-            HIP_TRY(hipStreamWaitEvent(c->s_wide, c->ev_fork[ring_slot], 0));
-            a.src_list = 0u; a.overlap = 1u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), c->s_wide);
-            HIP_TRY(hipEventRecord(c->ev_join[ring_slot], c->s_wide));
-            a.overlap = 2u;
-        }
-        if (lately || c->debug_stats) {
-            a.src_list = 0u; brx_launch_decode_l1(a, std::min(n, per_cu * 12u), st);
-            a.overlap = 0u;
-            if (overlap) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[ring_slot], 0)); // (both level-1 launches list for level 2)
-            a.src_list = 1u; brx_launch_decode_l2(a, std::min(n, per_cu * 8u), st);
-            a.src_list = 2u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
-        } else {
-            // A context that has not handed a stream up lately (most never do): ONE wider launch instead of three -- the
-            // level-3 kernel, whose table memory holds whatever levels 1 and 2 hold, takes the regular kernel's list directly.
-            // An empty launch costs ~5 us; three of them were a tenth of a 4096 x backward65536 batch.  Should streams
-            // spill after all they run 4 per CU this once, and the next launches of the context get the full chain again.
-            a.src_list = 0u; brx_launch_decode_l3(a, std::min(n, per_cu * 4u), st);
-        }
+    if (a.defer != nullptr) {
+        for (int k = 0; k < 3; k++)
+            if (joined[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[ring_slot][k], 0));
+        BrxKernelArgs ac = a; // the catch-all: its waves leave at once when nothing is listed
+        ac.cls = nullptr;
+        ac.list_mask = plan_b ? 8u : 15u;
+        ac.counter_idx = 4u;
+        brx_launch_decode_l3(ac, std::min(n, per_cu * 4u), st);
         HIP_TRY(hipGetLastError());
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -787,19 +848,39 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (which >= 2 && which <= 5) { // streams of the most recent launch listed for level which - 1 (waits for that launch);
-                                    // 5: streams the lean instance left to the regular kernel (large ones + given up)
+    if (which >= 2 && which <= 7) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
+                                    // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
+                                    // regular kernel (large ones + given up); 6 = streams of the late list (handed up with their
+                                    // state at a later meta-block); 7 = bytes decoded twice (0: every one of those was resumed)
         if (!c->any_launch) return -1.0;
         if (!c->last_counter) return 0.0;
-        uint32_t v = 0;
+        uint32_t w[16];
         if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
-        if (hipMemcpy(&v, c->last_counter + (which == 5 ? 10 : 3 + which), 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
-        return (double)v; // every stream that left level 0 (levels 2 and 3 take theirs out of these)
+        if (hipMemcpy(w, c->last_counter, 64, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        const uint32_t late = std::min<uint32_t>(w[8], BRX_LATE_CAP);
+        switch (which) {
+        case 2: return (double)w[5] + w[6] + w[7] + late;
+        case 3: return (double)w[6] + w[7];
+        case 4: return (double)w[7];
+        case 5: return (double)w[10];
+        case 6: return (double)late;
+        default: return (double)w[11];
+        }
     }
     if (!c->have_timing) return -1.0;
     float ms = 0.f;
     hipError_t e = which == 0 ? hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) : hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
     return e == hipSuccess ? (double)ms : -1.0;
+}
+
+extern "C" int brx_last_trace(brx_ctx *c, uint64_t *dst, uint32_t n) {
+    if (!c || !dst) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_last_trace: NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->d_trace || n > c->trace_n) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_last_trace: no trace of that many streams (BRX_OPTION_TRACE)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->any_launch) HIP_TRY(hipEventSynchronize(c->ev_last));
+    HIP_TRY(hipMemcpy(dst, c->d_trace, (size_t)n * 32u, hipMemcpyDeviceToHost));
+    return BRX_SUCCESS;
 }
 
 extern "C" int brx_synchronize(brx_ctx *c, void *hip_stream) {

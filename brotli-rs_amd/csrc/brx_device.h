@@ -14,12 +14,14 @@
 //     2       20 480 B      4 288 words             8
 //     3       40 960 B      9 408 words             4
 // (sizes are multiples of 1 280 B so that the waves of a CU fill its 160 KiB whatever the allocation granule.)  A wave that
-// finds a stream spilling its level's table memory drops it and lists it for the next level; the four kernels are
-// launched back to back on one HIP stream, no host round trip (BrxKernelArgs::defer).  Beyond level 3: the spill slabs.
+// finds a stream spilling its level's table memory drops it and lists it for the level that holds its tables
+// (BrxKernelArgs::defer, no host round trip).  Beyond level 3: the spill slabs.
 #ifndef BRX_LEVEL
 #define BRX_LEVEL 0
 #endif
 #define BRX_LEVELS 4
+#define BRX_LIST_REGIONS 6  // regions of one launch in brx_ctx::d_defer: lists 0..2, the late list, the lean kernel's list, the class bytes
+#define BRX_LATE_CAP 16384u // entries of the late list (with state records); a stream that finds it full keeps its slab
 #if BRX_LEVEL == 0
 #define BRX_LDS_GROW 0u
 #elif BRX_LEVEL == 1
@@ -101,14 +103,35 @@ struct BrxKernelArgs {
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
     uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..15 zeroed in-stream before the launch:
-                            // [k] work counter of the level-k kernel, [4 + k] streams listed for level k (k = 1..3)
-    uint32_t *defer;        // nullptr, or 3 lists of defer_cap stream indices (list of level k at (k - 1) * defer_cap): a
-                            // kernel lists for the next level the streams whose tables spill its LDS table memory (and
-                            // leaves them undecoded); the level-k kernel decodes exactly the streams of its list
+                            // [k] ticket counter of the level-k kernel (k = 0..3), [4] tickets of the catch-all launch, [5 + j]
+                            // streams in list j (j = 0..2: classified for level j + 1; j = 3: the late list), [9] tickets of the
+                            // classification pre-pass, [10] streams the lean kernel listed, [11] bytes decoded twice (see below)
+    // Streams whose meta-block tables spill a kernel's LDS table memory are not decoded there: they are LISTED for the level
+    // whose table memory holds them (the need is known exactly once the header is parsed) and decoded by that level's kernel.
+    //   lists 0..2 (region j of `defer`): streams of level j + 1 that have produced no output yet -- decoded from their start;
+    //   list 3, the LATE list: streams that were under way when a LATER meta-block outgrew their level -- entry k comes with
+    //            a state record (`handup`, 16 words per entry: the reference's Decompressor carries exactly this across a
+    //            meta-block boundary, src/lib.rs:1572-1573) and is resumed at that meta-block's header, never restarted.
+    //            Word 11 of the counter line adds the output position at every hand-up and subtracts it at every resume with
+    //            state: 0 after the launch = no byte was decoded twice.
+    // Two launch plans (launch() in brx_api.cpp): A -- the regular kernel classifies while it decodes, ONE catch-all level-3
+    // launch behind it takes all four lists; B -- a header-only pre-pass of the regular kernel (`prepass`) classifies every
+    // stream first (`cls`), then all four levels run NEXT TO each other on four HIP streams, each on its own list, and the
+    // catch-all takes the late list.  No kernel ever waits for another one's list.
+    uint32_t *defer;        // nullptr (no hand-up at all: spilled tables stay in a slab), or BRX_LIST_REGIONS regions of defer_cap words
     uint32_t defer_cap;
+    uint32_t *handup;       // state records of the late list, 16 words per entry, late_cap entries
+    uint32_t late_cap;
+    uint8_t *cls;           // plan B: per-stream class written by the pre-pass (0 = the regular kernel's), else nullptr
+    uint32_t prepass;       // regular kernel only: 1 = classify (first meta-block header) and write cls / lists 0..2, decode nothing
+    uint32_t list_mask;     // wider kernels: the lists this launch decodes (bit j = list j)
+    uint32_t counter_idx;   // the word of the counter line this launch takes its tickets from
+    uint32_t late_only;     // kernels below level 3: 1 = every hand-up goes to the late list (plan B: the class lists are being read)
     uint32_t tiny_bytes;    // compressed streams up to this size run their commands in the C++ loop alone (BRX_TINY_STREAM_BYTES)
     uint32_t sw_threshold;  // wider kernels: up to this many listed streams they run the sparse-launch build of the loop
     const BrxSlabPool *pool; // spill slabs
+    unsigned long long *trace; // nullptr, or 4 words per stream (BRX_OPTION_TRACE): when and where it was decoded -- start and end
+                            // (100 MHz realtime counter), HW_ID | level << 32, spare
     unsigned long long *debug; // bring-up profiling (BRX_DEBUG_STATS=1): 10 words per stream, else nullptr
     uint32_t *dump;         // bring-up (BRX_DEBUG_DUMP, debug_stop 9): word 0 = records written, then records of
                             // BRX_DUMP_WORDS words: {stream id, command index, 14 spare, the wave's whole LDS}
@@ -116,14 +139,9 @@ struct BrxKernelArgs {
     BrxResume *resume;      // nullptr, or one record per stream: resumable mode (see BrxResume)
     uint8_t *out_mirror;    // nullptr, or the device-visible address of pinned host memory laid out like `out`: output bytes are
                             // stored to both (the D2H copy fused into the decode)
-    uint32_t overlap;       // 1: the level-1 kernel runs NEXT TO the regular one (its own HIP stream): list entries start as
-                            // 0xffffffff, a level-1 wave waits for its entry, and word 8 of the counter line turns non-zero
-                            // (in stream order behind the regular kernel) once no further entry can come
-    uint32_t src_list;      // wider kernels: which list this launch decodes (level k normally list k - 1; the level-3 kernel
-                            // launched alone behind the regular one takes list 0, see launch())
     uint32_t launch_seq;    // sequence number of this launch on its context, and
-    volatile uint32_t *handed_seq; // nullptr, or a pinned host word that takes launch_seq whenever the regular kernel hands a
-                            // stream up: the host turns `overlap` on only for contexts that met such streams lately
+    volatile uint32_t *handed_seq; // nullptr, or a pinned host word that takes launch_seq whenever a stream is listed for a wider
+                            // level: the host picks plan B only for contexts that met such streams lately
     uint32_t loop_build;    // which build of the assembly loop: 0 = bit window in VGPRs (full CUs), 1 = in SGPRs (sparse launch)
     // The lean instance in front of the regular kernel (brx_launch_decode_s): it decodes the streams of at most `small_bytes`
     // compressed bytes and lists the others (and the small ones it gives up on) in `s_list`, count in word 10 of the counter

@@ -155,6 +155,7 @@ struct Dec {
     u32 dist0, dist1, dist2, dist3; // last distances, dist0 most recent
     // table memory
     u32 lds_top, scr_top;
+    u32 need_cur, need_peak;   // words of table memory allocated right now / at this meta-block's peak: the level that holds it
     u32 *scratch;              // this stream's spill slab, nullptr until the first spill (scratch_claim)
     const BrxSlabPool *pool;
     // per-lane constant vectors
@@ -260,6 +261,10 @@ FI u32 tm_alloc(Dec &d, u32 nwords) {
 }
 #else
 FI u32 tm_alloc(Dec &d, u32 nwords) {
+    // (what a wider level needs for the same objects: it packs them one behind the other, without the hole this level leaves at
+    // the end of its LDS part when an object does not fit)
+    d.need_cur += nwords;
+    d.need_peak = d.need_cur > d.need_peak ? d.need_cur : d.need_peak;
     if (d.lds_top + nwords <= BRX_TM_WORDS) {
         u32 r = d.lds_top;
         d.lds_top += nwords;
@@ -337,6 +342,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
 #define ST_POOL 38    // (2 words) const BrxSlabPool *
 #define ST_MIRROR 40  // (2 words) host-visible mirror of the output slot, or 0
+#define ST_NEED 42    // after a header whose tables spilled: words of table memory the meta-block needs (Dec::need_peak)
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
 // generic_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
@@ -392,6 +398,7 @@ FI void dec_load(Dec &d, const Lds &s) {
     d.t_dict = (const u8 *)(uintptr_t)get64(s, 23); d.t_xforms = (const BrxTransform *)(uintptr_t)get64(s, 25);
     d.t_lut = (const u32 *)(uintptr_t)get64(s, 27); d.wd = get64(s, 29); d.wd_limit = get64(s, 31);
     d.pool = (const BrxSlabPool *)(uintptr_t)get64(s, ST_POOL);
+    d.need_cur = 0u; d.need_peak = 0u;
     // (the per-lane constant vectors v_ic / v_lut0..2 are not loaded here: the kernel loads them once per wave and hands them
     // to generic_commands as arguments -- five global loads less per call of a segment)
     d.cbase = 0xffffff00u; // force a re-stage of the input chunks
@@ -408,6 +415,7 @@ FI void dec_load_in(Dec &d, const Lds &s) {
     d.bitend = get64(s, 5);
     d.lds_top = rfl(s.st[18]); d.scr_top = rfl(s.st[19]); d.scratch = (u32 *)(uintptr_t)get64(s, 20);
     d.pool = (const BrxSlabPool *)(uintptr_t)get64(s, ST_POOL);
+    d.need_cur = 0u; d.need_peak = 0u;
     d.cbase = 0xffffff00u; // force a re-stage of the input chunks
     d.chunkA = 0; d.chunkB = 0;
     in_seek(d, get64(s, 3));
@@ -415,6 +423,7 @@ FI void dec_load_in(Dec &d, const Lds &s) {
 FI void dec_store_in(const Dec &d, Lds &s) {
     put64(s, 3, d.bitpos);
     s.st[18] = d.lds_top; s.st[19] = d.scr_top; put64(s, 20, (u64)(uintptr_t)d.scratch);
+    s.st[ST_NEED] = d.need_peak;
 }
 
 #endif // !BRX_SMALL
@@ -1362,7 +1371,7 @@ FI u32 header_body(Dec &d, Lds &s) {
     enum { S_CAT_N, S_CAT_TYPES, S_CAT_COUNTS, S_MISC, S_CM, S_CM_BODY, S_NTD, S_CODES_INIT, S_CODE };
     u32 step = S_CAT_N, c = 0, h = 0;
     u32 npostfix = 0, ndirect = 0, cmode_w = 0, ntl = 1, ntd = 1, cml = 0, cmd = 0, dalpha = 0;
-    u32 cm = 0, cm_len = 0, rlemax = 0, which = 0, save_lds = 0, save_scr = 0;
+    u32 cm = 0, cm_len = 0, rlemax = 0, which = 0, save_lds = 0, save_scr = 0, save_need = 0;
     u32 ht = 0, total = 0, idx = 0;
     L.nbl = I.nbl = D.nbl = 1; L.btype = I.btype = D.btype = 0; L.btype_prev = I.btype_prev = D.btype_prev = 1;
     L.blen = I.blen = D.blen = 0xffffffffu; L.h_types = I.h_types = D.h_types = 0; L.h_counts = I.h_counts = D.h_counts = 0;
@@ -1446,12 +1455,14 @@ FI u32 header_body(Dec &d, Lds &s) {
             if (hb_bits(d, 1)) rlemax = hb_bits(d, 4) + 1u;
             save_lds = d.lds_top; // the map's code is dead once the map is read
             save_scr = d.scr_top;
+            save_need = d.need_cur;
             alphabet = rlemax + (which ? ntd : ntl);
             step = S_CM_BODY;
         } else if (step == S_CM_BODY) {
             if ((rc = read_context_map_body(d, s, h, rlemax, cm, cm_len))) return rc;
             d.lds_top = save_lds;
             d.scr_top = save_scr;
+            d.need_cur = save_need;
             step = which ? S_CODES_INIT : S_NTD;
             continue;
         }
@@ -1978,46 +1989,28 @@ __device__ __noinline__ void seg_finish() {
 #define BRX_LAUNCH_NAME brx_launch_decode_l3
 #define BRX_WAVES_PER_SIMD 1
 #endif
-#if BRX_LEVEL == 1
-// Level 1 next to the regular kernel (BrxKernelArgs::overlap, launch() in brx_api.cpp).  Two launches share one list and one
-// slot counter: the EARLY one on the context's second HIP stream while the regular kernel is still running (overlap == 1),
-// the LATE one behind the regular kernel on the caller's stream (overlap == 2) for whatever is left.
-FI u32 ld_dev(const u32 *p) { return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-// Early launch: a wave first claims a permit -- `claimed` counts the claims, a claim numbered below the count of listed
-// streams holds (so never more permits than listed streams), one at or beyond it is taken back -- and only with a permit
-// takes the next slot number from the counter the late launch uses as well.  Every step is one add (linear under
-// contention; a compare-and-swap on the slot counter took 10 x the time of 4096 x lcet10 when 3 000 waves arrived at once).
-// No slot is taken in vain before the regular kernel is complete, so none is lost: whatever number the early waves have
-// not taken, the late launch takes.  With nothing listed a wave stays for at most ~1 ms after its start and only while the
-// regular kernel is running (word 8 of the counter line is written behind it in stream order) -- it holds LDS that
-// workgroups of the regular kernel may be waiting for if the dispatcher served this launch first.
-// Returns the slot or 0xffffffff (leave).
-FI u32 early_slot(u32 *head, u32 *claimed, const u32 *listed, const u32 *complete, unsigned long long t_start) {
-    const u32 one = threadIdx.x == 0u ? 1u : 0u; // every lane executes the atomics (see the work queue below), lane 0 counts
-    u32 naps = 1u;
-    for (;;) {
-        if (ld_dev(claimed) < ld_dev(listed)) {
-            const u32 p = rdl(atomicAdd(claimed, one), 0);
-            if (p < ld_dev(listed)) {
-                const u32 t = rdl(atomicAdd(head, one), 0);
-                // (beyond the list only once the late launch is taking numbers too: the regular kernel is complete)
-                return t < ld_dev(listed) ? t : 0xffffffffu;
-            }
-            (void)atomicSub(claimed, one);
-        }
-        if (ld_dev(complete) != 0u) return 0xffffffffu;
-        if (__builtin_amdgcn_s_memrealtime() - t_start > 100000ull) return 0xffffffffu; // 1 ms of the 100 MHz clock
-        for (u32 k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(127);
-        naps = naps < 8u ? naps * 2u : 8u;
-    }
+// ---- hand-up of a stream to a wider level (BrxKernelArgs::defer) -------------------------------------------------------
+// Table memory of the four levels in words (brx_device.h): the level a meta-block needing `need` words belongs to.
+FI u32 level_for(u32 need) {
+    return need <= 1728u + 2560u / 4u ? 1u : need <= 1728u + 10240u / 4u ? 2u : 3u;
 }
-// The slot is listed (its number is below the count) but its entry may be a few hundred ns behind: the regular kernel's wave
-// takes the number, then stores the stream index (entries start as 0xffffffff).
-FI u32 listed_entry(const u32 *entry) {
-    for (;;) {
-        const u32 v = ld_dev(entry);
-        if (v != 0xffffffffu) return v;
-        __builtin_amdgcn_s_sleep(8);
+// Words of a state record (the late list): what the reference's Decompressor carries across a meta-block boundary
+// (src/lib.rs:1572-1573 resets everything of the meta-block; output position, window, the last four distances stay) plus
+// this decoder's cursor and the framing of the meta-block whose header comes next.
+enum { HU_BITPOS = 0, HU_POS = 2, HU_WINDOW = 3, HU_DIST = 4, HU_WD = 8, HU_ISLAST = 10, HU_MLEN = 11, HU_SID = 12, HU_WORDS = 16 };
+#if BRX_LEVEL > 0
+// Resume with state: the ring takes the last BRX_RING_BYTES of the stream's output back from HBM (the kernel that handed the
+// stream up flushed everything; it ran in an earlier launch, so its stores are visible).  Units beyond the output's ends read
+// as zeros or stale bytes: no command reads them before it has written them.
+__device__ __noinline__ void seg_resume() {
+    Lds &s = g_lds;
+    Dec d;
+    dec_load(d, s);
+    const u32 vend = (d.pos + d.a + 15u) & ~15u;
+    for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) {
+        const u32 v = vend - BRX_RING_BYTES + 1024u * j + 16u * d.lane;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, v - d.a, 0, 0);
+        *(u32x4 *)&s.ring[v & RMASK] = q;
     }
 }
 #endif
@@ -2027,20 +2020,22 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     if (a.debug_stop == 1u) return;
     const WaveConsts wc = wave_consts((const u32 *)a.t.context_lut);
 #define generic_commands(m_) generic_commands((m_), wc.v_ic, wc.v_lut0, wc.v_lut1, wc.v_lut2)
-    u32 *const counter = a.work_counter + BRX_LEVEL;
+    u32 *const counter = a.work_counter + a.counter_idx;
 #if BRX_LEVEL > 0
-    // (level 1 next to the regular kernel, BrxKernelArgs::overlap: early launch = the list is still growing; late launch =
-    // the list is final, the early one may have taken any part of it)
-    const bool overlap = BRX_LEVEL == 1 && a.overlap != 0u;
-    const bool early = BRX_LEVEL == 1 && a.overlap == 1u;
-    const u32 n_streams = rfl(a.defer == nullptr ? 0u : early ? a.n_total : __builtin_nontemporal_load(&a.work_counter[5u + a.src_list]));
+    // A wider kernel decodes the lists of `list_mask` one behind the other: lists 0..2 hold streams to be decoded from their
+    // start, list 3 (late) streams to be resumed from a state record.
+    if (a.defer == nullptr) return;
+    u32 cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    if (a.list_mask & 1u) cnt0 = rfl(__builtin_nontemporal_load(&a.work_counter[5]));
+    if (a.list_mask & 2u) cnt1 = rfl(__builtin_nontemporal_load(&a.work_counter[6]));
+    if (a.list_mask & 4u) cnt2 = rfl(__builtin_nontemporal_load(&a.work_counter[7]));
+    if (a.list_mask & 8u) cnt3 = rfl(__builtin_nontemporal_load(&a.work_counter[8]));
+    cnt0 = cnt0 < a.defer_cap ? cnt0 : a.defer_cap; cnt1 = cnt1 < a.defer_cap ? cnt1 : a.defer_cap;
+    cnt2 = cnt2 < a.defer_cap ? cnt2 : a.defer_cap; cnt3 = cnt3 < a.late_cap ? cnt3 : a.late_cap;
+    const u32 n_streams = cnt0 + cnt1 + cnt2 + cnt3;
     if (n_streams == 0u) return;
-#if BRX_LEVEL == 1
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
-    const u32 *const my_list = a.defer + (size_t)a.src_list * a.defer_cap;
     // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
-    const bool sw_loop = a.loop_build != 0u || (!overlap && n_streams <= a.sw_threshold) || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
+    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
 #else
     // (behind the lean instance, BrxKernelArgs::s_list: queue slots [0, n) are this launch's own, the slots beyond are the
     // streams the lean kernel listed -- the large ones and the small ones it gave up on)
@@ -2056,42 +2051,35 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     bool first = true;
     for (;;) {
         u32 sid;
-#if BRX_LEVEL == 1
-        if (early) {
-            sid = early_slot(counter, &a.work_counter[9], &a.work_counter[5], &a.work_counter[8], t_start);
-            if (sid == 0xffffffffu) break;
-        } else if (first && !overlap) {
-#else
         if (first) {
-#endif
             first = false;
+            // (workgroup i runs on XCD i % 8: with slot = i a batch whose streams repeat with a period of 2, 4 or 8 -- every fourth
+            // stream the long one -- would put all its long streams on two XCDs.  The swizzle keeps every aligned block of 8 slots on
+            // 8 different XCDs and varies which one takes which with the block's number; a ragged last block of 64 stays as it is.)
             sid = blockIdx.x;
+            if ((sid | 63u) < gridDim.x) sid ^= (sid >> 3) & 7u;
         } else {
-#if BRX_LEVEL == 1
-            if (!overlap)
-#endif
             if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
             // Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right behind the
             // lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63 around both
             // across the back edge -- they then spin in their own loop and never meet lane 0 again.
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
-#if BRX_LEVEL == 1
-            // next to the regular kernel every slot comes from the counter: a workgroup is resident where and when waves of the
-            // regular kernel have retired (a whole XCD may be busy with long streams to the end) -- slots tied to workgroup
-            // indices would leave listed streams waiting for exactly those workgroups
-            if (overlap) sid -= gridDim.x; // (the late launch: what the early one left)
-#endif
         }
         if (sid >= n_streams) break;
-#if BRX_LEVEL == 1
-        if (overlap) sid = listed_entry(&my_list[sid]);
-        else
-#endif
 #if BRX_LEVEL > 0
-        sid = rfl(my_list[sid]); // the streams the level below left to this one
+        u32 late_slot = 0xffffffffu; // >= 0: resume from state record `late_slot`
+        if (sid < cnt0) sid = rfl(a.defer[sid]);
+        else if (sid < cnt0 + cnt1) sid = rfl(a.defer[(size_t)a.defer_cap + (sid - cnt0)]);
+        else if (sid < cnt0 + cnt1 + cnt2) sid = rfl(a.defer[2u * (size_t)a.defer_cap + (sid - cnt0 - cnt1)]);
+        else {
+            late_slot = sid - cnt0 - cnt1 - cnt2;
+            sid = rfl(a.defer[3u * (size_t)a.defer_cap + late_slot]);
+        }
 #else
         if (sid >= a.n) sid = rfl(a.s_list[sid - a.n]);        // listed by the lean kernel
         else if (a.order != nullptr) sid = rfl(a.order[sid]); // the host path queues the longest streams first
+        // plan B: the pre-pass has classified every stream of this queue; the ones of the wider levels are theirs
+        if (a.cls != nullptr && a.prepass == 0u && rfl((u32)a.cls[sid]) != 0u) continue;
 #endif
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
@@ -2201,22 +2189,81 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         const u32 prof_on = 0u;
 #endif
         const bool tiny = i1 - i0 <= (u64)a.tiny_bytes || i1 < i0;
-        bool deferred = false;
+        const unsigned long long t_begin = a.trace != nullptr ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        u32 hand = 0u, hand_level = 0u, late_at = 0u; // hand: 1 = listed for `hand_level` (decoded from its start there), 2 = late list entry `late_at`
+        u64 hdr_bitpos = 0ull;
         u64 tstream = prof_on ? (u64)__builtin_readcyclecounter() : 0ull;
 #ifdef BRX_BRINGUP
         if (lane < 32u) g_prof[lane] = 0ull;
 #endif
         PT_BEGIN(pd);
-        u32 st = seg_frame();
+#if BRX_LEVEL == 0
+        if (a.prepass != 0u) {
+            // ---- plan B's classification pre-pass: framing + the first compressed meta-block's header, nothing else.  A stream
+            // whose tables spill and that has produced no output yet gets the level that holds them; everything else -- fits,
+            // errors, streams without a compressed meta-block, output before the first header -- stays with the regular kernel.
+            u32 c = 0u;
+            u32 st0 = seg_frame();
+            if (st0 == SEG_NEED_HEADER) {
+                st0 = cold_header();
+                if (st0 == ST_OK && get64(s, 20) != 0ull && rfl(s.st[10]) == 0u) c = level_for(rfl(s.st[ST_NEED]));
+            }
+            {
+                const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);
+                if (slab != nullptr) scratch_release(a.pool, slab);
+            }
+            if (lane == 0u) a.cls[sid] = (u8)c;
+            if (c != 0u) {
+                const u32 slot = rdl(atomicAdd(a.work_counter + 4 + c, lane == 0u ? 1u : 0u), 0);
+                if (lane == 0u) a.defer[(size_t)(c - 1u) * a.defer_cap + slot] = sid;
+                if (lane == 0u && a.handed_seq != nullptr) *a.handed_seq = a.launch_seq; // (pinned host word: "this context meets such streams")
+            }
+            continue;
+        }
+#endif
+        u32 st;
+#if BRX_LEVEL > 0
+        if (late_slot != 0xffffffffu) {
+            // ---- resume with state (the late list): the stream was under way in a narrower kernel when the header that comes
+            // next outgrew it.  Its record goes over the fresh state, the ring comes back from HBM, and the loop below starts at
+            // that header.
+            const u32 *rec = a.handup + (size_t)late_slot * HU_WORDS;
+            const u32 rpos = rfl(rec[HU_POS]);
+            if (lane == 0u) {
+                s.st[3] = rec[HU_BITPOS]; s.st[4] = rec[HU_BITPOS + 1];
+                s.st[10] = rpos; s.st[12] = rpos + s.st[11];
+                s.st[13] = rec[HU_WINDOW];
+                s.st[14] = rec[HU_DIST]; s.st[15] = rec[HU_DIST + 1]; s.st[16] = rec[HU_DIST + 2]; s.st[17] = rec[HU_DIST + 3];
+                s.st[29] = rec[HU_WD]; s.st[30] = rec[HU_WD + 1];
+                s.st[ST_STARTED] = 1u; s.st[ST_ISLAST] = rec[HU_ISLAST]; s.st[ST_MLEN] = rec[HU_MLEN];
+                (void)atomicSub(a.work_counter + 11, rpos); // nothing of this stream is decoded twice
+            }
+            seg_resume();
+            st = SEG_NEED_HEADER;
+        } else
+#endif
+        st = seg_frame();
         PT_ADD(0, pd);
         while (st == SEG_NEED_HEADER) {
+            hdr_bitpos = get64(s, 3);
             st = cold_header();
             PT_ADD(1, pd);
             if (st) break;
 #if BRX_LEVEL < BRX_LEVELS - 1
-            if (a.defer != nullptr && get64(s, 20) != 0ull) { // this meta-block's tables spilled into a slab: a stream
-                deferred = true;                               // for the next level
-                break;
+            if (a.defer != nullptr && get64(s, 20) != 0ull) {
+                // This meta-block's tables spilled into a slab: a stream for the level that holds them.  With no output so far
+                // it is listed for that level and decoded from its start (plan A's classification, done by the regular kernel
+                // on its way); otherwise -- and whenever the class lists are already being read (plan B) -- it goes to the
+                // late list with its state.  A full late list: the stream stays and runs this meta-block from its slab.
+                hand_level = level_for(rfl(s.st[ST_NEED]));
+                if (hand_level <= BRX_LEVEL) hand_level = BRX_LEVEL + 1u;
+                if (BRX_LEVEL == 0 && a.late_only == 0u && rfl(s.st[10]) == 0u) {
+                    hand = 1u;
+                } else {
+                    late_at = rdl(atomicAdd(a.work_counter + 8, lane == 0u ? 1u : 0u), 0);
+                    if (late_at < a.late_cap) hand = 2u;
+                }
+                if (hand != 0u) break;
             }
 #endif
             if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u)) {
@@ -2279,13 +2326,21 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if (slab != nullptr) scratch_release(a.pool, slab);
         }
 #if BRX_LEVEL < BRX_LEVELS - 1
-        if (deferred) { // no status, no length: the next level decodes the stream from its start (same bytes, same slots)
-            const u32 slot = rdl(atomicAdd(a.work_counter + 5 + BRX_LEVEL, lane == 0u ? 1u : 0u), 0);
-            // (device-scope store: with BrxKernelArgs::overlap a level-1 wave on another XCD is waiting for this entry)
-            if (lane == 0u) __hip_atomic_store(&a.defer[(size_t)BRX_LEVEL * a.defer_cap + slot], sid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if BRX_LEVEL == 0
+        if (hand != 0u) { // no status, no length: a wider level finishes the stream (same bytes, same slots)
+            if (hand == 1u) {
+                const u32 slot = rdl(atomicAdd(a.work_counter + 4 + hand_level, lane == 0u ? 1u : 0u), 0);
+                if (lane == 0u) a.defer[(size_t)(hand_level - 1u) * a.defer_cap + slot] = sid;
+            } else if (lane == 0u) { // (everything decoded so far is in HBM: seg_finish above)
+                u32 *rec = a.handup + (size_t)late_at * HU_WORDS;
+                rec[HU_BITPOS] = (u32)hdr_bitpos; rec[HU_BITPOS + 1] = (u32)(hdr_bitpos >> 32);
+                rec[HU_POS] = s.st[10]; rec[HU_WINDOW] = s.st[13];
+                rec[HU_DIST] = s.st[14]; rec[HU_DIST + 1] = s.st[15]; rec[HU_DIST + 2] = s.st[16]; rec[HU_DIST + 3] = s.st[17];
+                rec[HU_WD] = s.st[29]; rec[HU_WD + 1] = s.st[30];
+                rec[HU_ISLAST] = s.st[ST_ISLAST]; rec[HU_MLEN] = s.st[ST_MLEN]; rec[HU_SID] = sid;
+                a.defer[3u * (size_t)a.defer_cap + late_at] = sid;
+                (void)atomicAdd(a.work_counter + 11, s.st[10]); // taken back by the resume: what stays was decoded twice
+            }
             if (lane == 0u && a.handed_seq != nullptr) *a.handed_seq = a.launch_seq; // (pinned host word: "this context meets such streams")
-#endif
             continue;
         }
 #endif
@@ -2301,6 +2356,12 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         if (lane == 0u) {
             a.status[sid] = (int)st;
             a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)needed : (u64)pos;
+        }
+        if (a.trace != nullptr && lane == 0u) {
+            a.trace[(size_t)sid * 4u] = t_begin;
+            a.trace[(size_t)sid * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+            a.trace[(size_t)sid * 4u + 2u] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)BRX_LEVEL << 32);
+            a.trace[(size_t)sid * 4u + 3u] = (unsigned long long)blockIdx.x | ((unsigned long long)gridDim.x << 32);
         }
     }
 }

@@ -124,16 +124,19 @@ enum {
                                      meta-blocks; 7 = the C++ loop alone, re-entered after every command */
     BRX_OPTION_LOOP_BUILD = 2,    /* -1 = by occupancy (default); 0 = bit window in VGPRs (full chip); 1 = in SGPRs (sparse launch) */
     BRX_OPTION_QUEUE_ORDER = 3,   /* 1 = longest compressed stream first on the host path (default); 0 = index order */
-    BRX_OPTION_HAND_UP = 4,       /* 1 = streams whose tables spill a kernel's LDS go to the next wider instance (default); 0 = they
-                                     stay, tables in an HBM slab */
-    BRX_OPTION_OVERLAP = 5,       /* level 1 next to the regular kernel: 0 = never, 1 = for contexts that handed a stream up lately
-                                     (default), 2 = always */
+    BRX_OPTION_HAND_UP = 4,       /* 1 = streams whose tables spill a kernel's LDS go to the wider instance that holds them (default);
+                                     0 = they stay, tables in an HBM slab */
+    BRX_OPTION_LEVELS = 5,        /* how the wider instances are launched: 0 = one catch-all launch behind the regular kernel, 2 = a
+                                     header-only classification pre-pass, then all four instances next to each other, each on
+                                     its own list; 1 (default) = the latter for contexts that listed a stream within their last
+                                     64 launches */
     BRX_OPTION_TINY_BYTES = 6,    /* compressed size up to which the regular kernel runs a stream in its C++ loop alone (128) */
     BRX_OPTION_HOST_IN_PLACE = 7, /* 1 = pinned host buffers are read / written by the kernel itself (default); 0 = staged copies */
     BRX_OPTION_GRID_CAP = 8,      /* 0 = none (default); else at most this many resident waves of the regular kernel */
     BRX_OPTION_SMALL_BYTES = 9,   /* compressed size up to which a stream goes to the lean instance first (default 128, at most
                                      500; 0 = no lean instance) */
-    BRX_OPTION_SMALL_WAVES = 10   /* waves per CU of the lean instance's grid (default 32) */
+    BRX_OPTION_SMALL_WAVES = 10,  /* waves per CU of the lean instance's grid (default 32) */
+    BRX_OPTION_TRACE = 11         /* 1 = every launch records when and where each stream was decoded (brx_last_trace); default 0 */
 };
 int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
 
@@ -159,13 +162,20 @@ const char *brx_last_error(void);
 
 /* Timing of the most recent brx_decode_batch call made with BRX_OPT_TIMING (milliseconds, HIP events on
  * the launch stream).  which: 0 = whole device section, 1 = decode kernels. Returns <0 if unavailable.
- * which = 2, 3, 4 (no BRX_OPT_TIMING needed; waits for the most recent launch): how many streams of that launch were
- * handed to the level-1, -2, -3 instance of the kernel.  Streams whose prefix-code tables do not fit the regular 6 912 B
- * of LDS table memory are handed over on the device to kernels with 9 472 / 17 152 / 37 632 B of it (12 / 8 / 4 instead
- * of 16 streams per CU), launched behind the regular one; which = 2 counts every stream that left the regular kernel.
- * which = 5: how many streams the lean instance (short streams, 32 per CU, launched in front of the regular kernel) left to the
- * regular kernel -- the ones above its size limit plus the short ones it gave up on (any error, block switches, large tables). */
+ * which = 2 .. 7 (no BRX_OPT_TIMING needed; waits for the most recent launch): counters of that launch.  Streams whose
+ * prefix-code tables do not fit the regular 6 912 B of LDS table memory are handed over on the device to the instance of the
+ * kernel that holds them -- 9 472 / 17 152 / 37 632 B of table memory, 12 / 8 / 4 instead of 16 streams per CU:
+ *   2, 3, 4  streams decoded at level >= 1, >= 2, 3 (2 = every stream that left the regular kernel)
+ *   5        streams the lean instance (short streams, 32 per CU, launched in front of the regular kernel) left to the regular
+ *            kernel -- the ones above its size limit plus the short ones it gave up on (any error, block switches, large tables)
+ *   6        streams that were handed up at a LATER meta-block, with their decoder state (resumed there, not restarted)
+ *   7        output bytes decoded twice because of hand-overs (0 = every such stream was resumed where it stood) */
 double brx_last_timing(brx_ctx *ctx, int which);
+
+/* Diagnostics (BRX_OPTION_TRACE = 1): 4 words per stream of the most recent launch -- start and end of its decode on the GPU's
+ * 100 MHz realtime counter, HW_ID register (XCC / SE / CU / SIMD / wave slot of the wave that decoded it) | kernel level << 32,
+ * workgroup index | grid size << 32.  Streams decoded by the lean instance have all-zero records.  Waits for that launch. */
+int brx_last_trace(brx_ctx *ctx, uint64_t *dst, uint32_t n);
 
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
 int brx_synchronize(brx_ctx *ctx, void *hip_stream);

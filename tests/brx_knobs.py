@@ -7,7 +7,7 @@ from brotli_rs_amd import brx
 
 # environment name -> (option, value or None = the variable's integer value)
 ENV = {"BRX_DEBUG_STOP": ("command_loop", None), "BRX_LOOP_BUILD": ("loop_build", None), "BRX_NO_ORDER": ("queue_order", 0),
-       "BRX_NO_DEFER": ("hand_up", 0), "BRX_NO_OVERLAP": ("overlap", 0), "BRX_FORCE_OVERLAP": ("overlap", 2),
+       "BRX_NO_DEFER": ("hand_up", 0), "BRX_PLAN_A": ("levels", 0), "BRX_PLAN_B": ("levels", 2),
        "BRX_TINY_BYTES": ("tiny_bytes", None), "BRX_NO_MIRROR": ("host_in_place", 0), "BRX_GRID_CAP": ("grid_cap", None),
        "BRX_SMALL_BYTES": ("small_bytes", None), "BRX_SMALL_WAVES": ("small_waves", None)}
 

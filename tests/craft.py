@@ -587,3 +587,63 @@ def odd_long_stream(seed, rounds, first=1 << 16, mib=4, tail=2, wbits=22):
         out += out[len(out) - (1 << 20):len(out) - (1 << 20) + tail]
         MetaBlock(cmds, mlen=total - first).emit(b, r == rounds - 1, 0)
     return b.bytes(), bytes(out)
+
+
+def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
+    """A stream of len(trees_per_mb) compressed meta-blocks; meta-block j has NTREESL = trees_per_mb[j] literal trees (two
+    symbols each, a 34-word table per tree in the HIP decoder's table memory) behind a context map over the 64 context ids,
+    so the table memory a meta-block needs is chosen per meta-block: a stream whose LATER meta-block outgrows the kernel
+    instance that started it (the regular one holds ~48 such trees, level 1 ~66, level 2 ~120).  Commands as in
+    context_mode_stream: 6 / 7 literals, then a copy of 2 from the last distance.  Returns (stream, expected_output) -- the
+    output from an independent model of the context rules."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    out = bytearray()
+    for j, nt in enumerate(trees_per_mb):
+        is_last = j == len(trees_per_mb) - 1
+        trees = [sorted(rng.sample(range(256), 2)) for _ in range(nt)]
+        cmap = [rng.randrange(nt) for _ in range(64)]
+        cmds = [6 + rng.randrange(2) for _ in range(n_cmds)]
+        mlen = sum(cmds) + 2 * (n_cmds - 1)
+        _mb_header(b, mlen, is_last)
+        b.put(0, 1); b.put(0, 1); b.put(0, 1)  # NBLTYPESL/I/D = 1
+        b.put(0, 2)            # NPOSTFIX
+        b.put(0, 4)            # NDIRECT
+        b.put(mode, 2)         # context mode of literal block type 0
+        _nbltypes(b, nt)       # NTREESL (the same variable-length code as NBLTYPES)
+        if nt >= 2:
+            b.put(0, 1)        # RLEMAX = 0
+            if nt <= 4:
+                simple_code(b, list(range(nt)), max(1, (nt - 1).bit_length()))
+                cm_codes = None
+            else:
+                cm_codes = complex_code(b, uniform_lengths(nt))
+            for c in cmap:
+                if cm_codes is None:
+                    b.put(*code_bits(list(range(nt)), c))
+                else:
+                    put_sym(b, cm_codes, c)
+            b.put(0, 1)        # no inverse move-to-front
+        else:
+            cmap = [0] * 64
+        b.put(0, 1)            # NTREESD = 1
+        for t in trees:
+            simple_code(b, t, 8)
+        iac = [176, 177]       # cell 2 (explicit distance): insert code 6, copy code 0 / 1
+        simple_code(b, iac, 10)
+        simple_code(b, [0], 6)  # distance code 0 only: zero-bit code (= the last distance; 4 at the start of the stream)
+        for k, ins in enumerate(cmds):
+            b.put(*code_bits(iac, 176))
+            b.put(ins - 6, 1)
+            for _ in range(ins):
+                p1 = out[-1] if len(out) >= 1 else 0
+                p2 = out[-2] if len(out) >= 2 else 0
+                t = trees[cmap[context_id(mode, p1, p2)]]
+                s = rng.choice(t)
+                b.put(*code_bits(t, s))
+                out.append(s)
+            if k != n_cmds - 1:
+                for _ in range(2):
+                    out.append(out[-4])
+    return b.bytes(), bytes(out)

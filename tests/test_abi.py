@@ -38,7 +38,7 @@ def test_shipped_library_reads_no_environment():
     path = brotli_rs_amd.build_library()
     blob = open(path, "rb").read()
     former = [b"BRX_DEBUG_STOP", b"BRX_DEBUG_STATS", b"BRX_DEBUG_DUMP", b"BRX_NO_ORDER", b"BRX_NO_DEFER", b"BRX_GRID_CAP", b"BRX_NO_OVERLAP",
-              b"BRX_FORCE_OVERLAP", b"BRX_TINY_BYTES", b"BRX_NO_MIRROR", b"BRX_LOOP_BUILD", b"BRX_SMALL_BYTES", b"BRX_SMALL_WAVES"]
+              b"BRX_FORCE_OVERLAP", b"BRX_PLAN_A", b"BRX_PLAN_B", b"BRX_TINY_BYTES", b"BRX_NO_MIRROR", b"BRX_LOOP_BUILD", b"BRX_SMALL_BYTES", b"BRX_SMALL_WAVES"]
     assert not [n for n in former if n in blob]
     nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
     assert nm.returncode == 0 and "getenv" not in nm.stdout

@@ -669,9 +669,9 @@ def test_level1_kernel_next_to_the_regular_one(ctx):
 
 
 def test_fresh_context_sends_spilling_streams_straight_to_level_3():
-    """A context that has not handed a stream up lately launches ONE wider kernel behind the regular one (level 3 reading
-    the regular kernel's list) instead of three; streams that spill after all are decoded there, bit-exact, and the next
-    launch of the context runs the full chain (level 2 takes mapsdatazrh again)."""
+    """A context that has not listed a stream lately launches ONE wider kernel behind the regular one (plan A: the catch-all
+    level-3 launch reads every list); streams that spill after all are decoded there, bit-exact, and the next launch of the
+    context classifies first and runs all levels next to each other (plan B)."""
     from brotli_rs_amd import brx
     c2 = brx_knobs.context(0)
     try:
@@ -683,21 +683,64 @@ def test_fresh_context_sends_spilling_streams_straight_to_level_3():
             bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if w[0] != st or (st == 0 and o != w[1])]
             assert not bad, (rep, bad[:8])
             assert c2.last_wide_streams() == 27
-            if "BRX_FORCE_OVERLAP" not in os.environ:  # (that switch also forces the full chain from the first launch)
-                assert c2.last_wide_streams(2) == (0 if rep == 0 else 9), (rep, c2.last_wide_streams(2))
+            assert c2.last_wide_streams(2) == 9, (rep, c2.last_wide_streams(2))  # (the level is known from the header: mapsdatazrh is level 2's)
+            assert c2.last_late_streams() == 0 and c2.last_redo_bytes() == 0
     finally:
         c2.close()
 
 
-def test_wide_kernels_strictly_behind_the_regular_one():
-    """BRX_NO_OVERLAP=1: the level-1 kernel on the caller's stream behind the regular one (how every launch ran before the
-    two overlapped) -- same parity subset, fresh process."""
+@pytest.mark.parametrize("plan", ["BRX_PLAN_A", "BRX_PLAN_B"])
+def test_both_launch_plans_on_every_launch(plan):
+    """BRX_PLAN_A=1: always the catch-all level-3 launch behind the regular kernel; BRX_PLAN_B=1: always the classification
+    pre-pass and all four levels next to each other -- same parity subset, fresh process each."""
     import subprocess
     import sys
-    env = dict(os.environ, BRX_NO_OVERLAP="1")
+    env = dict(os.environ, **{plan: "1"})
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "gpu_subset_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("levels", [0, 2])
+def test_later_meta_block_that_outgrows_its_level_is_resumed_not_restarted(levels):
+    """Streams whose THIRD (fourth ...) meta-block needs more table memory than the kernel instance that started them holds
+    (tests/craft.py growing_tables_stream: the number of literal trees is chosen per meta-block) are handed up at that meta-block's
+    header with their decoder state -- what the reference's Decompressor carries across a meta-block boundary, src/lib.rs:1572-1573
+    -- and resumed there: bit-exact, counted in the late list, and not one output byte decoded twice.  Both launch plans."""
+    import craft
+    c2 = brx_knobs.context(0, levels=levels)
+    try:
+        shapes = [[2, 2, 60, 2, 80], [1, 3, 5, 130, 2], [50, 2], [2] * 6, [50, 2, 80], [3, 70], [90, 1, 1, 60], [2, 2, 2, 49, 2, 140, 2]]
+        fx = [craft.growing_tables_stream(11 + i, sh, mode=i % 4, n_cmds=30 + 40 * (i % 3)) for i, sh in enumerate(shapes)]
+        alice = _read("alice29.txt.compressed")
+        streams, want, late_a, late_b = [], [], 0, 0
+        for rep in range(37):
+            for i, (st_, out_) in enumerate(fx):
+                streams.append(st_); want.append(out_)
+                # plan A: a first header that spills sends the stream to the catch-all (level 3 holds everything); one that spills
+                # later is a late entry.  plan B: the pre-pass gives the first header's level; every later outgrowing is late.
+                first = shapes[i][0]
+                need = lambda nt: 0 if nt <= 48 else 1 if nt <= 66 else 2 if nt <= 125 else 3
+                lvl, la, lb = need(first), 0, 0
+                for nt in shapes[i][1:]:
+                    if need(nt) > lvl:
+                        if lvl == 0:
+                            la = 1
+                        lb += 1 if lvl < 3 else 0
+                        lvl = 3  # (whoever takes a late entry is the catch-all: level 3)
+                late_a += la if need(first) == 0 else 0
+                late_b += lb
+            streams.append(alice); want.append(_read("alice29.txt"))
+        for o_, w_ in zip(fx, [oracle.decode(f[0]) for f in fx]):
+            assert w_[0] == 0 and w_[1] == o_[1]  # (the model of craft.py and the oracle agree)
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, [len(w) + 16 for w in want])
+            bad = [(i, int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if st != 0 or o != w]
+            assert not bad, bad[:8]
+            assert c2.last_redo_bytes() == 0, c2.last_redo_bytes()
+            assert c2.last_late_streams() == (late_a if levels == 0 else late_b), (c2.last_late_streams(), late_a, late_b)
+    finally:
+        c2.close()
 
 
 def test_farcopy_streams(ctx):
