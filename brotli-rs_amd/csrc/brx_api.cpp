@@ -241,7 +241,7 @@ static int ctx_init(brx_ctx *c, int device) {
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
     HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 64u));
-    HIP_TRY(hipHostMalloc((void **)&c->h_handed, 16 + 32 * BRX_COUNTER_RING, hipHostMallocMapped)); // (word 0: handed_seq; from word 4: 8 words per launch slot, plan B's counts)
+    HIP_TRY(hipHostMalloc((void **)&c->h_handed, 16 + 64 * BRX_COUNTER_RING, hipHostMallocMapped)); // (word 0: handed_seq; from word 4: 16 words per launch slot, plan B's counts)
     *c->h_handed = 0u;
     HIP_TRY(hipHostGetDevicePointer((void **)&c->d_handed, c->h_handed, 0));
     HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 64u));
@@ -493,6 +493,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.list_mask = 0u;
     a.counter_idx = 0u;
     a.late_only = 0u;
+    a.big_bytes = 0u;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
     uint32_t *regions = nullptr; // this launch's BRX_LIST_REGIONS regions of defer_cap words
     if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS) {
@@ -561,15 +562,15 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     //   A  the regular kernel classifies on its way (a stream whose first header spills is listed for the level that holds its
     //      tables), ONE catch-all level-3 launch behind it takes every list.  An empty launch costs ~5 us, and most batches
     //      never list anything.
-    //   B  a header-only pre-pass of the regular kernel classifies every stream of its queue first; then levels 3, 2, 1 (their
-    //      own HIP streams, forked behind the pre-pass) and the regular kernel run NEXT TO each other, each on its own complete
+    //   B  a header-only pre-pass of the regular kernel classifies every stream of its queue first; the host reads the counts
+    //      and launches exactly the kernels that have work, NEXT TO each other on their own HIP streams, each on its own complete
     //      list from its first wave on -- in a mixed batch the streams of the wider levels would otherwise wait for the longest
     //      stream of the regular kernel before they even start; the caller's stream joins them, and the catch-all takes the late
     //      list (streams that outgrew their level at a later meta-block: resumed there with their state).
-    // B costs the pre-pass (the first header of every stream is parsed twice), two more launches and the fork / join events
-    // (~30 us), so it is taken only by contexts that listed a stream within their last 64 launches: every kernel that lists one
-    // notes the launch in a pinned host word, read here without any API call.  No kernel ever waits for another one's list, and
-    // correctness does not depend on the plan.
+    // B costs the pre-pass (the first header of every stream is parsed twice: 0.3 .. 1 ms for a full grid, and the call waits
+    // for it) and the fork / join events, so it is taken only by contexts that listed a stream within their last 64 launches:
+    // every kernel that lists one notes the launch in a pinned host word, read here without any API call.  No kernel ever waits
+    // for another one's list, and correctness does not depend on the plan.
     a.launch_seq = (uint32_t)c->launch_seq; // (already advanced: >= 1)
     a.handed_seq = c->d_handed;
     const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
@@ -602,8 +603,8 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         // to real ones: a CU's LDS is handed out first-fit, and 10 KiB workgroups that come and go while 20 KiB ones are being
         // placed leave those at offsets between which nothing of their size fits any more (4096 x mapsdatazrh: 6 instead of 8
         // level-2 streams per CU for the whole launch, 89 ms instead of 60).
-        uint32_t *hc = c->h_handed + 4u + 8u * (uint32_t)ring_slot;
-        HIP_TRY(hipMemcpyAsync(hc, a.work_counter + 5, 24, hipMemcpyDeviceToHost, st));
+        uint32_t *hc = c->h_handed + 4u + 16u * (uint32_t)ring_slot;
+        HIP_TRY(hipMemcpyAsync(hc, a.work_counter + 5, 36, hipMemcpyDeviceToHost, st)); // words 5 .. 13
         HIP_TRY(hipEventRecord(c->ev_fork[ring_slot], st));
         HIP_TRY(hipEventSynchronize(c->ev_fork[ring_slot]));
         const uint32_t cnt[4] = {0u, std::min<uint32_t>(hc[0], n), std::min<uint32_t>(hc[1], n), std::min<uint32_t>(hc[2], n)};
@@ -612,22 +613,49 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         const uint32_t n0 = queued > wide ? queued - wide : 0u;
         a.cls = ap.cls;
         a.late_only = 1u;
-        // widest first (their streams tend to be the long jobs; big workgroups get contiguous LDS while the CUs are empty); the
-        // narrowest kernel with work stays on the caller's stream, the others get their own and are joined below
-        int narrowest = n0 ? 0 : cnt[1] ? 1 : cnt[2] ? 2 : 3;
+        // the regular kernel's queue, long jobs first without a sort: two walks split at the mean compressed size of its streams
+        a.big_bytes = hc[8] != 0u ? (uint32_t)std::min<uint64_t>(((uint64_t)hc[7] << 6) / hc[8], 0xffffffffull) : 0u;
+        // What is resident together.  A CU's 160 KiB of LDS is handed out in four parts of 40 KiB (one per SIMD; measured:
+        // profiles/r04_two_queues.txt, r04_residency.txt): 4 regular workgroups, 3 of level 1, 2 of level 2 or 1 of level 3 per
+        // part -- and a dispatch that has run out of room does not move on when room appears elsewhere, its pending workgroups
+        // wait for the CU they are due on.  So every kernel gets a PERSISTENT grid of workgroups that all find room at once (the
+        // rest of its list comes through its ticket counter), sized so that the classes take about the same number of rounds.
+        // One class only: its own kernel, alone.  Several: level 1 joins level 2 -- parts fill without a gap only with sizes
+        // 10 / 20 / 40 KiB (12.5 + 2 x 10 leaves 7.5 unused, and a part that holds three regular workgroups holds nothing else),
+        // widest first.
+        const uint32_t parts = c->max_grid / 4u;
+        uint32_t g[4] = {std::min<uint32_t>(n0, grid), std::min<uint32_t>(cnt[1], per_cu * 12u), std::min<uint32_t>(cnt[2], per_cu * 8u),
+                         std::min<uint32_t>(cnt[3], per_cu * 4u)};
+        uint32_t mask[4] = {0u, 1u, 2u, 4u};
+        const int classes = (n0 != 0u) + (cnt[1] != 0u) + (cnt[2] != 0u) + (cnt[3] != 0u);
+        if (classes > 1) {
+            const uint32_t m2 = cnt[1] + cnt[2];
+            const double demand = n0 / 4.0 + m2 / 2.0 + cnt[3];
+            const double sc = demand > (double)parts ? (double)parts / demand : 1.0;
+            auto share = [&](uint32_t cnt_, uint32_t per_part) -> uint32_t {
+                if (cnt_ == 0u) return 0u;
+                const uint32_t r = (uint32_t)(cnt_ * sc) / per_part * per_part; // whole parts
+                return std::max<uint32_t>(std::min(r, cnt_), std::min(cnt_, per_part));
+            };
+            g[0] = std::min<uint32_t>(share(n0, 4u), grid);
+            g[1] = 0u;
+            g[2] = share(m2, 2u);
+            g[3] = share(cnt[3], 1u);
+            mask[2] = 3u; // lists 0 and 1
+        }
+        const int narrowest = g[0] ? 0 : g[1] ? 1 : g[2] ? 2 : 3;
         for (int k = 3; k >= 1; k--) {
-            if (cnt[k] == 0u) continue;
+            if (g[k] == 0u) continue;
             BrxKernelArgs aw = a;
             aw.cls = nullptr;
-            aw.list_mask = 1u << (k - 1);
+            aw.list_mask = mask[k];
             aw.counter_idx = (uint32_t)k;
-            const unsigned gk = std::min(cnt[k], per_cu * (k == 1 ? 12u : k == 2 ? 8u : 4u));
             hipStream_t sw = k == narrowest ? st : c->s_wide[k - 1];
             if (sw != st) HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
-            if (k == 1) brx_launch_decode_l1(aw, gk, sw); else if (k == 2) brx_launch_decode_l2(aw, gk, sw); else brx_launch_decode_l3(aw, gk, sw);
+            if (k == 1) brx_launch_decode_l1(aw, g[k], sw); else if (k == 2) brx_launch_decode_l2(aw, g[k], sw); else brx_launch_decode_l3(aw, g[k], sw);
             if (sw != st) { HIP_TRY(hipEventRecord(c->ev_join[ring_slot][k - 1], sw)); joined[k - 1] = true; }
         }
-        if (n0 != 0u) brx_launch_decode(a, std::min<unsigned>(n0, grid), st);
+        if (g[0] != 0u) brx_launch_decode(a, g[0], st);
     } else {
         brx_launch_decode(a, grid, st);
     }

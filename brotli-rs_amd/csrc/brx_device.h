@@ -126,6 +126,9 @@ struct BrxKernelArgs {
     uint32_t prepass;       // regular kernel only: 1 = classify (first meta-block header) and write cls / lists 0..2, decode nothing
     uint32_t list_mask;     // wider kernels: the lists this launch decodes (bit j = list j)
     uint32_t counter_idx;   // the word of the counter line this launch takes its tickets from
+    uint32_t big_bytes;     // regular kernel, plan B: 0, or the mean compressed size of its streams -- the queue is then walked twice, first
+                            // for the streams of at least this size, then for the smaller ones (the long jobs start first, no sort);
+                            // the pre-pass leaves the sum (in units of 64 B) and the count in words 12 / 13 of the counter line
     uint32_t late_only;     // kernels below level 3: 1 = every hand-up goes to the late list (plan B: the class lists are being read)
     uint32_t tiny_bytes;    // compressed streams up to this size run their commands in the C++ loop alone (BRX_TINY_STREAM_BYTES)
     uint32_t sw_threshold;  // wider kernels: up to this many listed streams they run the sparse-launch build of the loop

@@ -1972,6 +1972,10 @@ __device__ __noinline__ void seg_finish() {
 // would run that meta-block in the C++ loop against tables in HBM (lcet10.txt: 8 x slower than its neighbours); with a.defer
 // set a kernel instead drops such a stream at the first spill and lists it for the next level, whose kernel -- launched
 // right behind on the same HIP stream, no host round trip -- decodes the listed streams from their start.
+// (Every instance is compiled for 4 waves per SIMD = at most 128 VGPRs, the wider ones too although their LDS allows fewer waves:
+// in a mixed batch the instances run next to each other on one CU, and a wave of a kernel compiled for 3 / 2 / 1 waves per SIMD
+// is given 136 / 176 / 264 registers -- accumulation registers the compiler reserves because it may -- so that a SIMD holds one
+// of them plus TWO regular waves instead of three: 12 waves per CU instead of 15, profiles/r04_two_queues.txt.)
 #if BRX_LEVEL == 0
 #define BRX_KERNEL_NAME brx_decode_kernel
 #define BRX_LAUNCH_NAME brx_launch_decode
@@ -1979,15 +1983,15 @@ __device__ __noinline__ void seg_finish() {
 #elif BRX_LEVEL == 1
 #define BRX_KERNEL_NAME brx_decode_kernel_l1
 #define BRX_LAUNCH_NAME brx_launch_decode_l1
-#define BRX_WAVES_PER_SIMD 3
+#define BRX_WAVES_PER_SIMD 4
 #elif BRX_LEVEL == 2
 #define BRX_KERNEL_NAME brx_decode_kernel_l2
 #define BRX_LAUNCH_NAME brx_launch_decode_l2
-#define BRX_WAVES_PER_SIMD 2
+#define BRX_WAVES_PER_SIMD 4
 #else
 #define BRX_KERNEL_NAME brx_decode_kernel_l3
 #define BRX_LAUNCH_NAME brx_launch_decode_l3
-#define BRX_WAVES_PER_SIMD 1
+#define BRX_WAVES_PER_SIMD 4
 #endif
 // ---- hand-up of a stream to a wider level (BrxKernelArgs::defer) -------------------------------------------------------
 // Table memory of the four levels in words (brx_device.h): the level a meta-block needing `need` words belongs to.
@@ -2051,6 +2055,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     bool first = true;
     for (;;) {
         u32 sid;
+        bool pass2 = false;
         if (first) {
             first = false;
             // (workgroup i runs on XCD i % 8: with slot = i a batch whose streams repeat with a period of 2, 4 or 8 -- every fourth
@@ -2059,12 +2064,22 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             sid = blockIdx.x;
             if ((sid | 63u) < gridDim.x) sid ^= (sid >> 3) & 7u;
         } else {
+#if BRX_LEVEL == 0
+            if (n_streams <= gridDim.x && a.big_bytes == 0u) break; // one stream per wave: nothing is queued
+#else
             if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
+#endif
             // Every lane executes the atomic (only lane 0 adds): a lane-0-only branch here sits right behind the
             // lane-0-only status store that ends the previous iteration, and LLVM threads lanes 1..63 around both
             // across the back edge -- they then spin in their own loop and never meet lane 0 again.
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
         }
+#if BRX_LEVEL == 0
+        if (a.big_bytes != 0u && sid >= n_streams) { // second walk over the queue: the smaller streams
+            sid -= n_streams;
+            pass2 = true;
+        }
+#endif
         if (sid >= n_streams) break;
 #if BRX_LEVEL > 0
         u32 late_slot = 0xffffffffu; // >= 0: resume from state record `late_slot`
@@ -2083,6 +2098,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #endif
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
+#if BRX_LEVEL == 0
+        if (a.big_bytes != 0u && ((i1 >= i0 ? i1 - i0 : 0ull) >= (u64)a.big_bytes) == pass2) continue; // the other walk's
+#endif
         {
             Dec d;
             d.lane = lane;
@@ -2213,6 +2231,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 if (slab != nullptr) scratch_release(a.pool, slab);
             }
             if (lane == 0u) a.cls[sid] = (u8)c;
+            if (c == 0u && lane == 0u) { // (the regular kernel's own streams: their mean size splits its queue, BrxKernelArgs::big_bytes)
+                const u64 len = i1 >= i0 ? i1 - i0 : 0ull;
+                (void)atomicAdd(a.work_counter + 12, (u32)(len >> 6 > 0xfffffull ? 0xfffffull : len >> 6));
+                (void)atomicAdd(a.work_counter + 13, 1u);
+            }
             if (c != 0u) {
                 const u32 slot = rdl(atomicAdd(a.work_counter + 4 + c, lane == 0u ? 1u : 0u), 0);
                 if (lane == 0u) a.defer[(size_t)(c - 1u) * a.defer_cap + slot] = sid;

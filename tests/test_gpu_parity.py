@@ -738,7 +738,10 @@ def test_later_meta_block_that_outgrows_its_level_is_resumed_not_restarted(level
             bad = [(i, int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if st != 0 or o != w]
             assert not bad, bad[:8]
             assert c2.last_redo_bytes() == 0, c2.last_redo_bytes()
-            assert c2.last_late_streams() == (late_a if levels == 0 else late_b), (c2.last_late_streams(), late_a, late_b)
+            # (plan B runs the level-1 class in the level-2 kernel when the batch mixes classes: a stream that only outgrows
+            # level 1 later is then never handed up -- between the streams that leave the regular kernel and the full count)
+            late = c2.last_late_streams()
+            assert late == late_a if levels == 0 else late_a <= late <= late_b, (late, late_a, late_b)
     finally:
         c2.close()
 
