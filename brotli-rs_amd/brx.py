@@ -80,6 +80,8 @@ def load_library():
     L.brx_stream_new.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.brx_stream_new_bounded.restype = ctypes.c_void_p
     L.brx_stream_new_bounded.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.brx_stream_new_reader.restype = ctypes.c_void_p
+    L.brx_stream_new_reader.argtypes = [ctypes.c_void_p, READ_FN, ctypes.c_void_p]
     L.brx_stream_read.restype = ctypes.c_int64
     L.brx_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     L.brx_stream_free.restype = None
@@ -92,10 +94,12 @@ def load_library():
     return L
 
 
+READ_FN = ctypes.CFUNCTYPE(ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_size_t)  # brx_read_fn
+
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
                     "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch",
-                    "brx_ctx_set_option", "brx_last_trace"]
+                    "brx_ctx_set_option", "brx_last_trace", "brx_stream_new_reader"]
 
 
 def status_str(code: int) -> str:
@@ -319,12 +323,16 @@ class Decompressor(io.RawIOBase):
     keeps its context alive; should the context be closed explicitly first, later reads raise BrxError.
     """
 
-    def __init__(self, reader, ctx: Context = None):
+    def __init__(self, reader, ctx: Context = None, streaming: bool = False):
+        """streaming=True: the inner reader is PULLED while the stream decodes (brx_stream_new_reader: compressed input and output
+        both in bounded sliding windows on the device, any stream length) instead of being drained on the first read."""
         super().__init__()
         self._reader = reader
         self._ctx = ctx
         self._stream = None
         self._lib = load_library()
+        self._streaming = streaming
+        self._cb = None
 
     def readable(self):
         return True
@@ -332,6 +340,24 @@ class Decompressor(io.RawIOBase):
     def prepare(self):
         """Drain the inner reader and queue the stream on its context WITHOUT decoding: the first read of any queued
         stream then decodes all of them in one batch (many live Decompressors cost about one batch)."""
+        if self._stream is None and self._streaming:
+            self._ctx = self._ctx or default_context()
+            reader = self._reader
+
+            def pull(_user, buf, cap):
+                try:
+                    data = reader.read(cap)
+                except Exception:  # an exception must not cross the C ABI: the stream ends here (UnexpectedEOF if it was not done)
+                    return 0
+                n = len(data) if data else 0
+                if n:
+                    ctypes.memmove(buf, bytes(data), n)
+                return n
+
+            self._cb = READ_FN(pull)  # (kept alive as long as the stream)
+            self._stream = self._lib.brx_stream_new_reader(self._ctx._h, self._cb, None)
+            if not self._stream:
+                raise BrxError("brx_stream_new_reader failed")
         if self._stream is None:
             data = self._reader.read() if hasattr(self._reader, "read") else bytes(self._reader)
             self._ctx = self._ctx or default_context()  # (held: the context must outlive the stream object)

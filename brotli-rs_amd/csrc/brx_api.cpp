@@ -1055,13 +1055,21 @@ struct brx_stream {
     bool decoded = false;
     int32_t status = 0;
     int lib_rc = BRX_SUCCESS;
-    // bounded mode (large streams): decoded slice by slice into a sliding device window, never more resident than
-    // BRX_BOUNDED_WINDOW + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK of output (+ the compressed input + one spill slab)
+    // bounded mode (large streams, and every stream over a reader): decoded slice by slice into a sliding device window of
+    // output, from a sliding device window of compressed input -- never more resident than BRX_BOUNDED_BUFSIZE of output +
+    // BRX_IN_WINDOW of input (+ two spill slabs and two state records) on the device, one staging chunk on the host
     bool bounded = false, finished = false;
-    uint8_t *d_in = nullptr, *d_buf = nullptr;
-    BrxResume *d_rec = nullptr;
+    brx_read_fn read_fn = nullptr; // the compressed input is PULLED (reference: BufReader over R, src/bitreader/mod.rs:21-53);
+    void *read_user = nullptr;     // nullptr = from `in` (brx_stream_new / brx_stream_new_bounded)
+    size_t mem_at = 0;             // ... how much of `in` has been pulled
+    bool src_eof = false;
+    uint8_t *d_inwin = nullptr, *d_buf = nullptr;
+    size_t in_fill = 0, in_cursor = 0; // bytes resident in d_inwin; the decoder's cursor in it (after the last good slice)
+    uint64_t in_slide_pending = 0;     // bytes the window has moved up since the record was last told
+    std::vector<uint8_t> stage;
+    BrxResume *d_rec = nullptr, *d_rec_bak = nullptr;
     BrxSlabPool *d_pool = nullptr;
-    uint32_t *d_bitmap = nullptr, *d_slab = nullptr;
+    uint32_t *d_bitmap = nullptr, *d_slab = nullptr, *d_slab_bak = nullptr; // (d_bitmap: 2 words, the second is the checkpoint's)
     uint64_t *d_meta = nullptr; // in_off[2] | out_off[2] | out_len[1] | status
     uint64_t shift = 0, pos = 0, delivered = 0;
 };
@@ -1071,41 +1079,82 @@ struct brx_stream {
 #define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
 #define BRX_BOUNDED_SLIDE_MIN (1u << 20)        // the window slides only once it is over by this much (see bounded_step)
 #define BRX_BOUNDED_BUFSIZE ((size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK)
+#define BRX_IN_WINDOW (8u << 20)      // compressed bytes resident on the device
+#define BRX_IN_KEEP 4096u             // ... of which this much below the cursor stays (the kernel stages 256-byte chunks behind it)
+#define BRX_IN_STAGE (1u << 20)       // host staging chunk of the pulls
 
 static void bounded_release(brx_stream *s) {
-    if (!s->d_buf && !s->d_in) return;
+    if (!s->d_buf && !s->d_inwin) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
-    (void)hipFree(s->d_in);
+    (void)hipFree(s->d_inwin);
     (void)hipFree(s->d_buf);
-    (void)hipFree(s->d_rec);
-    (void)hipFree(s->d_pool);
-    (void)hipFree(s->d_bitmap);
     (void)hipFree(s->d_slab);
-    (void)hipFree(s->d_meta);
-    s->d_in = s->d_buf = nullptr;
-    s->d_rec = nullptr;
+    (void)hipFree(s->d_rec); // (one allocation: both records, the pool descriptor, the bitmap, the offset / result words)
+    s->d_inwin = s->d_buf = nullptr;
+    s->d_rec = s->d_rec_bak = nullptr;
     s->d_pool = nullptr;
-    s->d_bitmap = s->d_slab = nullptr;
+    s->d_bitmap = s->d_slab = s->d_slab_bak = nullptr;
     s->d_meta = nullptr;
+    std::vector<uint8_t>().swap(s->stage);
 }
 
 static int bounded_init(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const size_t bufsize = BRX_BOUNDED_BUFSIZE;
-    HIP_TRY(hipMalloc(&s->d_in, s->in.size() + 16));
+    HIP_TRY(hipMalloc(&s->d_inwin, (size_t)BRX_IN_WINDOW + 16));
     HIP_TRY(hipMalloc(&s->d_buf, bufsize));
-    HIP_TRY(hipMalloc(&s->d_rec, sizeof(BrxResume)));
-    HIP_TRY(hipMalloc(&s->d_pool, sizeof(BrxSlabPool)));
-    HIP_TRY(hipMalloc(&s->d_bitmap, 4));
-    HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u));
-    HIP_TRY(hipMalloc(&s->d_meta, 64));
-    HIP_TRY(hipMemcpy(s->d_in, s->in.data(), s->in.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(s->d_rec, 0, 16));
+    HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 8u)); // the slab and its checkpoint
+    s->d_slab_bak = s->d_slab + BRX_SCRATCH_WORDS;
+    const size_t rec_bytes = (sizeof(BrxResume) + 255u) & ~(size_t)255;
+    uint8_t *small = nullptr;
+    HIP_TRY(hipMalloc(&small, 2 * rec_bytes + 1024));
+    s->d_rec = (BrxResume *)small;
+    s->d_rec_bak = (BrxResume *)(small + rec_bytes);
+    s->d_pool = (BrxSlabPool *)(small + 2 * rec_bytes);
+    s->d_bitmap = (uint32_t *)(small + 2 * rec_bytes + 256);
+    s->d_meta = (uint64_t *)(small + 2 * rec_bytes + 512);
+    HIP_TRY(hipMemset(s->d_rec, 0, 32));
     const uint32_t only_slab_0 = 0xfffffffeu; // a private pool of ONE slab that survives between the slices
     HIP_TRY(hipMemcpy(s->d_bitmap, &only_slab_0, 4, hipMemcpyHostToDevice));
     BrxSlabPool p = {s->d_bitmap, s->d_slab, 32};
     HIP_TRY(hipMemcpy(s->d_pool, &p, sizeof p, hipMemcpyHostToDevice));
+    s->stage.resize(BRX_IN_STAGE);
+    return BRX_SUCCESS;
+}
+
+// Pull compressed bytes: up to `cap` into buf, 0 = the source is exhausted.
+static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap) {
+    if (s->read_fn) return s->read_fn(s->read_user, buf, cap);
+    const size_t k = std::min(cap, s->in.size() - s->mem_at);
+    if (k) memcpy(buf, s->in.data() + s->mem_at, k);
+    s->mem_at += k;
+    return k;
+}
+
+// Move the input window up to the cursor (when that frees at least 1 MiB) and fill it from the source.
+static int bounded_refill(brx_stream *s) {
+    brx_ctx *c = s->ctx;
+    if (s->in_cursor >= BRX_IN_KEEP + (1u << 20)) {
+        const size_t delta = (s->in_cursor - BRX_IN_KEEP) & ~(size_t)15, keep = s->in_fill - delta;
+        for (size_t done = 0; done < keep; done += delta) { // forward, in pieces no longer than the move: no overlap
+            const size_t piece = std::min(delta, keep - done);
+            HIP_TRY(hipMemcpyAsync(s->d_inwin + done, s->d_inwin + delta + done, piece, hipMemcpyDeviceToDevice, c->stream));
+        }
+        s->in_fill -= delta;
+        s->in_cursor -= delta;
+        s->in_slide_pending += delta;
+    }
+    while (!s->src_eof && s->in_fill < BRX_IN_WINDOW) {
+        const size_t got = stream_pull(s, s->stage.data(), std::min<size_t>(s->stage.size(), BRX_IN_WINDOW - s->in_fill));
+        if (got == 0) {
+            s->src_eof = true;
+            break;
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_inwin + s->in_fill, s->stage.data(), got, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream)); // (the staging chunk is reused)
+        s->in_fill += got;
+    }
     return BRX_SUCCESS;
 }
 
@@ -1130,26 +1179,67 @@ static int bounded_step(brx_stream *s) {
         }
         s->shift = new_shift;
     }
+    // the input side: keep at least half a window of compressed bytes in front of the cursor while the source has any
+    if (!s->src_eof && s->in_fill - s->in_cursor < BRX_IN_WINDOW / 2u) {
+        int rc = bounded_refill(s);
+        if (rc) return rc;
+    }
     const uint64_t cap_abs = std::min<uint64_t>(s->shift + bufsize, BRX_STREAM_LIMIT);
     const uint64_t pause_at = s->pos + BRX_BOUNDED_CHUNK;
-    uint64_t meta[4] = {0, s->in.size(), 0, cap_abs};
-    HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), &pause_at, 8, hipMemcpyHostToDevice, c->stream));
     uint8_t *virt = (uint8_t *)((uintptr_t)s->d_buf - (uintptr_t)s->shift); // address of output byte 0, were it still resident
-    int rc = launch(c, c->stream, false, s->d_in, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
-                    (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
-    if (rc) return rc;
-    uint64_t res[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(res, s->d_meta + 4, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const int32_t st = (int32_t)(res[1] & 0xffffffffu);
-    if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // one command larger than the slack (caller falls back)
-    s->pos = res[0];
-    if (st != BRX_PAUSED) {
-        s->finished = true;
-        s->status = st;
+    for (int attempt = 0;; attempt++) {
+        // checkpoint: the record, the slab's claim bit and the slab as they are before the slice
+        HIP_TRY(hipMemcpyAsync(s->d_rec_bak, s->d_rec, sizeof(BrxResume), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_bitmap + 1, s->d_bitmap, 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_slab_bak, s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u, hipMemcpyDeviceToDevice, c->stream));
+        uint64_t meta[4] = {0, s->in_fill, 0, cap_abs};
+        HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
+        const uint64_t pz[2] = {pause_at, s->in_slide_pending};
+        HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), pz, 16, hipMemcpyHostToDevice, c->stream));
+        int rc = launch(c, c->stream, false, s->d_inwin, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
+                        (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
+        if (rc) return rc;
+        uint64_t res[2] = {0, 0}, cur = 0;
+        HIP_TRY(hipMemcpyAsync(res, s->d_meta + 4, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&cur, &s->d_rec->lds[BRX_RESUME_CURSOR_WORD], 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int32_t st = (int32_t)(res[1] & 0xffffffffu);
+        if (st == BRX_UNEXPECTED_EOF && !s->src_eof && attempt < 64) {
+            // The slice ran into the end of the RESIDENT input while the source has more (or is not known to be dry).  Put
+            // the decoder back to where it stood before the slice -- its record, its slab -- bring more input in, and run the
+            // slice again: the output it wrote is written once more.  (A slice that still fails with a full window in front of
+            // the cursor is a real UnexpectedEOF of the format -- or a single command of more than ~7 MiB of compressed bytes,
+            // which this reader does not take.)
+            HIP_TRY(hipMemcpyAsync(s->d_rec, s->d_rec_bak, sizeof(BrxResume), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_bitmap, s->d_bitmap + 1, 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_slab, s->d_slab_bak, (size_t)BRX_SCRATCH_WORDS * 4u, hipMemcpyDeviceToDevice, c->stream));
+            const size_t fill0 = s->in_fill;
+            const uint64_t slide0 = s->in_slide_pending;
+            if ((rc = bounded_refill(s))) return rc;
+            if (s->in_fill != fill0 || s->in_slide_pending != slide0) continue; // more is resident now
+            if (!s->src_eof) { // a full window in front of the cursor and still not enough
+                s->finished = true;
+                s->status = st;
+                return BRX_SUCCESS;
+            }
+            continue; // the source turned out to be dry: once more, and the UnexpectedEOF is real
+        }
+        s->in_slide_pending = 0;
+        if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // one command larger than the slack (caller falls back)
+        s->pos = res[0];
+        if (st != BRX_PAUSED) {
+            s->finished = true;
+            s->status = st;
+            if (st == BRX_OK && !s->src_eof) { // bytes behind the end of the stream (StreamEnd, src/lib.rs:2155-2167)?
+                uint8_t probe;
+                if (stream_pull(s, &probe, 1) != 0) s->status = BRX_EXPECTED_END_OF_STREAM;
+                else s->src_eof = true;
+            }
+        } else {
+            s->in_cursor = (size_t)(cur >> 3);
+        }
+        return BRX_SUCCESS;
     }
-    return BRX_SUCCESS;
 }
 
 static void stream_detach(brx_stream *s) {
@@ -1195,6 +1285,19 @@ static brx_stream *stream_new_impl(brx_ctx *ctx, const uint8_t *in, size_t n, bo
 extern "C" brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n) { return stream_new_impl(ctx, in, n, false); }
 
 extern "C" brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n) { return stream_new_impl(ctx, in, n, true); }
+
+extern "C" brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, void *user) {
+    if (!read) {
+        fail(BRX_ERR_INVALID_ARGUMENT, "brx_stream_new_reader: read is NULL");
+        return nullptr;
+    }
+    brx_stream *s = stream_new_impl(ctx, nullptr, 0, true);
+    if (s) {
+        s->read_fn = read;
+        s->read_user = user;
+    }
+    return s;
+}
 
 // Decode every pending stream of the context in one batch; streams whose guessed capacity was too small go into
 // the next round with the size the kernel asked for (at least x4), up to the 4 GiB - 256 B per-stream limit.
@@ -1279,6 +1382,12 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
                 if (rc) { bounded_release(s); s->lib_rc = rc; continue; }
             }
             int rc = bounded_step(s);
+            if (rc == BRX_ERR_OUT_OF_MEMORY && !s->finished && s->read_fn != nullptr) {
+                // (over a reader the compressed bytes behind the window are gone: no second way)
+                bounded_release(s);
+                s->lib_rc = fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: one command produces more than the bounded reader's slack (1 MiB); decode this stream from memory (brx_stream_new)");
+                continue;
+            }
             if (rc == BRX_ERR_OUT_OF_MEMORY && !s->finished) {
                 // a single command (a copy or an uncompressed meta-block) larger than the slack: decode the whole stream
                 // the unbounded way and go on serving from where this reader stands

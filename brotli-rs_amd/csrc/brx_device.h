@@ -84,12 +84,21 @@ struct BrxDeviceTables {
 // Resumable decode of ONE stream with bounded output memory (the Read facade for very large streams):
 // the kernel stops at the first command boundary at or beyond `pause_at`, flushes its ring, parks the whole wave state
 // (its LDS) here and reports BRX_PAUSED; the next launch picks up from it against a slid output window.
+// The compressed input is a sliding window too (the reference pulls its input through a BufReader as it decodes,
+// src/bitreader/mod.rs:21-53): in_off[sid] .. in_off[sid + 1] is what is resident NOW; when the host has moved the window up by
+// `in_slide` bytes (a multiple of 16) since the last slice, the parked cursor moves down with it.  A slice that runs into the end
+// of the resident input reports UnexpectedEOF like any truncated stream; the host, knowing that more input exists, puts the
+// record back to what it was before the slice and runs it again with more input resident (brx_api.cpp, bounded_step).
 struct BrxResume {
     uint32_t state;  // 0 = fresh stream, 1 = paused (lds valid), 2 = finished
     uint32_t phase;  // where to resume (kernel-internal)
     uint64_t pause_at;
+    uint64_t in_slide;
+    uint64_t spare;
     uint32_t lds[2560];
 };
+#define BRX_RESUME_CURSOR_WORD (2432u + 3u) // index into BrxResume::lds of the parked input cursor (Lds::st[3..4], bits from the
+                                            // window's first dword): 2048 B ring + 6912 B tables + 768 B scratch, st[] follows
 #define BRX_PAUSED 28 // per-stream status of a paused resumable decode (never leaves brx_api.cpp)
 
 struct BrxKernelArgs {

@@ -75,6 +75,9 @@ struct __attribute__((aligned(16))) Lds {
 #endif
 
 static_assert(sizeof(Lds) == BRX_LDS_BYTES, "Lds layout");
+#if BRX_LEVEL == 0 && !defined(BRX_SMALL)
+static_assert(__builtin_offsetof(Lds, st) / 4u + 3u == BRX_RESUME_CURSOR_WORD, "the host reads the parked input cursor at this word");
+#endif
 // One Lds per workgroup (= per wave).  File scope, so the out-of-line segments address it as LDS directly (a
 // generic Lds* parameter would turn every access into a flat_* instruction).
 __shared__ Lds g_lds;
@@ -2153,7 +2156,18 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     const u64 capacity = o1 >= o0 ? o1 - o0 : 0ull;
                     const u32 cap = capacity > 0xffffff00ull ? 0xffffff00u : (u32)capacity;
                     s.st[7] = (u32)op; s.st[8] = (u32)(op >> 32); s.st[9] = cap;
-                    const u64 wdl = 8ull * (i1 - i0) + (u64)cap + 65536ull;
+                    // ... and so may the input window have (BrxResume::in_slide): new base / end, the cursor relative to it; the
+                    // loop watchdog counts per slice (its limit follows from what is resident)
+                    const u8 *inp = a.in + i0;
+                    const u32 mis = (u32)((uintptr_t)inp & 3u);
+                    const u64 iw = (u64)(uintptr_t)(inp - mis), in_len = i1 >= i0 ? i1 - i0 : 0ull;
+                    s.st[0] = (u32)iw; s.st[1] = (u32)(iw >> 32); s.st[2] = (u32)((mis + in_len + 3u) >> 2);
+                    const u64 be = 8ull * (mis + in_len);
+                    s.st[5] = (u32)be; s.st[6] = (u32)(be >> 32);
+                    const u64 bp = ((u64)s.st[3] | ((u64)s.st[4] << 32)) - 8ull * rec->in_slide;
+                    s.st[3] = (u32)bp; s.st[4] = (u32)(bp >> 32);
+                    s.st[29] = 0u; s.st[30] = 0u;
+                    const u64 wdl = 8ull * in_len + (u64)cap + 65536ull;
                     s.st[31] = (u32)wdl; s.st[32] = (u32)(wdl >> 32);
                 }
                 phase = rfl(rec->phase);

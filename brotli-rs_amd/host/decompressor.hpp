@@ -14,7 +14,8 @@
 // Semantics of read(): n > 0 bytes, 0 at end of stream forever after; an invalid stream throws
 // brotli::InvalidData whose what() is the reference's description string (the reference returns
 // io::Error::new(ErrorKind::InvalidData, description), src/lib.rs:2177).  Two documented differences of the
-// whole-stream GPU backend: the inner reader is drained eagerly on the first read; for a stream that fails the bytes
+// GPU backend: the inner reader of a SHORT stream (compressed input < 4 MiB) is drained eagerly on the first read, a longer one is
+// pulled as it decodes; for a stream that fails the bytes
 // produced before the error are delivered first, then the error (the reference delivers an unspecified prefix too,
 // SURVEY.md Q13).
 #pragma once
@@ -59,24 +60,57 @@ inline brx_ctx *default_context() {
     return ctx;
 }
 
+// Decompressor<R>: small streams are drained and POOLED (the first read of any queued Decompressor decodes all of them in one
+// batch); a stream whose compressed input does not end within the first 4 MiB is decoded the way the reference does it -- the
+// inner reader is PULLED while the stream decodes (brx_stream_new_reader: src/bitreader/mod.rs:21-53), compressed input and
+// decoded output both in bounded sliding windows on the device, whatever the stream's length.
 template <class R> class Decompressor {
     R inner_;
     brx_stream *stream_ = nullptr;
+    std::vector<uint8_t> head_; // what was drained before the stream turned out to be a long one: replayed to the puller first
+    size_t head_at_ = 0;
+
+    static size_t pull(void *user, uint8_t *buf, size_t cap) { // brx_read_fn
+        Decompressor *d = static_cast<Decompressor *>(user);
+        try {
+            if (d->head_at_ < d->head_.size()) {
+                size_t k = d->head_.size() - d->head_at_ < cap ? d->head_.size() - d->head_at_ : cap;
+                for (size_t i = 0; i < k; i++) buf[i] = d->head_[d->head_at_ + i];
+                d->head_at_ += k;
+                if (d->head_at_ == d->head_.size()) std::vector<uint8_t>().swap(d->head_), d->head_at_ = 0;
+                return k;
+            }
+            return d->inner_.read(buf, cap);
+        } catch (...) {
+            return 0; // no exception crosses the C ABI: the input ends here
+        }
+    }
 
   public:
+    static constexpr size_t POOLED_LIMIT = 4u << 20;
     explicit Decompressor(R r) : inner_(std::move(r)) {} // infallible and reads nothing, like the reference's new()
     Decompressor(const Decompressor &) = delete;          // the reference derives Debug only, not Clone
     Decompressor &operator=(const Decompressor &) = delete;
     ~Decompressor() { brx_stream_free(stream_); }
 
-    // Drain the inner reader and queue the stream on the context without decoding: the first read() of ANY queued
-    // Decompressor then decodes all of them in one batch (brx.h, Read facade).
+    // Drain the inner reader (up to POOLED_LIMIT) and queue the stream on the context without decoding: the first read() of ANY
+    // queued Decompressor then decodes all of them in one batch (brx.h, Read facade).  A longer input becomes a pulled stream.
     void prepare() {
         if (stream_) return;
         std::vector<uint8_t> in;
         uint8_t tmp[65536];
-        for (size_t k; (k = inner_.read(tmp, sizeof tmp)) > 0;) in.insert(in.end(), tmp, tmp + k);
-        stream_ = brx_stream_new(default_context(), in.data(), in.size());
+        bool ended = false;
+        while (in.size() < POOLED_LIMIT) {
+            size_t k = inner_.read(tmp, sizeof tmp);
+            if (k == 0) { ended = true; break; }
+            in.insert(in.end(), tmp, tmp + k);
+        }
+        if (ended) {
+            stream_ = brx_stream_new(default_context(), in.data(), in.size());
+        } else {
+            head_.swap(in);
+            stream_ = brx_stream_new_reader(default_context(), &Decompressor::pull, this);
+        }
         if (!stream_) throw std::runtime_error("brx_stream_new failed");
     }
 

@@ -240,6 +240,15 @@ brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
  * decoded before the error.  A stream with a single command larger than the slack (a > 1 MiB copy or uncompressed
  * meta-block) falls back to whole-stream decoding. */
 brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
+/* The bounded reader over a SOURCE instead of a buffer: the reference's Decompressor::new(r: R) with R: Read
+ * (src/lib.rs:398-410), which pulls its input through a BufReader as it decodes (src/bitreader/mod.rs:21-53).  `read` is called
+ * -- from inside brx_stream_read, on the caller's thread -- for up to `cap` more compressed bytes; it returns how many it gave,
+ * 0 = end of input (and is not called again).  Compressed input is held in a sliding 8 MiB device window the same way the
+ * output is: a stream of any length decodes with about 35 MiB of buffers on the device and 1 MiB on the host.  A slice that runs
+ * out of resident input is rolled back and run again with more; limits: one command may not produce more than the reader's
+ * slack (1 MiB; such a stream needs brx_stream_new) nor consume more than ~7 MiB of compressed bytes. */
+typedef size_t (*brx_read_fn)(void *user, uint8_t *buf, size_t cap);
+brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, void *user);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);
 void brx_stream_free(brx_stream *s);
 

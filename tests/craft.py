@@ -647,3 +647,35 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
                 for _ in range(2):
                     out.append(out[-4])
     return b.bytes(), bytes(out)
+
+
+def periodic_stream_parts(seed, commands=700, literals=90):
+    """A stream of ANY length in constant memory: (prefix, unit, final, unit_output).  stream = prefix + unit * K + final decodes
+    to unit_output * K.  The prefix is the stream header and an empty metadata block (which pads to a byte boundary); a unit is
+    one compressed meta-block -- `commands` x (`literals` random bytes at 8 bits each, then a copy of 4 from inside the unit,
+    explicit distance codes only) -- and again an empty metadata block, so every unit starts and ends on a byte boundary and
+    decodes the same whatever came before it; final = ISLAST + ISLASTEMPTY.  Literal-heavy on purpose: about one compressed byte
+    per output byte, so a long stream moves the reader's INPUT window as much as its output window."""
+    rng = random.Random(seed)
+
+    def empty_metadata(b):
+        b.put(0, 1); b.put(3, 2); b.put(0, 1); b.put(0, 2)  # ISLAST = 0, MNIBBLES code 3, reserved, MSKIPBYTES = 0
+        b.put(0, (-b.n) % 8)
+
+    b = Bits()
+    stream_header(b, 22)
+    empty_metadata(b)
+    prefix = b.bytes()
+    cmds, out = [], bytearray()
+    for k in range(commands):
+        lits = rng.randbytes(literals)
+        out += lits
+        d = rng.randrange(4, min(len(out), 3000) + 1)
+        cmds.append((lits, 4, d))
+        for _ in range(4):
+            out.append(out[-d])
+    b = Bits()
+    MetaBlock(cmds, mlen=len(out)).emit(b, False, len(out))
+    empty_metadata(b)
+    assert b.n % 8 == 0
+    return prefix, b.bytes(), b"\x03", bytes(out)

@@ -212,6 +212,70 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def _build_cpp(tmp_path, name):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / name)
+    lib = os.path.join(root, "brotli-rs_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "cpp", name + ".cpp"),
+                           "-o", exe, "-L", lib, "-lbrx", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_pulled_reader_holds_a_window_of_input_and_of_output(ctx, tmp_path):
+    """brotli::Decompressor<R> over a reader that is PULLED while the stream decodes (brx_stream_new_reader; the reference's
+    BufReader, src/bitreader/mod.rs:21-53): a 160 MiB stream with about as many compressed bytes, made in constant memory
+    (tests/craft.py periodic_stream_parts), decodes bit-exact with well under 64 MiB resident on the device and on the host --
+    both the input and the output window slide several times.  The same input cut short: everything decoded before the end is
+    served, then UnexpectedEOF."""
+    import craft
+    import subprocess
+    exe = _build_cpp(tmp_path, "stream_reader_test")
+    parts = craft.periodic_stream_parts(5)
+    names = []
+    for tag, data in zip(("prefix", "unit", "final", "unit_out"), parts):
+        f = tmp_path / (tag + ".bin")
+        f.write_bytes(data)
+        names.append(str(f))
+    assert oracle.decode(parts[0] + parts[1] * 3 + parts[2])[1] == parts[3] * 3
+    K = 2550  # 160 MiB
+    out = subprocess.run([exe] + names + [str(K)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    assert int(f[2]) == K * len(parts[3]), out.stdout
+    assert float(f[4]) < 64.0 and float(f[6]) - float(f[10]) < 16.0, out.stdout  # device peak; host growth over the stream
+    out = subprocess.run([exe] + names + [str(K), str(50 * len(parts[1]) + 777)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK error after" in out.stdout, out.stdout + out.stderr
+    assert int(out.stdout.split()[3]) >= 49 * len(parts[3])  # (the prefix: at least every whole unit before the cut, bar the last)
+
+
+def test_python_decompressor_streaming_mode(ctx):
+    """brx.Decompressor(reader, streaming=True): pulled input; trailing bytes behind the stream's end are the reference's
+    ExpectedEndOfStream even when they only arrive after the decoder has finished with what was resident."""
+    import craft
+    import io
+    from brotli_rs_amd import brx
+    p_, u_, f_, o_ = craft.periodic_stream_parts(9, commands=300, literals=40)
+    data = p_ + u_ * 40 + f_
+    d = brx.Decompressor(io.BytesIO(data), ctx, streaming=True)
+    assert d.read() == o_ * 40
+    d.close()
+    d = brx.Decompressor(io.BytesIO(data + b"tail"), ctx, streaming=True)
+    got = bytearray()
+    with pytest.raises(ValueError) as e:
+        while True:
+            chunk = d.read(1 << 16)
+            if not chunk:
+                break
+            got += chunk
+    assert brx.status_str(2) in str(e.value) and bytes(got) == o_ * 40
+    d.close()
+    for name in ("alice29.txt", "lcet10.txt", "mapsdatazrh"):
+        d = brx.Decompressor(io.BytesIO(_read(name + ".compressed")), ctx, streaming=True)
+        assert d.read() == _read(name)
+        d.close()
+
+
 def test_stream_generator_round_trip(ctx):
     """brx_generate_batch (csrc/brx_gen.hip): streams made on the GPU -- text, random bytes, fills, far repeats, empty and
     1-byte inputs, inputs around the meta-block size -- decode back to their inputs with the CPU oracle (both lookup modes
@@ -929,7 +993,7 @@ def test_pinned_buffers_are_used_in_place(ctx):
 def test_bounded_memory_stream_of_70_MiB(ctx):
     """The Read facade in bounded mode: a 70 MiB stream (4.4 MiB compressed: chosen automatically,
     inputs >= 4 MiB) decoded slice by slice by the resumable kernel into a ~21 MiB sliding device window; the reader sees
-    the bytes as the slices complete.  Device memory in use must stay under 32 MiB above the baseline.  Also a small
+    the bytes as the slices complete.  Device memory in use must stay under 40 MiB above the baseline (22 MiB of output window, 8 MiB of input window, the slab and its checkpoint -- whatever the stream's length, on both sides).  Also a small
     stream forced into bounded mode, and a corrupted long stream: everything decoded before the error is served, then
     the oracle's error."""
     import craft
@@ -962,7 +1026,7 @@ def test_bounded_memory_stream_of_70_MiB(ctx):
     assert total == len(exp) and got_hash.hexdigest() == want_hash
     assert L.brx_stream_read(h, buf, len(buf)) == 0
     L.brx_stream_free(h)
-    assert free0 - min_free < (32 << 20), (free0 - min_free) >> 20
+    assert free0 - min_free < (40 << 20), (free0 - min_free) >> 20
     # small stream, bounded on request; odd read sizes
     comp2, exp2 = _read("alice29.txt.compressed"), _read("alice29.txt")
     h = L.brx_stream_new_bounded(ctx._h, comp2, len(comp2))
