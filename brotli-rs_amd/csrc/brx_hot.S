@@ -16,7 +16,8 @@
 //   * the symbol entries of the prefix-code tables carry what the loop needs next (prepare_fast_tables() in
 //     brx_kernels.hip): literal = byte | context info, insert&copy = offset of the symbol's record (one s_load_dwordx2:
 //     both bases, both extra-bit counts, implicit-distance flag), distance = extra-bit count | base (or a ring code);
-//   * limit and base of a code length sit side by side (one ds_read_b64 per lookup);
+//   * limit and base of a code length share one word (one ds_read_b32 per lane loads a tree; SPLIT_TREE makes the pair the
+//     lookups work on);
 //   * the literal context id is two masks of the previous entries' info bytes; a one-tree meta-block keeps its literal
 //     tree in registers and skips contexts altogether;
 //   * the common path of a command falls through; everything unusual is out of line.
@@ -50,7 +51,8 @@
 #define LDS_ITAB (8960+LDS_GROW)   // byte -> context info (filled by prepare_fast_tables)
 #define LDS_SPARE (9216+LDS_GROW)  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
 #define LDS_CMH (9472+LDS_GROW)    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
-#define SYMOFF 128      // symbol list of a tree: after its 32 header words
+#define SYMOFF 68       // symbol list of a tree: after its 17 header words (brx_kernels.hip, "Table layout in table memory")
+#define INFOOFF 64      // the header's info word: kind | max_len << 8 | x << 16
 // EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup + lane 16, which carries the symbol-list
 // address of a resident tree).  Everything uniform needs one lane; copies, flushes and input staging set their own mask.
 // Fewer switching lanes = less power = a higher clock on the loaded chip (DVFS, MI355X_MICROARCH.md).
@@ -138,7 +140,7 @@
 // ---- VGPRs (v40-v47 are callee-saved in the AMDGPU calling convention: using them would make the wrapper spill them)
 #define VZERO v0
 #define VLANE v1
-#define VLANE8 v2
+#define VLANE4 v2
 #define VLANE16 v3
 #define VCHA v4
 #define VCHB v5
@@ -338,6 +340,12 @@
     v_add_u32 \tmp, -1, VSH
     v_lshrrev_b32 \reg, \tmp, \reg
 .endm
+// A tree's header words as loaded (lane L: limit[L] << 16 | base[L] & 0xffff, lane 0: 0) -> the pair the lookups work on:
+// \lim = limit[L] << 16, \base = base[L] sign-extended.
+.macro SPLIT_TREE lim, base
+    v_bfe_i32 \base, \lim, 0, 16
+    v_and_b32 \lim, 0xffff0000, \lim
+.endm
 // Canonical prefix-code lookup (table layout: brx_kernels.hip, "Table layout in table memory").
 // lim = per-lane limit[L] << 16 (lane 0: 0), base = per-lane base[L] of the tree (lane L, L = 1..15; lanes >= 16 repeat).
 // Out: CLEN = code length (SGPR), VI = index into the tree's sorted symbol list (VGPR).  Clobbers T2, T3, VR, VU, vcc.
@@ -463,8 +471,8 @@
     v_mov_b32 VZERO, 0
     v_mbcnt_lo_u32_b32 VLANE, -1, 0
     v_mbcnt_hi_u32_b32 VLANE, -1, VLANE
-    v_and_b32 VLANE8, 15, VLANE
-    v_lshlrev_b32 VLANE8, 3, VLANE8
+    v_and_b32 VLANE4, 15, VLANE
+    v_lshlrev_b32 VLANE4, 2, VLANE4                     // 4 * (lane & 15): lane L reads header word L of a tree
     v_lshlrev_b32 VLANE16, 4, VLANE
     v_and_b32 VSH, 15, VLANE
     v_sub_u32 VSH, 32, VSH                              // LOOKUP2: lane L shifts the reversed window by 32 - L
@@ -599,8 +607,8 @@
     s_waitcnt lgkmcnt(0)
     v_lshlrev_b32 VLHOFF, 2, VLHOFF
     v_lshlrev_b32 VDHOFF, 2, VDHOFF
-    ds_read_b32 VT0, VLHOFF offset:LDS_TM+4             // header word 1: kind | max_len << 8 | x << 16
-    ds_read_b32 VT1, VDHOFF offset:LDS_TM+4
+    ds_read_b32 VT0, VLHOFF offset:LDS_TM+INFOOFF       // the header's info word: kind | max_len << 8 | x << 16
+    ds_read_b32 VT1, VDHOFF offset:LDS_TM+INFOOFF
     v_add_u32 VLHOFF, LDS_TM, VLHOFF
     v_add_u32 VDHOFF, LDS_TM, VDHOFF
     s_waitcnt lgkmcnt(0)
@@ -653,8 +661,8 @@
     s_lshl_b32 T7, T7, 2
     s_add_u32 T7, T7, LDS_TM
     s_add_u32 HISYM, T7, SYMOFF
-    v_add_u32 VT0, T7, VLANE8
-    ds_read_b64 VIAC, VT0                               // limits and bases of the insert&copy tree
+    v_add_u32 VT0, T7, VLANE4
+    ds_read_b32 VIACL, VT0                              // header words of the insert&copy tree (split below, SPLIT_TREE)
     // context masks of the mode (context_info() in brx_kernels.hip): id * 4 = (info(p1) & MA) | ((info(p2) & MB) << SB)
     s_mov_b32 MA, 0xfc
     s_mov_b32 MB, 0
@@ -708,10 +716,11 @@
     v_readlane_b32 T7, VLHOFF, T6                       // descriptor of tree T6
     s_cmp_lt_i32 T7, 0
     s_cbranch_scc1 .Lent_r_single
-    v_add_u32 VT0, T7, VLANE8
-    ds_read_b64 VLB, VT0
+    v_add_u32 VT0, T7, VLANE4
+    ds_read_b32 VLIM, VT0
     s_add_u32 T7, T7, SYMOFF
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VLIM, VBASE
     v_lshl_add_u32 VBASE, VBASE, 1, T7                  // folded bases (LOOKUP2F)
     TO_COUNTS VLIM, VT1
     s_branch .Lent_r_store
@@ -746,8 +755,8 @@
     s_cbranch_scc1 .Lent_multi
     s_bitset1_b32 FLAGS, 3
     s_add_u32 LITSYM, T6, SYMOFF
-    v_add_u32 VT0, T6, VLANE8
-    ds_read_b64 VLIT, VT0
+    v_add_u32 VT0, T6, VLANE4
+    ds_read_b32 VLITL, VT0
 .Lent_multi:
     // bit window
     s_waitcnt vmcnt(0)
@@ -795,6 +804,8 @@
     s_and_b32 T0, VFL, 1023
     s_cmp_lg_u32 T0, 0
     s_cbranch_scc1 .Lexit
+    SPLIT_TREE VIACL, VIACB
+    SPLIT_TREE VLITL, VLITB
     v_lshl_add_u32 VIACB, VIACB, 1, HISYM               // folded bases of the resident trees (LOOKUP2F)
     v_lshl_add_u32 VLITB, VLITB, 1, LITSYM
     TO_COUNTS VIACL, VT3
@@ -879,8 +890,8 @@
 #ifndef BRX_DIST_RESIDENT
     v_readlane_b32 DTREE, VDH4, DCTX
     s_nop 1
-    v_add_u32 VT0, DTREE, VLANE8                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
-    ds_read_b64 VDH, VT0
+    v_add_u32 VT0, DTREE, VLANE4                        // (a one-symbol tree has no header: an out-of-range read, returns 0)
+    ds_read_b32 VDHV, VT0
 #endif
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc1 .Lhave_lits                          // one command in three has literals
@@ -905,6 +916,7 @@
 #else
 .Ldist_ticked:                                          // (back from a distance block switch)
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VDHV, VDHB
     LOOKUP2 VDHV, VDHB, DTREE, 2, ds_read_b32, SYMOFF, 5
 #endif
     s_waitcnt lgkmcnt(0)
@@ -1142,9 +1154,10 @@
     s_waitcnt lgkmcnt(0)                                // VH = tree descriptor of this literal's context
     v_cmp_gt_i32 vcc, 0, VH
     s_cbranch_vccnz .Llit_single\sfx
-    v_add_u32 VT0, VH, VLANE8
-    ds_read_b64 VLB, VT0
+    v_add_u32 VT0, VH, VLANE4
+    ds_read_b32 VLIM, VT0
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VLIM, VBASE
     LOOKUP2 VLIM, VBASE, VH, 1, ds_read_u16, SYMOFF, \rid
     s_waitcnt lgkmcnt(0)
     v_readlane_b32 T0, VS, CLEN                         // byte | context info << 8
@@ -1884,14 +1897,20 @@
     s_lshl_b32 s37, s37, 2
     s_add_u32 s36, s36, LDS_TM                          // header of the block type code
     s_add_u32 s37, s37, LDS_TM                          // header of the block count code
-    v_add_u32 VT1, s36, VLANE8
-    v_add_u32 VT2, s37, VLANE8
-    ds_read_b64 VLB, VT1                                // limits / bases of the type code (lane 0: 0, the info word)
-    ds_read_b64 v[14:15], VT2                           // ... of the count code
+    v_add_u32 VT1, s36, VLANE4
+    v_add_u32 VT2, s37, VLANE4
+    ds_read_b32 VLIM, VT1                               // header words of the type code
+    ds_read_b32 v14, VT2                                // ... of the count code
+    v_mov_b32 VT1, s36
+    v_mov_b32 VT2, s37
+    ds_read_b32 VT1, VT1 offset:INFOOFF                 // ... and their info words
+    ds_read_b32 VT2, VT2 offset:INFOOFF
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VLIM, VBASE
+    SPLIT_TREE v14, v15
     // both must be complete general codes: kind 2 in the info word, limit[15] = 2^15 (left-aligned: 0x80000000)
-    v_readlane_b32 T2, VBASE, 0
-    v_readlane_b32 T3, v15, 0
+    v_readfirstlane_b32 T2, VT1
+    v_readfirstlane_b32 T3, VT2
     s_and_b32 T2, T2, 3
     s_and_b32 T3, T3, 3
     s_cmp_lg_u32 T2, 2
@@ -1979,9 +1998,10 @@
     s_lshl_b32 T2, T2, 2
     s_add_u32 T2, T2, LDS_TM
     s_add_u32 T3, T2, SYMOFF
-    v_add_u32 VT0, T2, VLANE8
-    ds_read_b64 VIAC, VT0
+    v_add_u32 VT0, T2, VLANE4
+    ds_read_b32 VIACL, VT0
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VIACL, VIACB
     v_lshl_add_u32 VIACB, VIACB, 1, T3                  // folded bases (LOOKUP2F)
     TO_COUNTS VIACL, VT1
     s_branch .Lcmd_ticked
@@ -2083,8 +2103,8 @@
 #else
     v_readlane_b32 DTREE, VDH4, DCTX
     s_nop 1
-    v_add_u32 VT0, DTREE, VLANE8
-    ds_read_b64 VDH, VT0
+    v_add_u32 VT0, DTREE, VLANE4
+    ds_read_b32 VDHV, VT0
 #endif
     s_cmp_lt_i32 DTREE, 0
     s_cbranch_scc0 .Ldist_ticked
@@ -2104,10 +2124,11 @@
     v_readlane_b32 T2, VDH4, T3
     s_cmp_lt_i32 T2, 0
     s_cbranch_scc1 .Lld_single
-    v_add_u32 VT0, T2, VLANE8
-    ds_read_b64 VLB, VT0
+    v_add_u32 VT0, T2, VLANE4
+    ds_read_b32 VLIM, VT0
     s_add_u32 T2, T2, SYMOFF
     s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VLIM, VBASE
     v_lshl_add_u32 VBASE, VBASE, 2, T2
     TO_COUNTS VLIM, VT0
     s_set_gpr_idx_on T3, 8                              // VGPR index mode, destination + T3

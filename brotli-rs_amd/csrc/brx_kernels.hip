@@ -432,14 +432,18 @@ FI void dec_store_in(const Dec &d, Lds &s) {
 #endif // !BRX_SMALL
 
 // ---- prefix codes ----------------------------------------------------------------------------------------
-// Table layout in table memory (word address h): BRX_HDR_WORDS = 32 header words, then the symbols in (length, symbol)
+// Table layout in table memory (word address h): BRX_HDR_WORDS = 17 header words, then the symbols in (length, symbol)
 // order -- as u16 (literal, insert&copy, block-type / block-count / context-map codes) or as u32 (distance codes, WIDE).
-//   header[2L], L = 1..15   : limit[L] << 16, limit[L] = (first_code[L] + count[L]) << (15-L) -- the exclusive upper bound
-//                             of the length-L codes as a left-aligned 31-bit value; header[0] = 0 (never matches)
-//   header[2L + 1], L = 1..15: base[L] = offset[L] - first_code[L] (two's complement): code value + base = symbol index
-//   header[1]               : kind | max_len << 8 | x << 16  (kind 0 empty, 1 one symbol x, 2 general with x symbols)
-// (limit and base of one length sit side by side: the assembly loop fetches both with one ds_read_b64 per lane.)
-// One v_cmp of (bit-reversed window >> 1) against the limits gives the code length (lowest matching lane).
+//   header[L], L = 1..15 : limit[L] << 16 | (base[L] & 0xffff)
+//                          limit[L] = (first_code[L] + count[L]) << (15-L) -- the exclusive upper bound of the length-L codes as
+//                          a left-aligned 15-bit value (2^15 = the complete code's last bound);
+//                          base[L] = offset[L] - first_code[L] (two's complement, it fits 16 bits): code value + base = symbol index
+//   header[0]            : 0 (never matches)
+//   header[16]           : kind | max_len << 8 | x << 16  (kind 0 empty, 1 one symbol x, 2 general with x symbols)
+// (Round 4: limit and base share a word -- 17 header words instead of 32 per tree, which is what keeps the tables of real text
+// at quality 10 / 11 inside the regular kernel's table memory: lcet10.txt 2 208 -> 1 7xx words.  The compare takes the word as it
+// is against (window << 16 | 0xffff); the assembly loop splits a tree's words once when it loads them.)
+// One v_cmp of the bit-reversed window against the limits gives the code length (lowest matching lane).
 // Lookup = reference Tree::lookup_symbol (src/huffman/tree/mod.rs:63-93): zero bits for a single-symbol
 // code (Q5); an unassigned codeword of an incomplete code reads max_len+1 bits and yields None (Q15).
 //
@@ -450,11 +454,12 @@ FI void dec_store_in(const Dec &d, Lds &s) {
 //   insert&copy trees  sym << 4 = byte offset of the symbol's record in BrxDeviceTables::iac
 //   distance trees     0x80000000 | code for the 16 last-distance codes, else nbits | base << 5 with
 //                      distance = base + (extra << NPOSTFIX)  (decode_distance, src/lib.rs:1412-1481)
-#define BRX_HDR_WORDS 32u
+#define BRX_HDR_WORDS 17u
+#define BRX_HDR_INFO 16u // word of the header that holds kind | max_len << 8 | x << 16
 #define BRX_DIST_UNFIT 0xc0000000u
 template <bool INL, bool WIDE> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h, u32 &sym) {
-    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 31u)); // even lanes 2L: limits, odd lanes 2L+1: bases, lane 1: info word
-    u32 h0 = rdl(hv, 1);
+    u32 hv = tm_ld32<INL>(d, s, h + (d.lane & 31u)); // lanes 1..15: limit << 16 | base, lane 16: the info word
+    u32 h0 = rdl(hv, BRX_HDR_INFO);
     u32 kind = h0 & 3u;
     if (kind == 0u) return LK_NONE;
     if (kind == 1u) {
@@ -465,14 +470,14 @@ template <bool INL, bool WIDE> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h,
     u32 peek = in_peek_raw(d) & 0x7fffu;
     if (rem < 15u) peek &= (1u << (u32)rem) - 1u;
     u32 v = __brev(peek) >> 17; // first stream bit = MSB of a 15-bit left-aligned code
-    u64 m = ballot((v << 16) < hv) & 0x55555554ull; // lanes 2, 4 .. 30 carry limit[1..15] << 16
+    u64 m = ballot(((v << 16) | 0xffffu) < hv) & 0xfffeull; // lanes 1 .. 15
     if (m == 0ull) {
         u32 maxlen = (h0 >> 8) & 0xffu;
         return rem >= (u64)(maxlen + 1u) ? LK_NONE : LK_EOF;
     }
-    u32 L = (u32)__builtin_ctzll(m) >> 1;
+    u32 L = (u32)__builtin_ctzll(m);
     if ((u64)L > rem) return LK_EOF;
-    u32 base = rdl(hv, 2u * L + 1u);
+    u32 base = rdl(hv, L); // (its low half; the sum is taken modulo 2^16)
     u32 idx = ((v >> (15u - L)) + base) & 0xffffu;
     sym = WIDE ? rfl(tm_ld32<INL>(d, s, h + BRX_HDR_WORDS + idx)) : rfl(tm_ld16<INL>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
     in_consume(d, L);
@@ -547,7 +552,7 @@ FI u32 row_scan_add(u32 x) {
 // lanes below this one whose bit is set in the wave mask m
 FI u32 lanes_below(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 
-// The 32 header words of a general code from its length histogram: lane L (1..15) passes the number of length-L codes in
+// The header words of a general code from its length histogram: lane L (1..15) passes the number of length-L codes in
 // `cnt` (other lanes: anything).  Canonical assignment, reference src/huffman/mod.rs:19-43 (the bl_count[0] quirk Q7
 // vanishes under the reference's own masking of the code to `len` bits), as two prefix sums over the lanes:
 //   limit[L] = (first_code[L] + count[L]) << (15 - L) = sum over k <= L of count[k] << (15 - k)     (the Kraft sum)
@@ -564,10 +569,9 @@ FI u32 emit_code_header(Dec &d, Lds &s, u32 cnt, const bool wide, u32 &off) {
     const u32 nnz = rdl(offi, 15);
     const u32 maxlen = 63u - (u32)__builtin_clzll(ballot(c != 0u) | 1ull);
     const u32 h = tm_alloc(d, BRX_HDR_WORDS + (wide ? nnz : ((nnz + 1u) >> 1)));
-    const u32 w0 = lane == 0u ? 0u : lim << 16;                              // header[2L]
-    const u32 w1 = lane == 0u ? (2u | (maxlen << 8) | (nnz << 16)) : base;  // header[2L + 1]; header[1] = kind | max_len | symbols
-    if (h < BRX_TM_WORDS) { if (lane < 16u) { tm_st32<true>(d, s, h + 2u * lane, w0); tm_st32<true>(d, s, h + 2u * lane + 1u, w1); } }
-    else { if (lane < 16u) { tm_st32<false>(d, s, h + 2u * lane, w0); tm_st32<false>(d, s, h + 2u * lane + 1u, w1); } }
+    const u32 w = lane == 0u ? 0u : lane == BRX_HDR_INFO ? (2u | (maxlen << 8) | (nnz << 16)) : (lim << 16) | (base & 0xffffu);
+    if (h < BRX_TM_WORDS) { if (lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + lane, w); }
+    else { if (lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + lane, w); }
     return h;
 }
 FI void code_put_symbol(const Dec &d, Lds &s, u32 h, const bool wide, bool on, u32 slot, u32 sym) {
@@ -635,7 +639,7 @@ FI u32 build_simple(Dec &d, Lds &s, u32 nsym, u32 k0, u32 k1, u32 k2, u32 k3, co
 
 FI u32 build_single(Dec &d, Lds &s, u32 sym) {
     u32 h = tm_alloc(d, BRX_HDR_WORDS);
-    u32 w = d.lane == 1u ? (1u | (sym << 16)) : 0u;
+    u32 w = d.lane == BRX_HDR_INFO ? (1u | (sym << 16)) : 0u;
     if (h < BRX_TM_WORDS) { if (d.lane < BRX_HDR_WORDS) tm_st32<true>(d, s, h + d.lane, w); }
     else { if (d.lane < BRX_HDR_WORDS) tm_st32<false>(d, s, h + d.lane, w); }
     return h;
@@ -1206,7 +1210,7 @@ FI u32 hd_tree(const Dec &d, const Lds &s, u32 h) {
     return h < BRX_TM_WORDS ? tm_ld32<true>(d, s, h + (d.lane & 31u)) : tm_ld32<false>(d, s, h + (d.lane & 31u));
 }
 FI u32 hd_decode(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sym) {
-    const u32 h0 = rdl(hv, 1);
+    const u32 h0 = rdl(hv, BRX_HDR_INFO);
     const u32 kind = h0 & 3u;
     if (kind == 0u) return LK_NONE;
     if (kind == 1u) {
@@ -1214,13 +1218,13 @@ FI u32 hd_decode(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sym) {
         return LK_OK;
     }
     const u32 v = __brev(hb_peek(d) & 0x7fffu) >> 17; // first stream bit = MSB of a 15-bit left-aligned code
-    const u64 m = ballot((v << 16) < hv) & 0x55555554ull; // lanes 2, 4 .. 30 carry limit[1..15] << 16
+    const u64 m = ballot(((v << 16) | 0xffffu) < hv) & 0xfffeull; // lanes 1 .. 15 carry limit << 16 | base
     if (m == 0ull) {
         hb_skip(d, ((h0 >> 8) & 0xffu) + 1u);
         return LK_NONE;
     }
-    const u32 L = (u32)__builtin_ctzll(m) >> 1;
-    const u32 idx = ((v >> (15u - L)) + rdl(hv, 2u * L + 1u)) & 0xffffu;
+    const u32 L = (u32)__builtin_ctzll(m);
+    const u32 idx = ((v >> (15u - L)) + rdl(hv, L)) & 0xffffu;
     sym = h < BRX_TM_WORDS ? rfl(tm_ld16<true>(d, s, (h + BRX_HDR_WORDS) * 2u + idx)) : rfl(tm_ld16<false>(d, s, (h + BRX_HDR_WORDS) * 2u + idx));
     hb_skip(d, L);
     return LK_OK;
@@ -1591,28 +1595,28 @@ FI u32 distance_payload(u32 code, u32 npostfix, u32 ndirect) {
 FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mode, bool uniform) {
     const u8 *lut = (const u8 *)d.t_lut;
     for (u32 t = 0; t < m.ntd; t++) {
-        const u32 info = rfl(s.tm[rfl(s.tm[m.hd + t]) + 1u]);
+        const u32 info = rfl(s.tm[rfl(s.tm[m.hd + t]) + BRX_HDR_INFO]);
         if ((info & 3u) == 1u && (info >> 16) >= 16u) return false;
     }
     for (u32 t = 0; t < m.ntd; t++) {
         const u32 h = rfl(s.tm[m.hd + t]);
-        const u32 info = rfl(s.tm[h + 1u]);
+        const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
         if ((info & 3u) != 2u) continue; // (a one-symbol tree keeps the plain code in its info word)
         const u32 nnz = info >> 16;
         for (u32 k = d.lane; k < nnz; k += 64u) s.tm[h + BRX_HDR_WORDS + k] = distance_payload(s.tm[h + BRX_HDR_WORDS + k], m.npostfix, m.ndirect);
     }
     for (u32 t = 0; t < n_iac; t++) {
         const u32 h = rfl(s.tm[m.hi + t]);
-        const u32 nnz = rfl(s.tm[h + 1u]) >> 16;
+        const u32 nnz = rfl(s.tm[h + BRX_HDR_INFO]) >> 16;
         u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
         for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 4);
     }
     for (u32 t = 0; uniform && t < m.ntl; t++) {
         const u32 h = rfl(s.tm[m.hl + t]);
-        const u32 info = rfl(s.tm[h + 1u]);
+        const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
         if ((info & 3u) == 1u) { // one-symbol tree: the symbol lives in the info word
             const u32 sym = (info >> 16) & 0xffu;
-            if (d.lane == 0u) s.tm[h + 1u] = (info & 0xffffu) | ((sym | (context_info(lut, mode, sym) << 8)) << 16);
+            if (d.lane == 0u) s.tm[h + BRX_HDR_INFO] = (info & 0xffffu) | ((sym | (context_info(lut, mode, sym) << 8)) << 16);
             continue;
         }
         const u32 nnz = info >> 16;
@@ -1663,13 +1667,13 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;
             if (h_ >= BRX_TM_WORDS - BRX_HDR_WORDS) { ok = 0u; why |= 2u; }
             else {
-                const u32 kind_ = rfl(s.tm[h_ + 1u]) & 3u; // literal / distance trees may be one-symbol codes
+                const u32 kind_ = rfl(s.tm[h_ + BRX_HDR_INFO]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
                 if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u; }
                 // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
-                // the left-aligned upper bound of its longest codes is then exactly 2^15 (<< 16 in the table)
-                const u32 hvw_ = s.tm[h_ + 2u * (d.lane & 15u)];
-                const bool full_ = ballot(hvw_ == 0x80000000u) != 0ull;
+                // the left-aligned upper bound of its longest codes is then exactly 2^15 (the high half of the header word)
+                const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
+                const bool full_ = ballot((hvw_ >> 16) == 0x8000u) != 0ull;
                 if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }

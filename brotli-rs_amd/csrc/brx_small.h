@@ -27,7 +27,7 @@ struct SmTabs { // the header's results (what Lds::mbw carries in the regular ke
 // Lookup in a code whose header words sit across the lanes of `hv` (loaded once per tree; layout: "Table layout in table
 // memory" above) through the hb_* reader.  false = no such codeword / empty code (the reference: an error, or None).
 template <bool WIDE> FI bool sm_sym(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sym) {
-    const u32 h0 = rdl(hv, 1);
+    const u32 h0 = rdl(hv, BRX_HDR_INFO);
     const u32 kind = h0 & 3u;
     if (kind == 1u) { // one symbol: zero bits (Q5)
         sym = h0 >> 16;
@@ -35,10 +35,10 @@ template <bool WIDE> FI bool sm_sym(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sy
     }
     if (kind == 0u) return false;
     const u32 v = __brev(hb_peek(d) & 0x7fffu) >> 17;
-    const u64 m = ballot((v << 16) < hv) & 0x55555554ull;
+    const u64 m = ballot(((v << 16) | 0xffffu) < hv) & 0xfffeull;
     if (m == 0ull) return false; // an unassigned codeword of an incomplete code (Q15)
-    const u32 L = (u32)__builtin_ctzll(m) >> 1;
-    const u32 idx = ((v >> (15u - L)) + rdl(hv, 2u * L + 1u)) & 0xffffu;
+    const u32 L = (u32)__builtin_ctzll(m);
+    const u32 idx = ((v >> (15u - L)) + rdl(hv, L)) & 0xffffu;
     sym = WIDE ? rfl(s.tm[h + BRX_HDR_WORDS + idx]) : rfl(((const u16 *)s.tm)[(h + BRX_HDR_WORDS) * 2u + idx]);
     hb_skip(d, L);
     return true;

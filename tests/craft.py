@@ -591,9 +591,9 @@ def odd_long_stream(seed, rounds, first=1 << 16, mib=4, tail=2, wbits=22):
 
 def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
     """A stream of len(trees_per_mb) compressed meta-blocks; meta-block j has NTREESL = trees_per_mb[j] literal trees (two
-    symbols each, a 34-word table per tree in the HIP decoder's table memory) behind a context map over the 64 context ids,
-    so the table memory a meta-block needs is chosen per meta-block: a stream whose LATER meta-block outgrows the kernel
-    instance that started it (the regular one holds ~48 such trees, level 1 ~66, level 2 ~120).  Commands as in
+    symbols each, an 18-word table + a handle per tree in the HIP decoder's table memory) behind a context map over the 64
+    context ids, so the table memory a meta-block needs is chosen per meta-block: a stream whose LATER meta-block outgrows the
+    kernel instance that started it (the regular one holds ~88 such trees, level 1 ~121, level 2 ~222).  Commands as in
     context_mode_stream: 6 / 7 literals, then a copy of 2 from the last distance.  Returns (stream, expected_output) -- the
     output from an independent model of the context rules."""
     rng = random.Random(seed)

@@ -146,7 +146,7 @@ def growing_table_streams():
     kernel instance that started the stream, or the first one does, or none.  Expected bytes from craft.py's own model."""
     import craft
     sets = []
-    for i, shape in enumerate(([2, 2, 60, 2, 80], [1, 3, 5, 130, 2], [50, 2], [2] * 6, [50, 2, 80], [3, 70], [90, 1, 1, 60], [250, 2])):
+    for i, shape in enumerate(([2, 2, 105, 2, 150], [1, 3, 5, 250, 2], [100, 2], [2] * 6, [100, 2, 160], [3, 140], [170, 1, 1, 110], [256, 2])):
         for mode in (i % 4, (i + 1) % 4):
             st, out = craft.growing_tables_stream(60 + i, shape, mode=mode, n_cmds=25 + 30 * (i % 3))
             sets.append(("growing_tables_%s_mode%d" % ("_".join(map(str, shape)), mode), st, 0, out))

@@ -212,6 +212,14 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def _level1_stream(seed=77, n_cmds=500):
+    """(compressed, expected) of a stream whose one meta-block needs more table memory than the regular kernel holds and no more
+    than level 1 does (tests/craft.py growing_tables_stream: 105 literal trees).  (Until round 4 lcet10.txt was that stream: with
+    limit and base of a code length sharing one header word its tables, 2 208 words then, fit the regular kernel.)"""
+    import craft
+    return craft.growing_tables_stream(seed, [105], mode=2, n_cmds=n_cmds)
+
+
 def _build_cpp(tmp_path, name):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -639,11 +647,11 @@ def test_tiny_streams_through_the_assembly_loop_too():
 
 
 def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
-    """lcet10.txt's tables (2 208 words) do not fit the regular kernel's 1 728 words of LDS table memory: the regular kernel
+    """A stream whose tables do not fit the regular kernel's 1 728 words of LDS table memory (_level1_stream): the regular kernel
     drops such a stream at the spill and lists it, the wide-LDS kernel launched behind it decodes it from the start.  A
     mixed batch (spilling and fitting streams, reject vectors, empty outputs, unaligned slots) is bit-exact, the count
     of handed-over streams is what the batch holds, and a batch without any hands over nothing."""
-    lcet = _read("lcet10.txt.compressed")
+    lcet, lcet_out = _level1_stream()
     alice = _read("alice29.txt.compressed")
     rest = [_read(e["stream"]) for e in MANIFEST]
     streams = []
@@ -660,7 +668,7 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
            if w[0] != st or (st == 0 and o != w[1])]
     assert not bad, bad[:8]
-    assert 73 <= wide <= 73 + 12, wide  # every lcet10 and mapsdatazrh (the few other spilling fixtures of data/ on top)
+    assert 73 <= wide <= 73 + 12, wide  # every level-1 stream and mapsdatazrh (the few other spilling fixtures of data/ on top)
     assert 3 <= ctx.last_wide_streams(2) <= 3 + 12 and ctx.last_wide_streams(3) <= 12
     outs, status, out_len = ctx.decode_batch([alice] * 40, len(_read("alice29.txt")) + 16)
     assert ctx.last_wide_streams() == 0
@@ -668,20 +676,19 @@ def test_wide_kernel_takes_the_streams_whose_tables_spill(ctx):
     # a spilling stream whose slot is too small: status 25 and the length needed so far, from whichever kernel meets it
     outs, status, out_len = ctx.decode_batch([lcet, alice, lcet], [1000, 200000, 500000])
     w0 = oracle.decode(lcet, 0, cap=1000)
-    assert [int(x) for x in status] == [25, 0, 0] and w0[0] == 25
-    assert outs[2] == _read("lcet10.txt")
+    assert [int(x) for x in status] == [25, 0, 0] and w0[0] == 25 and len(lcet_out) > 1000
+    assert outs[2] == lcet_out
 
 
 def test_level1_kernel_next_to_the_regular_one(ctx):
-    """A mixed full-chip batch on the device path: alice29 / asyoulik / plrabn12 fill the regular kernel, every fourth stream is
-    lcet10 (tables spill: listed for level 1 within its first header), a few mapsdatazrh go on to level 2.  The level-1 kernel
-    runs on the context's second HIP stream NEXT TO the regular one: its waves wait for list entries while the regular kernel
-    is still decoding and leave when it is complete.  Bytes, lengths and statuses are the reference files'; every lcet10 and
-    mapsdatazrh went through the wide kernels."""
+    """A mixed full-chip batch on the device path: alice29 / asyoulik / plrabn12 fill the regular kernel, every fourth stream
+    needs level 1 (_level1_stream), a few mapsdatazrh level 2.  After the first launch the context classifies before it launches
+    (plan B) and the wider kernels run NEXT TO the regular one on their own HIP streams.  Bytes, lengths and statuses are the
+    expected ones; every level-1 stream and mapsdatazrh went through the wide kernels."""
     import torch
     dev = torch.device("cuda:0")
-    names = ["alice29.txt", "lcet10.txt", "asyoulik.txt", "plrabn12.txt"]
-    fx = [(_read(n_ + ".compressed"), _read(n_)) for n_ in names]
+    names = ["alice29.txt", None, "asyoulik.txt", "plrabn12.txt"]
+    fx = [(_read(n_ + ".compressed"), _read(n_)) if n_ else _level1_stream(78, 4000) for n_ in names]
     maps = (_read("mapsdatazrh.compressed"), _read("mapsdatazrh"))
     n = 4400  # more streams than resident waves: the ticket queue of the regular kernel is in play as well
     pick = [maps if i % 400 == 7 else fx[i % 4] for i in range(n)]
@@ -739,7 +746,7 @@ def test_fresh_context_sends_spilling_streams_straight_to_level_3():
     from brotli_rs_amd import brx
     c2 = brx_knobs.context(0)
     try:
-        lcet, maps, alice = _read("lcet10.txt.compressed"), _read("mapsdatazrh.compressed"), _read("alice29.txt.compressed")
+        lcet, maps, alice = _level1_stream()[0], _read("mapsdatazrh.compressed"), _read("alice29.txt.compressed")
         streams = [alice, lcet, maps, _read("monkey.compressed"), lcet, bytes.fromhex("a103")] * 9
         want = [oracle.decode(s_, 0, cap=1 << 19) for s_ in streams]
         for rep in range(2):
@@ -774,7 +781,7 @@ def test_later_meta_block_that_outgrows_its_level_is_resumed_not_restarted(level
     import craft
     c2 = brx_knobs.context(0, levels=levels)
     try:
-        shapes = [[2, 2, 60, 2, 80], [1, 3, 5, 130, 2], [50, 2], [2] * 6, [50, 2, 80], [3, 70], [90, 1, 1, 60], [2, 2, 2, 49, 2, 140, 2]]
+        shapes = [[2, 2, 105, 2, 150], [1, 3, 5, 250, 2], [100, 2], [2] * 6, [100, 2, 160], [3, 140], [170, 1, 1, 110], [2, 2, 2, 80, 2, 240, 2]]
         fx = [craft.growing_tables_stream(11 + i, sh, mode=i % 4, n_cmds=30 + 40 * (i % 3)) for i, sh in enumerate(shapes)]
         alice = _read("alice29.txt.compressed")
         streams, want, late_a, late_b = [], [], 0, 0
@@ -784,7 +791,7 @@ def test_later_meta_block_that_outgrows_its_level_is_resumed_not_restarted(level
                 # plan A: a first header that spills sends the stream to the catch-all (level 3 holds everything); one that spills
                 # later is a late entry.  plan B: the pre-pass gives the first header's level; every later outgrowing is late.
                 first = shapes[i][0]
-                need = lambda nt: 0 if nt <= 48 else 1 if nt <= 66 else 2 if nt <= 125 else 3
+                need = lambda nt: 0 if nt <= 88 else 1 if nt <= 121 else 2 if nt <= 222 else 3  # (19 words per tree + ~55)
                 lvl, la, lb = need(first), 0, 0
                 for nt in shapes[i][1:]:
                     if need(nt) > lvl:
@@ -848,9 +855,9 @@ def test_two_overlapping_device_batches_on_two_hip_streams(ctx, order):
     import torch
     dev = torch.device("cuda:0")
     jobs = []
-    # metablock_reset and lcet10 spill the regular table memory: both batches hand streams to the wider kernel instances,
+    # metablock_reset and mapsdatazrh spill the regular table memory: both batches hand streams to the wider kernel instances,
     # each through its own lists, while the kernels of the other batches run
-    for name, n in (("alice29.txt", 700), ("metablock_reset", 96), ("lcet10.txt", 120)):
+    for name, n in (("alice29.txt", 700), ("metablock_reset", 96), ("mapsdatazrh", 120)):
         comp, exp = _read(name + ".compressed"), _read(name)
         cap = (len(exp) + 15) & ~15
         blob = torch.frombuffer(bytearray(comp * n), dtype=torch.uint8).to(dev)
