@@ -629,18 +629,33 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         uint32_t mask[4] = {0u, 1u, 2u, 4u};
         const int classes = (n0 != 0u) + (cnt[1] != 0u) + (cnt[2] != 0u) + (cnt[3] != 0u);
         if (classes > 1) {
+            // Shares in proportion to the parts each class would need for all its streams (about the same number of rounds for
+            // each); then the wide classes -- few streams, long ones -- get WHOLE rounds: 512 streams on 455 workgroups would
+            // leave 57 of them a second round behind everything else (mixed_allx4096: the last mapsdatazrh ended at 55 ms of 55),
+            // so a share of at least 2/3 of a class becomes all of it, anything less the even split over its rounds.  The regular
+            // class takes what is left (at least a quarter of the chip): its workgroups go through many short streams, a few
+            // more or less resident change its time in proportion, not in steps.
             const uint32_t m2 = cnt[1] + cnt[2];
             const double demand = n0 / 4.0 + m2 / 2.0 + cnt[3];
             const double sc = demand > (double)parts ? (double)parts / demand : 1.0;
-            auto share = [&](uint32_t cnt_, uint32_t per_part) -> uint32_t {
+            auto whole_rounds = [&](uint32_t cnt_) -> uint32_t {
                 if (cnt_ == 0u) return 0u;
-                const uint32_t r = (uint32_t)(cnt_ * sc) / per_part * per_part; // whole parts
-                return std::max<uint32_t>(std::min(r, cnt_), std::min(cnt_, per_part));
+                const double r = cnt_ * sc;
+                const uint32_t rounds = (uint32_t)std::max(1.0, 1.0 / std::max(r / cnt_, 1e-9) + 1.0 / 3.0); // 1 / share, rounded down from x.67
+                return (cnt_ + rounds - 1u) / rounds;
             };
-            g[0] = std::min<uint32_t>(share(n0, 4u), grid);
+            uint32_t r3 = whole_rounds(cnt[3]), r2 = whole_rounds(m2);
+            const uint32_t wide_parts_max = n0 ? parts - parts / 4u : parts;
+            while (r3 + (r2 + 1u) / 2u > wide_parts_max && (r3 > 1u || r2 > 2u)) { // (too much for the wide side: one more round each)
+                if (r3 > 1u) r3 = (r3 + 1u) / 2u;
+                if (r2 > 2u) r2 = (r2 + 1u) / 2u;
+            }
+            const uint32_t left = parts - std::min(parts, r3 + (r2 + 1u) / 2u);
+            g[0] = std::min<uint32_t>(std::min<uint32_t>(n0, left * 4u), grid);
+            if (n0 != 0u && g[0] == 0u) g[0] = 1u;
             g[1] = 0u;
-            g[2] = share(m2, 2u);
-            g[3] = share(cnt[3], 1u);
+            g[2] = r2;
+            g[3] = r3;
             mask[2] = 3u; // lists 0 and 1
         }
         const int narrowest = g[0] ? 0 : g[1] ? 1 : g[2] ? 2 : 3;
