@@ -91,7 +91,7 @@ struct brx_ctx {
     uint32_t small_waves_per_cu = 32;              // grid of the lean instance (A/B)
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
-    BrxSlabPool pool = {nullptr, nullptr, 0};
+    BrxSlabPool pool = {nullptr, nullptr, 0, nullptr};
     unsigned max_grid = 0;
     unsigned grid_cap = 0;
     bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
@@ -403,12 +403,13 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
     c->pool.bitmap = nullptr;
     c->pool.slabs = nullptr;
     c->pool.count = 0;
-    hipError_t e = hipMalloc(&c->pool.slabs, (size_t)want * BRX_SCRATCH_WORDS * 4u);
+    hipError_t e = hipMalloc(&c->pool.slabs, ((size_t)want + 1u) * BRX_SCRATCH_WORDS * 4u); // (+ 1: BrxSlabPool::sink)
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab pool allocation failed", e);
     e = hipMalloc(&c->pool.bitmap, (size_t)(want / 32u) * 4u);
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab bitmap allocation failed", e);
     HIP_TRY(hipMemset(c->pool.bitmap, 0, (size_t)(want / 32u) * 4u));
     c->pool.count = want;
+    c->pool.sink = c->pool.slabs + (size_t)want * BRX_SCRATCH_WORDS;
     HIP_TRY(hipMemcpy(c->d_pool, &c->pool, sizeof(BrxSlabPool), hipMemcpyHostToDevice));
     return BRX_SUCCESS;
 }
@@ -971,7 +972,7 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     const uint32_t cmd_cap = metablock_bytes / 4u + 2u;
     const size_t per_stream = 2048u * 4u + (adaptive ? (size_t)cmd_cap * 12u : 0u);
     // streams per launch: bounds the scratch (hash tables, 8 KiB per stream; command lists) at ~1 GiB
-    const uint32_t per_launch = (uint32_t)std::min<size_t>(32768, std::max<size_t>(64, ((size_t)1 << 30) / per_stream));
+    const uint32_t per_launch = (uint32_t)std::min<size_t>(32768, std::max<size_t>(1, ((size_t)1 << 30) / per_stream)); // (no floor above 1: ADVICE r3 -- 64 streams of 2^24-byte meta-blocks would ask for 3.2 GB)
     const size_t hash_bytes = (size_t)std::min(n, per_launch) * per_stream;
     auto run = [&](const void *s_, const uint64_t *so, uint32_t m, void *o_, const uint64_t *oo, uint64_t *ol, int32_t *stt) {
         if (adaptive)
@@ -1132,7 +1133,7 @@ static int bounded_init(brx_stream *s) {
     HIP_TRY(hipMemset(s->d_rec, 0, 32));
     const uint32_t only_slab_0 = 0xfffffffeu; // a private pool of ONE slab that survives between the slices
     HIP_TRY(hipMemcpy(s->d_bitmap, &only_slab_0, 4, hipMemcpyHostToDevice));
-    BrxSlabPool p = {s->d_bitmap, s->d_slab, 32};
+    BrxSlabPool p = {s->d_bitmap, s->d_slab, 32, s->d_slab}; // (sink = the one slab: only this stream's one wave ever asks)
     HIP_TRY(hipMemcpy(s->d_pool, &p, sizeof p, hipMemcpyHostToDevice));
     s->stage.resize(BRX_IN_STAGE);
     return BRX_SUCCESS;

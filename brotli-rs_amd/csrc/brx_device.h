@@ -62,6 +62,8 @@ struct BrxSlabPool {
     uint32_t *bitmap; // count / 32 words, bit set = slab in use
     uint32_t *slabs;  // count * BRX_SCRATCH_WORDS
     uint32_t count;   // multiple of 32
+    uint32_t *sink;   // one slab outside the bitmap: where the tables of a wave go that could not claim one within 0.5 s (a pool
+                      // that stays exhausted is a bug); its stream ends with the watchdog status, the device does not hang
 };
 
 // One static-dictionary word transform (spec Appendix B): prefix + elementary op + suffix.

@@ -228,7 +228,11 @@ FI void tm_zero_bytes(const Dec &d, Lds &s, u32 ba, u32 n) {
 FI u32 *scratch_claim(const BrxSlabPool *pool) {
     const u32 nwords = pool->count >> 5;
     u32 w = (blockIdx.x * 7u) % nwords;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
+        // (a pool that stays exhausted is a bug, not a state to wait out: after 0.5 s -- 100 MHz counter -- the stream gets the
+        // watchdog status instead of the device a hang)
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) return nullptr;
         u32 got = 0xffffffffu;
         if (threadIdx.x == 0u) {
             const u32 cur = __hip_atomic_load(&pool->bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -245,6 +249,7 @@ FI u32 *scratch_claim(const BrxSlabPool *pool) {
     }
 }
 FI void scratch_release(const BrxSlabPool *pool, const u32 *slab) {
+    if (slab == pool->sink) return; // (never claimed)
     const u32 idx = (u32)((size_t)(slab - pool->slabs) / BRX_SCRATCH_WORDS);
     if (threadIdx.x == 0u) atomicAnd(&pool->bitmap[idx >> 5], ~(1u << (idx & 31u)));
 }
@@ -267,13 +272,17 @@ FI u32 tm_alloc(Dec &d, u32 nwords) {
     // (what a wider level needs for the same objects: it packs them one behind the other, without the hole this level leaves at
     // the end of its LDS part when an object does not fit)
     d.need_cur += nwords;
-    d.need_peak = d.need_cur > d.need_peak ? d.need_cur : d.need_peak;
+    d.need_peak = d.need_cur > d.need_peak ? d.need_cur : d.need_peak; // (0xffffffff = "no slab could be had" stays)
     if (d.lds_top + nwords <= BRX_TM_WORDS) {
         u32 r = d.lds_top;
         d.lds_top += nwords;
         return r;
     }
     if (d.scratch == nullptr) d.scratch = scratch_claim(d.pool);
+    if (d.scratch == nullptr) { // no slab: the tables go to the pool's sink (shared, so they are garbage), the header ends with ST_WATCHDOG
+        d.need_peak = 0xffffffffu;
+        d.scratch = d.pool->sink;
+    }
     u32 r = BRX_TM_WORDS + d.scr_top;
     d.scr_top += nwords;
     return r;
@@ -1497,7 +1506,14 @@ __device__ __noinline__ u32 cold_header() {
     PT_ADD(13, pl);
     u32 rc = header_body(d, s);
     if (hb_over(d)) rc = ST_EOF; // a read crossed the end of the input: UnexpectedEOF came first (see hb_*)
-    if (rc) return rc;
+    if (d.need_peak == 0xffffffffu) rc = ST_WATCHDOG; // no spill slab could be had (scratch_claim gave up): tables are not what they should be
+    if (rc) {
+        // (the slab this header may have claimed goes back with the stream: the dispatcher releases what st[20..21] names.  Until
+        // round 4 an error behind the first spill lost it -- a slab less in the pool for the life of the context, and once a
+        // launch's waves outnumbered what was left they waited for ever: tests/test_gpu_parity.py truncation sweep)
+        put64(s, 20, (u64)(uintptr_t)d.scratch);
+        return rc;
+    }
     d.bitpos = hb_pos(d);
     dec_store_in(d, s);
     return ST_OK;

@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test runs under a time limit (pytest-timeout, when installed): a kernel that never ends must fail ONE test, not
+    hold the GPU box until the harness kills it."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

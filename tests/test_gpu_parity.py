@@ -212,6 +212,48 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("levels", [1, 2])
+def test_truncation_sweep_through_the_first_headers(levels):
+    """the header path reads through a zero-padded bit reader with ONE deferred end-of-input check (and the
+    code-length symbols in hand-written assembly), so every status of a truncated stream hangs on that check coming at the right
+    moment.  Streams with complex codes, context maps with RLE + inverse move-to-front, many trees (tables for every level of
+    the kernel) are cut at EVERY byte of their first header(s) -- and, at every fourth cut, inside the last byte (its upper bits
+    zeroed: what a reader sees that ran out of bits there) -- and must end with the oracle's status; both launch plans.
+    (What it found in round 4: a header that failed AFTER its tables had spilled into a slab never gave the slab back; some
+    hundred such streams later the context's pool was empty and the next launch waited for ever.  Every source is therefore
+    decoded twice, and the 256-tree stream -- one slab per cut -- goes first, in chunks smaller than the pool.)"""
+    import craft
+    c2 = brx_knobs.context(0, levels=levels)
+    try:
+        big = craft.growing_tables_stream(83, [256], mode=3, n_cmds=12)[0]
+        for rep in range(3):  # (96 streams per launch against a pool of 128 slabs: a leaked slab per stream would stall the third pass)
+            cuts = [big[:k] for k in range(300, 396)]
+            outs, status, out_len = c2.decode_batch(cuts, 1 << 16)
+            assert [int(x) for x in status] == [24] * len(cuts)
+        sources = [(_read("alice29.txt.compressed"), 1500), (_read("lcet10.txt.compressed"), 2600), (_read("mapsdatazrh.compressed"), 3600),
+                   (open(os.path.join(GOLDEN, "config5", "c5_0.compressed"), "rb").read(), 1200),
+                   (_level1_stream(81, 60)[0], 10 ** 6), (craft.growing_tables_stream(82, [3, 150, 2, 250], mode=1, n_cmds=20)[0], 10 ** 6),
+                   (craft.growing_tables_stream(83, [256], mode=3, n_cmds=12)[0], 10 ** 6), (_read("monkey.compressed"), 10 ** 6)]
+        total = 0
+        for data, upto in sources:
+            cuts = []
+            for k in range(1, min(len(data), upto) + 1):
+                cuts.append(data[:k])
+                if k % 4 == 0:
+                    for j in (1, 3, 6):
+                        cuts.append(data[:k - 1] + bytes([data[k - 1] & ((1 << j) - 1)]))
+            want = [oracle.decode(s_, 0, cap=1 << 16) for s_ in cuts]
+            outs, status, out_len = c2.decode_batch(cuts, 1 << 16)
+            bad = [(i, len(cuts[i]), w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status))
+                   if w[0] != st or (st == 0 and o != w[1])]
+            assert not bad, bad[:8]
+            total += len(cuts)
+        assert total > 15000
+    finally:
+        c2.close()
+
+
 def _level1_stream(seed=77, n_cmds=500):
     """(compressed, expected) of a stream whose one meta-block needs more table memory than the regular kernel holds and no more
     than level 1 does (tests/craft.py growing_tables_stream: 105 literal trees).  (Until round 4 lcet10.txt was that stream: with
