@@ -992,6 +992,9 @@ FI void bulk_copy_1k(Dec &d, Lds &s, u32 de) {
 // lane l reads its unit from the ring and stores it STRAIGHT to HBM -- no ring write, no flush read: one LDS read and
 // one 16 B/lane buffer store per KiB and wave (configs 3/4 of BASELINE.json run at the HBM write rate this way).
 // Afterwards the ring is re-seeded with the last 2 KiB of the output: the fill's last two blocks, again from the period in LDS.
+#ifndef BRX_FILL_AUX
+#define BRX_FILL_AUX 0 // cache policy bits of the fill's stores (A/B: 2 = nt)
+#endif
 FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
     flush_range(d, s, d.vfl, d.pos + d.a);                 // everything up to the cursor is in HBM now
     const u32 base = d.pos - P + d.a;                      // skewed ring coordinate of the period's first byte
@@ -1005,7 +1008,7 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
         u32 off = d.pos + 16u * d.lane;
         if (step == 0u) {
             if (d.mirror == nullptr) {
-                for (u32 k = 0; k < nblocks; k++) { __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0); off += 1024u; }
+                for (u32 k = 0; k < nblocks; k++) { __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, BRX_FILL_AUX); off += 1024u; }
             } else {
                 for (u32 k = 0; k < nblocks; k++) { OUT_STORE128(q, off); off += 1024u; }
             }
@@ -1015,7 +1018,7 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
                 o += step;
                 o = o >= P ? o - P : o;
                 const u32x4 qn = *(const u32x4 *)&s.ring[(base + o) & RMASK]; // (one read more than needed at the end)
-                __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(q, d.out_rsrc, off, 0, BRX_FILL_AUX);
                 if (both) __builtin_amdgcn_raw_buffer_store_b128(q, d.out2_rsrc, off, 0, 0);
                 off += 1024u;
                 q = qn;
