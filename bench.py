@@ -133,7 +133,7 @@ def kernel_source_id():
     """sha256 (16 hex digits) of the kernel sources: ties a committed PMC traffic measurement to the kernel it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("brx_hot.S", "brx_lens.S", "brx_kernels.hip", "brx_device.h"):
+    for f in ("brx_hot.S", "brx_lens.S", "brx_kernels.hip", "brx_small.h", "brx_device.h"):
         h.update(open(os.path.join(ROOT, "brotli-rs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -163,7 +163,7 @@ def measured_traffic(workload, streams):
         try:
             cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
+                   "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--no-chain-floor", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)

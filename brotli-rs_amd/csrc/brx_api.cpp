@@ -984,6 +984,10 @@ extern "C" int brx_generate_batch(brx_ctx *c, const uint8_t *src, const uint64_t
     };
     hipStream_t st = (opts && opts->hip_stream && (flags & BRX_MEM_DEVICE)) ? (hipStream_t)opts->hip_stream : c->stream;
     if (flags & BRX_MEM_DEVICE) {
+        // (device-pointer calls are asynchronous on the caller's stream and share this scratch: before it is REPLACED by a larger
+        // one nobody may be using the old one any more -- ADVICE r3; calls that fit run one behind the other on their streams'
+        // order only if they use the same stream: concurrent generator calls on different streams must use different contexts)
+        if (hash_bytes > c->st_gen_cap || !c->st_gen) HIP_TRY(hipDeviceSynchronize());
         int rc = grow(&c->st_gen, &c->st_gen_cap, hash_bytes);
         if (rc) return rc;
         for (uint32_t k = 0; k < n; k += per_launch) { // (same stream: the launches run one after the other and share the tables)

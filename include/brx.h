@@ -206,7 +206,10 @@ void brx_host_free(void *p);
  *   status          n  0, or 25 when the slot was too small (out_len then says how much was needed)
  * Pointers are host memory (staged) or, with BRX_MEM_DEVICE in opts->flags, device memory (opts->hip_stream as for
  * brx_decode_batch).  BRX_GEN_SWITCHES in opts->flags: every meta-block declares two literal block types (sharing the
- * one literal tree) and switches between them every 100 literals -- the block-switch commands of the format, 4 bits each.  Returns BRX_SUCCESS or a BRX_ERR_* code. */
+ * one literal tree) and switches between them every 100 literals -- the block-switch commands of the format, 4 bits each.  Returns BRX_SUCCESS or a BRX_ERR_* code.
+ * The generator's hash tables live in ONE scratch buffer per context: device-pointer calls on different HIP streams of one
+ * context are not concurrent-safe (use one context per stream); a call that needs a larger scratch synchronizes the device
+ * before it replaces the old one. */
 int brx_generate_batch(brx_ctx *ctx, const uint8_t *src, const uint64_t *src_off, uint32_t n, uint8_t *out,
                        const uint64_t *out_off, uint64_t *out_len, int32_t *status, uint32_t metablock_bytes,
                        const brx_opts *opts);

@@ -65,7 +65,7 @@ i = a.index("--pmc") + 1
 cs = []
 while not a[i].startswith("--"):
     cs.append(a[i]); i += 1
-assert "--kernel-trace" in a and "--no-traffic" in a and "--sys-trace" not in a and "-s" not in a and "--hip-trace" not in a
+assert "--kernel-trace" in a and "--no-traffic" in a and "--no-chain-floor" in a and "--sys-trace" not in a and "-s" not in a and "--hip-trace" not in a
 assert a.count("--pmc") == 1 and (len(cs) == 1 or all(c.startswith("SQ_") for c in cs))  # FETCH_SIZE / WRITE_SIZE: a pass each
 open(os.path.join(os.environ["FAKE_LOG"]), "a").write("+".join(cs) + "\\n")
 os.makedirs(os.path.join(d, "host", "123"), exist_ok=True)

@@ -540,6 +540,11 @@ class Wave:
         elif op == "v_bfe_u32":
             a, off, wid = self.vsrc(ops[1]), self.vsrc(ops[2]) & U32(31), self.vsrc(ops[3]) & U32(31)
             self.vset(ops[0], (a >> off) & ((U32(1) << wid) - U32(1)))
+        elif op == "v_bfe_i32":  # (SPLIT_TREE: the base half of a tree's header word, sign-extended)
+            a, off, wid = self.vsrc(ops[1]), self.vsrc(ops[2]) & U32(31), self.vsrc(ops[3]) & U32(31)
+            f = ((a >> off) & ((U32(1) << wid) - U32(1))).astype(np.int64)
+            sign = (f >> (wid.astype(np.int64) - 1)) & 1
+            self.vset(ops[0], (f - (sign << wid.astype(np.int64))).astype(np.uint32))
         elif op == "v_bfi_b32":
             m_, a, b = self.vsrc(ops[1]), self.vsrc(ops[2]), self.vsrc(ops[3])
             self.vset(ops[0], (m_ & a) | (~m_ & b))
