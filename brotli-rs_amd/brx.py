@@ -108,7 +108,7 @@ def status_str(code: int) -> str:
 
 # brx_ctx_set_option (include/brx.h, BRX_OPTION_*): explicit knobs -- neither the library nor this module reads the environment
 OPTIONS = {"command_loop": 1, "loop_build": 2, "queue_order": 3, "hand_up": 4, "levels": 5, "tiny_bytes": 6,
-           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10, "trace": 11}
+           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10, "trace": 11, "reader_window": 12}
 
 
 class Context:
@@ -258,6 +258,10 @@ class Context:
         if rc != 0:
             raise BrxError("brx_last_trace failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
         return buf
+
+    def stream_short_slices(self):
+        """Slices of bounded / pulled streams of this context that paused in front of an item the resident input did not hold."""
+        return int(self._lib.brx_last_timing(self._h, 8))
 
     def last_lean_listed(self):
         """Streams of the most recent launch that the lean instance (short streams, 32 waves per CU) left to the regular kernel:

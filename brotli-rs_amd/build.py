@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
-DEPS = SOURCES + ["brx_device.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
+DEPS = SOURCES + ["brx_device.h", "brx_plan.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
 

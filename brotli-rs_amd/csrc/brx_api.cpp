@@ -24,6 +24,7 @@
 #include "../../include/brx.h"
 #include "_gen/brx_tables_gen.h" // BRX_DICT, BRX_CONTEXT_LUT, BRX_TRANSFORMS  (tools/bin2h.py from tables/*.bin)
 #include "brx_device.h"
+#include "brx_plan.h"
 
 static thread_local std::string g_err;
 
@@ -95,6 +96,8 @@ struct brx_ctx {
     unsigned max_grid = 0;
     unsigned grid_cap = 0;
     bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
+    size_t reader_window = (8u << 20);            // BRX_OPTION_READER_WINDOW: compressed bytes a bounded / pulled stream keeps resident
+    uint64_t stream_short_slices = 0;             // slices of bounded streams that paused in front of an item the resident input did not hold (brx_last_timing 8)
     bool trace_on = false;                        // BRX_OPTION_TRACE: per-stream start / end / place of the most recent launch (brx_last_trace)
     unsigned long long *d_trace = nullptr;
     size_t trace_cap = 0, trace_n = 0;
@@ -355,6 +358,10 @@ extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
     case BRX_OPTION_GRID_CAP: c->grid_cap = (unsigned)std::max<int64_t>(value, 0); break;
     case BRX_OPTION_SMALL_BYTES: c->small_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), BRX_SMALL_MAX_BYTES); break;
     case BRX_OPTION_TRACE: c->trace_on = value != 0; break;
+    case BRX_OPTION_READER_WINDOW:
+        if (value < (1 << 20) || value > (256 << 20)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: reader window is 1 MiB .. 256 MiB");
+        c->reader_window = ((size_t)value + 65535u) & ~(size_t)65535;
+        break;
     case BRX_OPTION_SMALL_WAVES: c->small_waves_per_cu = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 32); break;
     default: return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: unknown option");
     }
@@ -616,49 +623,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         a.late_only = 1u;
         // the regular kernel's queue, long jobs first without a sort: two walks split at the mean compressed size of its streams
         a.big_bytes = hc[8] != 0u ? (uint32_t)std::min<uint64_t>(((uint64_t)hc[7] << 6) / hc[8], 0xffffffffull) : 0u;
-        // What is resident together.  A CU's 160 KiB of LDS is handed out in four parts of 40 KiB (one per SIMD; measured:
-        // profiles/r04_two_queues.txt, r04_residency.txt): 4 regular workgroups, 3 of level 1, 2 of level 2 or 1 of level 3 per
-        // part -- and a dispatch that has run out of room does not move on when room appears elsewhere, its pending workgroups
-        // wait for the CU they are due on.  So every kernel gets a PERSISTENT grid of workgroups that all find room at once (the
-        // rest of its list comes through its ticket counter), sized so that the classes take about the same number of rounds.
-        // One class only: its own kernel, alone.  Several: level 1 joins level 2 -- parts fill without a gap only with sizes
-        // 10 / 20 / 40 KiB (12.5 + 2 x 10 leaves 7.5 unused, and a part that holds three regular workgroups holds nothing else),
-        // widest first.
-        const uint32_t parts = c->max_grid / 4u;
-        uint32_t g[4] = {std::min<uint32_t>(n0, grid), std::min<uint32_t>(cnt[1], per_cu * 12u), std::min<uint32_t>(cnt[2], per_cu * 8u),
-                         std::min<uint32_t>(cnt[3], per_cu * 4u)};
-        uint32_t mask[4] = {0u, 1u, 2u, 4u};
-        const int classes = (n0 != 0u) + (cnt[1] != 0u) + (cnt[2] != 0u) + (cnt[3] != 0u);
-        if (classes > 1) {
-            // Shares in proportion to the parts each class would need for all its streams (about the same number of rounds for
-            // each); then the wide classes -- few streams, long ones -- get WHOLE rounds: 512 streams on 455 workgroups would
-            // leave 57 of them a second round behind everything else (mixed_allx4096: the last mapsdatazrh ended at 55 ms of 55),
-            // so a share of at least 2/3 of a class becomes all of it, anything less the even split over its rounds.  The regular
-            // class takes what is left (at least a quarter of the chip): its workgroups go through many short streams, a few
-            // more or less resident change its time in proportion, not in steps.
-            const uint32_t m2 = cnt[1] + cnt[2];
-            const double demand = n0 / 4.0 + m2 / 2.0 + cnt[3];
-            const double sc = demand > (double)parts ? (double)parts / demand : 1.0;
-            auto whole_rounds = [&](uint32_t cnt_) -> uint32_t {
-                if (cnt_ == 0u) return 0u;
-                const double r = cnt_ * sc;
-                const uint32_t rounds = (uint32_t)std::max(1.0, 1.0 / std::max(r / cnt_, 1e-9) + 1.0 / 3.0); // 1 / share, rounded down from x.67
-                return (cnt_ + rounds - 1u) / rounds;
-            };
-            uint32_t r3 = whole_rounds(cnt[3]), r2 = whole_rounds(m2);
-            const uint32_t wide_parts_max = n0 ? parts - parts / 4u : parts;
-            while (r3 + (r2 + 1u) / 2u > wide_parts_max && (r3 > 1u || r2 > 2u)) { // (too much for the wide side: one more round each)
-                if (r3 > 1u) r3 = (r3 + 1u) / 2u;
-                if (r2 > 2u) r2 = (r2 + 1u) / 2u;
-            }
-            const uint32_t left = parts - std::min(parts, r3 + (r2 + 1u) / 2u);
-            g[0] = std::min<uint32_t>(std::min<uint32_t>(n0, left * 4u), grid);
-            if (n0 != 0u && g[0] == 0u) g[0] = 1u;
-            g[1] = 0u;
-            g[2] = r2;
-            g[3] = r3;
-            mask[2] = 3u; // lists 0 and 1
-        }
+        // What is resident together: brx_plan.h (persistent grids that all find room at once, by 40-KiB LDS parts)
+        const BrxPlanB plan = brx_plan_b(n0, cnt, c->max_grid / 4u, c->max_grid);
+        uint32_t g[4] = {std::min<uint32_t>(plan.grid[0], grid), plan.grid[1], plan.grid[2], plan.grid[3]};
+        const uint32_t *mask = plan.mask;
         const int narrowest = g[0] ? 0 : g[1] ? 1 : g[2] ? 2 : 3;
         for (int k = 3; k >= 1; k--) {
             if (g[k] == 0u) continue;
@@ -892,6 +860,7 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
     if (which >= 2 && which <= 7) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
                                     // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
                                     // regular kernel (large ones + given up); 6 = streams of the late list (handed up with their
@@ -1077,19 +1046,21 @@ struct brx_stream {
     int lib_rc = BRX_SUCCESS;
     // bounded mode (large streams, and every stream over a reader): decoded slice by slice into a sliding device window of
     // output, from a sliding device window of compressed input -- never more resident than BRX_BOUNDED_BUFSIZE of output +
-    // BRX_IN_WINDOW of input (+ two spill slabs and two state records) on the device, one staging chunk on the host
+    // the input window (+ one spill slab and one state record) on the device, one staging chunk on the host
     bool bounded = false, finished = false;
     brx_read_fn read_fn = nullptr; // the compressed input is PULLED (reference: BufReader over R, src/bitreader/mod.rs:21-53);
     void *read_user = nullptr;     // nullptr = from `in` (brx_stream_new / brx_stream_new_bounded)
     size_t mem_at = 0;             // ... how much of `in` has been pulled
     bool src_eof = false;
+    bool no_progress = false, stalled = false; // the last slice paused where it started / ... and the window could not be improved
     uint8_t *d_inwin = nullptr, *d_buf = nullptr;
+    size_t in_window = (8u << 20);     // size of d_inwin (the context's reader_window when the stream started decoding)
     size_t in_fill = 0, in_cursor = 0; // bytes resident in d_inwin; the decoder's cursor in it (after the last good slice)
     uint64_t in_slide_pending = 0;     // bytes the window has moved up since the record was last told
     std::vector<uint8_t> stage;
-    BrxResume *d_rec = nullptr, *d_rec_bak = nullptr;
+    BrxResume *d_rec = nullptr;
     BrxSlabPool *d_pool = nullptr;
-    uint32_t *d_bitmap = nullptr, *d_slab = nullptr, *d_slab_bak = nullptr; // (d_bitmap: 2 words, the second is the checkpoint's)
+    uint32_t *d_bitmap = nullptr, *d_slab = nullptr;
     uint64_t *d_meta = nullptr; // in_off[2] | out_off[2] | out_len[1] | status
     uint64_t shift = 0, pos = 0, delivered = 0;
 };
@@ -1099,9 +1070,10 @@ struct brx_stream {
 #define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
 #define BRX_BOUNDED_SLIDE_MIN (1u << 20)        // the window slides only once it is over by this much (see bounded_step)
 #define BRX_BOUNDED_BUFSIZE ((size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK)
-#define BRX_IN_WINDOW (8u << 20)      // compressed bytes resident on the device
+#define BRX_IN_WINDOW (8u << 20)      // compressed bytes resident on the device (default; BRX_OPTION_READER_WINDOW)
 #define BRX_IN_KEEP 4096u             // ... of which this much below the cursor stays (the kernel stages 256-byte chunks behind it)
 #define BRX_IN_STAGE (1u << 20)       // host staging chunk of the pulls
+#define BRX_IN_MARGIN_DIV 32u         // a slice pauses window / 32 (256 KiB) in front of the resident end while the source has more
 
 static void bounded_release(brx_stream *s) {
     if (!s->d_buf && !s->d_inwin) return;
@@ -1109,11 +1081,11 @@ static void bounded_release(brx_stream *s) {
     (void)hipFree(s->d_inwin);
     (void)hipFree(s->d_buf);
     (void)hipFree(s->d_slab);
-    (void)hipFree(s->d_rec); // (one allocation: both records, the pool descriptor, the bitmap, the offset / result words)
+    (void)hipFree(s->d_rec); // (one allocation: the record, the pool descriptor, the bitmap, the offset / result words)
     s->d_inwin = s->d_buf = nullptr;
-    s->d_rec = s->d_rec_bak = nullptr;
+    s->d_rec = nullptr;
     s->d_pool = nullptr;
-    s->d_bitmap = s->d_slab = s->d_slab_bak = nullptr;
+    s->d_bitmap = s->d_slab = nullptr;
     s->d_meta = nullptr;
     std::vector<uint8_t>().swap(s->stage);
 }
@@ -1121,16 +1093,15 @@ static void bounded_release(brx_stream *s) {
 static int bounded_init(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    s->in_window = c->reader_window;
     const size_t bufsize = BRX_BOUNDED_BUFSIZE;
     HIP_TRY(hipMalloc(&s->d_inwin, (size_t)BRX_IN_WINDOW + 16));
     HIP_TRY(hipMalloc(&s->d_buf, bufsize));
-    HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 8u)); // the slab and its checkpoint
-    s->d_slab_bak = s->d_slab + BRX_SCRATCH_WORDS;
+    HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u));
     const size_t rec_bytes = (sizeof(BrxResume) + 255u) & ~(size_t)255;
     uint8_t *small = nullptr;
     HIP_TRY(hipMalloc(&small, 2 * rec_bytes + 1024));
     s->d_rec = (BrxResume *)small;
-    s->d_rec_bak = (BrxResume *)(small + rec_bytes);
     s->d_pool = (BrxSlabPool *)(small + 2 * rec_bytes);
     s->d_bitmap = (uint32_t *)(small + 2 * rec_bytes + 256);
     s->d_meta = (uint64_t *)(small + 2 * rec_bytes + 512);
@@ -1155,7 +1126,7 @@ static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap) {
 // Move the input window up to the cursor (when that frees at least 1 MiB) and fill it from the source.
 static int bounded_refill(brx_stream *s) {
     brx_ctx *c = s->ctx;
-    if (s->in_cursor >= BRX_IN_KEEP + (1u << 20)) {
+    if (s->in_cursor >= BRX_IN_KEEP + s->in_window / 8u) {
         const size_t delta = (s->in_cursor - BRX_IN_KEEP) & ~(size_t)15, keep = s->in_fill - delta;
         for (size_t done = 0; done < keep; done += delta) { // forward, in pieces no longer than the move: no overlap
             const size_t piece = std::min(delta, keep - done);
@@ -1165,8 +1136,8 @@ static int bounded_refill(brx_stream *s) {
         s->in_cursor -= delta;
         s->in_slide_pending += delta;
     }
-    while (!s->src_eof && s->in_fill < BRX_IN_WINDOW) {
-        const size_t got = stream_pull(s, s->stage.data(), std::min<size_t>(s->stage.size(), BRX_IN_WINDOW - s->in_fill));
+    while (!s->src_eof && s->in_fill < s->in_window) {
+        const size_t got = stream_pull(s, s->stage.data(), std::min<size_t>(s->stage.size(), s->in_window - s->in_fill));
         if (got == 0) {
             s->src_eof = true;
             break;
@@ -1200,22 +1171,32 @@ static int bounded_step(brx_stream *s) {
         s->shift = new_shift;
     }
     // the input side: keep at least half a window of compressed bytes in front of the cursor while the source has any
-    if (!s->src_eof && s->in_fill - s->in_cursor < BRX_IN_WINDOW / 2u) {
+    const uint64_t pos0 = s->pos;
+    if (!s->src_eof && (s->in_fill - s->in_cursor < s->in_window / 2u || s->no_progress)) {
+        const size_t fill0 = s->in_fill; // (a slice that paused at its in_low comes here too)
+        const uint64_t slide0 = s->in_slide_pending;
         int rc = bounded_refill(s);
         if (rc) return rc;
+        if (s->no_progress && s->in_fill == fill0 && s->in_slide_pending == slide0) s->stalled = true;
     }
+    s->no_progress = false;
     const uint64_t cap_abs = std::min<uint64_t>(s->shift + bufsize, BRX_STREAM_LIMIT);
     const uint64_t pause_at = s->pos + BRX_BOUNDED_CHUNK;
     uint8_t *virt = (uint8_t *)((uintptr_t)s->d_buf - (uintptr_t)s->shift); // address of output byte 0, were it still resident
-    for (int attempt = 0;; attempt++) {
-        // checkpoint: the record, the slab's claim bit and the slab as they are before the slice
-        HIP_TRY(hipMemcpyAsync(s->d_rec_bak, s->d_rec, sizeof(BrxResume), hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(s->d_bitmap + 1, s->d_bitmap, 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(s->d_slab_bak, s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u, hipMemcpyDeviceToDevice, c->stream));
+    {
         uint64_t meta[4] = {0, s->in_fill, 0, cap_abs};
         HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
-        const uint64_t pz[2] = {pause_at, s->in_slide_pending};
-        HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), pz, 16, hipMemcpyHostToDevice, c->stream));
+        // While the source has more, the slice pauses a margin (1/32 of the window: 256 KiB) short of the resident end -- at a
+        // command or meta-block boundary, or in the middle of a literal run -- and a segment that still runs into that end (a
+        // header, an uncompressed block, one whole command of the C++ loop) is taken back by the kernel itself: the slice
+        // pauses in FRONT of it (brx_kernels.hip, resumable mode).  So UnexpectedEOF comes out of a slice only when it was told
+        // that the resident input is all there is: the source is dry -- or `stalled`: the last slice paused where it had started
+        // although the window could not be moved or filled any further (one item that needs more input than the window holds, or
+        // a real UnexpectedEOF of the format); this slice reports what it finds.
+        const size_t margin = s->in_window / BRX_IN_MARGIN_DIV;
+        const uint64_t in_low = s->src_eof || s->in_fill <= margin || s->stalled ? ~0ull : 8ull * (s->in_fill - margin);
+        const uint64_t pz[3] = {pause_at, s->in_slide_pending, in_low};
+        HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), pz, 24, hipMemcpyHostToDevice, c->stream));
         int rc = launch(c, c->stream, false, s->d_inwin, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
                         (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
         if (rc) return rc;
@@ -1224,27 +1205,8 @@ static int bounded_step(brx_stream *s) {
         HIP_TRY(hipMemcpyAsync(&cur, &s->d_rec->lds[BRX_RESUME_CURSOR_WORD], 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const int32_t st = (int32_t)(res[1] & 0xffffffffu);
-        if (st == BRX_UNEXPECTED_EOF && !s->src_eof && attempt < 64) {
-            // The slice ran into the end of the RESIDENT input while the source has more (or is not known to be dry).  Put
-            // the decoder back to where it stood before the slice -- its record, its slab -- bring more input in, and run the
-            // slice again: the output it wrote is written once more.  (A slice that still fails with a full window in front of
-            // the cursor is a real UnexpectedEOF of the format -- or a single command of more than ~7 MiB of compressed bytes,
-            // which this reader does not take.)
-            HIP_TRY(hipMemcpyAsync(s->d_rec, s->d_rec_bak, sizeof(BrxResume), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(s->d_bitmap, s->d_bitmap + 1, 4, hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(s->d_slab, s->d_slab_bak, (size_t)BRX_SCRATCH_WORDS * 4u, hipMemcpyDeviceToDevice, c->stream));
-            const size_t fill0 = s->in_fill;
-            const uint64_t slide0 = s->in_slide_pending;
-            if ((rc = bounded_refill(s))) return rc;
-            if (s->in_fill != fill0 || s->in_slide_pending != slide0) continue; // more is resident now
-            if (!s->src_eof) { // a full window in front of the cursor and still not enough
-                s->finished = true;
-                s->status = st;
-                return BRX_SUCCESS;
-            }
-            continue; // the source turned out to be dry: once more, and the UnexpectedEOF is real
-        }
         s->in_slide_pending = 0;
+        s->stalled = false;
         if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // one command larger than the slack (caller falls back)
         s->pos = res[0];
         if (st != BRX_PAUSED) {
@@ -1256,7 +1218,10 @@ static int bounded_step(brx_stream *s) {
                 else s->src_eof = true;
             }
         } else {
-            s->in_cursor = (size_t)(cur >> 3);
+            const size_t cursor = (size_t)(cur >> 3);
+            s->no_progress = cursor == s->in_cursor && res[0] == pos0;
+            if (res[0] < pause_at && cur < in_low) c->stream_short_slices++; // (paused in front of something that did not fit what was resident)
+            s->in_cursor = cursor;
         }
         return BRX_SUCCESS;
     }

@@ -88,15 +88,18 @@ struct BrxDeviceTables {
 // (its LDS) here and reports BRX_PAUSED; the next launch picks up from it against a slid output window.
 // The compressed input is a sliding window too (the reference pulls its input through a BufReader as it decodes,
 // src/bitreader/mod.rs:21-53): in_off[sid] .. in_off[sid + 1] is what is resident NOW; when the host has moved the window up by
-// `in_slide` bytes (a multiple of 16) since the last slice, the parked cursor moves down with it.  A slice that runs into the end
-// of the resident input reports UnexpectedEOF like any truncated stream; the host, knowing that more input exists, puts the
-// record back to what it was before the slice and runs it again with more input resident (brx_api.cpp, bounded_step).
+// `in_slide` bytes (a multiple of 16) since the last slice, the parked cursor moves down with it.  A slice pauses early when its
+// cursor comes within a margin of the resident end while the source has more (`in_low`); one that still runs into the end -- a
+// single command or header longer than the margin -- reports UnexpectedEOF like any truncated stream, and the host, knowing that
+// more input exists, puts the record back to what it was before the slice and runs it again with more input resident
+// (brx_api.cpp, bounded_step).
 struct BrxResume {
     uint32_t state;  // 0 = fresh stream, 1 = paused (lds valid), 2 = finished
     uint32_t phase;  // where to resume (kernel-internal)
     uint64_t pause_at;
     uint64_t in_slide;
-    uint64_t spare;
+    uint64_t in_low; // pause as well once the input cursor (bits from the window's first dword) is at or beyond this: the source has
+                     // more, and what is resident ends soon (~0 = the resident input is all there is)
     uint32_t lds[2560];
 };
 #define BRX_RESUME_CURSOR_WORD (2432u + 3u) // index into BrxResume::lds of the parked input cursor (Lds::st[3..4], bits from the

@@ -237,19 +237,25 @@ __device__ void g2_build_lengths(G2Lds &L, const u32 *hist, u32 n) {
         for (u32 k = 0; k <= 16u; k++) bl[k] = 0;
         L.dep_int[m - 2u] = 0;
         for (u32 k = m - 2u; k-- > 0u;) { const u32 d = L.dep_int[L.par_int[k]] + 1u; L.dep_int[k] = (u8)(d > 60u ? 60u : d); }
-        u32 overflow = 0;
         for (u32 r = 0; r < m; r++) {
             u32 d = L.dep_int[L.par_leaf[r]] + 1u;
-            if (d > 15u) { d = 15u; overflow++; }
+            if (d > 15u) d = 15u;
             bl[d]++;
         }
-        while ((int)overflow > 0) {  // zlib gen_bitlen: move one leaf down from the deepest level with room, pair it with an overflowed one
+        // Leaves clamped to 15 bits over-subscribe the code: the Kraft sum in units of 2^-15 is above 2^15.  zlib's repair step --
+        // move one leaf down from the deepest level with room (bits -> bits + 1) and hang one 15-bit leaf next to it -- takes
+        // exactly one unit off: -2^(14-bits) for the leaf moved, -1 + 2^(14-bits) for the one re-hung.  As many steps as units.
+        // (Until round 4 the steps were counted zlib's way, "overflow -= 2", but over the LEAVES only -- zlib counts internal nodes
+        // too -- so codes of meta-blocks of 512 KiB and more, where depths beyond 15 appear, stayed over-subscribed: invalid streams.)
+        u32 kraft = 0;
+        for (u32 d = 1; d <= 15u; d++) kraft += bl[d] << (15u - d);
+        while (kraft > 32768u) {
             u32 bits = 14u;
             while (bl[bits] == 0u) bits--;
             bl[bits]--;
             bl[bits + 1u] += 2u;
             bl[15]--;
-            overflow -= 2u;
+            kraft--;
         }
         // the rarest symbols get the longest codes
         u32 r = 0;

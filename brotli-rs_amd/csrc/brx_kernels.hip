@@ -354,8 +354,11 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_IACTAB 36  // (2 words) BrxDeviceTables::iac for the assembly loop
 #define ST_POOL 38    // (2 words) const BrxSlabPool *
 #define ST_MIRROR 40  // (2 words) host-visible mirror of the output slot, or 0
+#define ST_PAUSE_AT 43 // (2 words) resumable mode: seg_frame stops between two meta-blocks once this many bytes are out (else ~0)
+#define ST_IN_LOW 45   // (2 words) ... or once the input cursor is this far (BrxResume::in_low; else ~0)
 #define ST_NEED 42    // after a header whose tables spilled: words of table memory the meta-block needs (Dec::need_peak)
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
+#define SEG_PAUSED 101u      // seg_frame (resumable mode): stopped between two meta-blocks, ST_PAUSE_AT reached
 // generic_commands modes / return value, and the Lds::mbw slots that carry a parked command
 #define HC_WHOLE 0u      // run the whole meta-block
 #define HC_START 1u      // first insert&copy symbol only, then park at R1
@@ -1917,8 +1920,17 @@ __device__ __noinline__ u32 seg_frame() {
     } else if (rfl(s.st[ST_ISLAST]) != 0u) {
         finished = true; // back from the command loop of the last meta-block: MetaBlockEnd :2146-2153
     }
+    const u64 pause_at = get64(s, ST_PAUSE_AT), in_low = get64(s, ST_IN_LOW);
+    u64 mb_start = ~0ull;
     while (!finished) {
         if (++d.wd > d.wd_limit) { rc = ST_WATCHDOG; break; }
+        // (resumable mode: uncompressed and metadata blocks are handled right here, one after the other -- a stream made of them
+        // alone would run through all the resident input and out of the output window without ever reaching a pause point)
+        if ((u64)d.pos >= pause_at || d.bitpos >= in_low) {
+            dec_store(d, s);
+            return SEG_PAUSED;
+        }
+        mb_start = d.bitpos;
         u32 is_last;
         if (!in_bits(d, 1, is_last)) { rc = ST_EOF; break; } // parse_is_last :420
         if (is_last) {
@@ -1972,6 +1984,15 @@ __device__ __noinline__ u32 seg_frame() {
             }
         }
         if (is_last) break; // MetaBlockEnd :2146-2153
+    }
+    if (rc == ST_EOF && in_low != ~0ull && mb_start != ~0ull) {
+        // (resumable mode, the source has more input than is resident: what looks like the end of the stream inside this
+        // meta-block's framing -- an uncompressed block longer than what is left, say -- is the end of the WINDOW.  Back to the
+        // meta-block's first bit -- nothing of it has been written yet -- and pause there; if it still fails with all the input
+        // the host can make resident, the host asks again with in_low = ~0 and gets the status)
+        in_seek(d, mb_start);
+        dec_store(d, s);
+        return SEG_PAUSED;
     }
     if (rc == ST_OK) { // StreamEnd :2155-2167
         if (in_byte_tail(d)) rc = ST_NON_ZERO_TRAILER_BIT;
@@ -2160,6 +2181,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if (lane == 0u) {
                 s.st[ST_STARTED] = 0u; s.st[ST_ISLAST] = 0u; s.st[ST_MLEN] = 0u;
                 s.st[ST_IACTAB] = (u32)(uintptr_t)a.t.iac; s.st[ST_IACTAB + 1] = (u32)((u64)(uintptr_t)a.t.iac >> 32);
+                s.st[ST_PAUSE_AT] = 0xffffffffu; s.st[ST_PAUSE_AT + 1] = 0xffffffffu;
+                s.st[ST_IN_LOW] = 0xffffffffu; s.st[ST_IN_LOW + 1] = 0xffffffffu;
             }
             if (lane < 32u) s.pad[lane] = 0u;
         }
@@ -2168,7 +2191,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             // ---- resumable mode: one stream decoded in slices against a sliding output window (brx_api.cpp, streaming
             // Read facade).  Pauses only between the out-of-line segments, where the whole state sits in LDS.
             BrxResume *rec = a.resume + sid;
-            enum { PH_FRAME = 0, PH_LOOP = 1 };
+            enum { PH_FRAME = 0, PH_LOOP = 1, PH_HEADER = 2, PH_ASMEXIT = 3 };
             u32 phase = PH_FRAME;
             u32 st = 0;
             if (rfl(rec->state) == 1u) {
@@ -2194,29 +2217,64 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     s.st[31] = (u32)wdl; s.st[32] = (u32)(wdl >> 32);
                 }
                 phase = rfl(rec->phase);
-                st = phase == PH_LOOP ? HC_CONTINUE : 0u;
+                st = (phase == PH_LOOP || phase == PH_ASMEXIT) ? HC_CONTINUE : 0u;
             }
-            const u64 pause_at = rec->pause_at;
+            const u64 pause_at = rec->pause_at, in_low = rec->in_low;
+            if (lane == 0u) {
+                s.st[ST_PAUSE_AT] = (u32)pause_at; s.st[ST_PAUSE_AT + 1] = (u32)(pause_at >> 32);
+                s.st[ST_IN_LOW] = (u32)in_low; s.st[ST_IN_LOW + 1] = (u32)(in_low >> 32);
+            }
             bool paused = false;
             for (;;) {
                 if (phase == PH_FRAME) {
-                    if ((u64)rfl(s.st[10]) >= pause_at && rfl(s.st[ST_STARTED]) != 0u && rfl(s.st[ST_ISLAST]) == 0u) { paused = true; break; }
+                    if (((u64)rfl(s.st[10]) >= pause_at || get64(s, 3) >= in_low) && rfl(s.st[ST_STARTED]) != 0u && rfl(s.st[ST_ISLAST]) == 0u) { paused = true; break; }
                     st = seg_frame();
+                    if (st == SEG_PAUSED) { paused = true; break; }
                     if (st != SEG_NEED_HEADER) break;
+                    phase = PH_HEADER;
+                }
+                // A segment that runs into the end of the RESIDENT input while the source has more (in_low != ~0) has not met the end
+                // of the stream: the slice pauses IN FRONT of it and the next one, with more input resident, runs it again.  The
+                // header stores its cursor only when it succeeds; a command of the C++ loop parks its state only when it succeeds too,
+                // but leaves Lds::st as it was when it failed -- so st as it stood before the call (one word per lane of a
+                // register) goes back, bar the flush cursor: what the failed call has flushed are good bytes, and they stay flushed.
+#define BRX_ST_BACKUP() const u32 st_bak = s.st[lane < 48u ? lane : 0u]
+#define BRX_ST_RESTORE() do { if (lane < 48u && lane != 12u && lane != 20u && lane != 21u) s.st[lane] = st_bak; } while (0) /* (a slab claimed meanwhile stays claimed) */
+                if (phase == PH_HEADER) {
+                    BRX_ST_BACKUP();
                     st = cold_header();
-                    if (st) break;
-                    st = generic_commands(HC_START);
+                    if (st == ST_OK) st = generic_commands(HC_START);
+                    if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); paused = true; break; }
+                    if (st != HC_CONTINUE && st != ST_OK) break;
                     phase = PH_LOOP;
                 }
                 while (st == HC_CONTINUE) {
-                    if ((u64)rfl(s.st[10]) >= pause_at) { paused = true; break; }
-                    if (rfl(s.mbw[MBW_ASM]) != 0u) {
-                        const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
-                        st = generic_commands(HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u)));
+                    u32 r;
+                    if (phase == PH_ASMEXIT) { // resumed right behind an exit of the assembly loop: the command it handed back is due
+                        r = rfl(s.mbw[MBW_EXIT]);
+                        phase = PH_LOOP;
                     } else {
-                        st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
+                        if ((u64)rfl(s.st[10]) >= pause_at || get64(s, 3) >= in_low) { paused = true; break; }
+                        if (rfl(s.mbw[MBW_ASM]) == 0u) {
+                            BRX_ST_BACKUP();
+                            st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
+                            if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; paused = true; break; }
+                            continue;
+                        }
+                        r = sw_loop ? asm_commands_sw() : asm_commands();
+                        // (the assembly loop knows no pause: it runs until something unusual comes up -- at the latest the last dwords
+                        // of the RESIDENT input, and the command it hands back there may well straddle that end.  While the source
+                        // has more the slice pauses HERE, in front of that command, instead of failing in it)
+                        if (get64(s, 3) >= in_low) { phase = PH_ASMEXIT; paused = true; break; }
+                    }
+                    {
+                        BRX_ST_BACKUP();
+                        st = generic_commands(HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u)));
+                        if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
                     }
                 }
+#undef BRX_ST_BACKUP
+#undef BRX_ST_RESTORE
                 if (paused || st) break;
                 phase = PH_FRAME;
             }

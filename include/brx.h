@@ -136,7 +136,9 @@ enum {
     BRX_OPTION_SMALL_BYTES = 9,   /* compressed size up to which a stream goes to the lean instance first (default 128, at most
                                      500; 0 = no lean instance) */
     BRX_OPTION_SMALL_WAVES = 10,  /* waves per CU of the lean instance's grid (default 32) */
-    BRX_OPTION_TRACE = 11         /* 1 = every launch records when and where each stream was decoded (brx_last_trace); default 0 */
+    BRX_OPTION_TRACE = 11,        /* 1 = every launch records when and where each stream was decoded (brx_last_trace); default 0 */
+    BRX_OPTION_READER_WINDOW = 12 /* compressed bytes a bounded / pulled stream keeps resident on the device (default 8 MiB; 1 .. 256
+                                     MiB): streams started afterwards */
 };
 int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
 
@@ -169,7 +171,9 @@ const char *brx_last_error(void);
  *   5        streams the lean instance (short streams, 32 per CU, launched in front of the regular kernel) left to the regular
  *            kernel -- the ones above its size limit plus the short ones it gave up on (any error, block switches, large tables)
  *   6        streams that were handed up at a LATER meta-block, with their decoder state (resumed there, not restarted)
- *   7        output bytes decoded twice because of hand-overs (0 = every such stream was resumed where it stood) */
+ *   7        output bytes decoded twice because of hand-overs (0 = every such stream was resumed where it stood)
+ *   8        (since the context was made) slices of bounded / pulled streams that paused in front of an item -- a header, an
+ *            uncompressed block, a command -- that the RESIDENT input did not hold, to run it with more (brx_stream_new_reader) */
 double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Diagnostics (BRX_OPTION_TRACE = 1): 4 words per stream of the most recent launch -- start and end of its decode on the GPU's
@@ -247,9 +251,10 @@ brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
  * (src/lib.rs:398-410), which pulls its input through a BufReader as it decodes (src/bitreader/mod.rs:21-53).  `read` is called
  * -- from inside brx_stream_read, on the caller's thread -- for up to `cap` more compressed bytes; it returns how many it gave,
  * 0 = end of input (and is not called again).  Compressed input is held in a sliding 8 MiB device window the same way the
- * output is: a stream of any length decodes with about 35 MiB of buffers on the device and 1 MiB on the host.  A slice that runs
- * out of resident input is rolled back and run again with more; limits: one command may not produce more than the reader's
- * slack (1 MiB; such a stream needs brx_stream_new) nor consume more than ~7 MiB of compressed bytes. */
+ * output is (BRX_OPTION_READER_WINDOW): a stream of any length decodes with about 32 MiB of buffers on the device and 1 MiB on the
+ * host.  A slice pauses before its resident input runs out -- in front of the header, uncompressed block or command that would
+ * not fit -- and goes on once more is resident.  Limits: one command may not produce more than the reader's slack (1 MiB; such a
+ * stream needs brx_stream_new) nor consume more compressed bytes than the window holds. */
 typedef size_t (*brx_read_fn)(void *user, uint8_t *buf, size_t cap);
 brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, void *user);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);

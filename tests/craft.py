@@ -271,8 +271,11 @@ class MetaBlock:
     a near-uniform insert&copy code over the symbols the commands use and a uniform distance code over the 64 symbols
     of NPOSTFIX = NDIRECT = 0.  Commands: (literal bytes, copy_len, distance) -- distance None = no copy (last command)."""
 
-    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0):
+    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0, lit_lengths=None, single_iac=False):
         self.commands, self.mlen, self.npostfix, self.ndirect = commands, mlen, npostfix, ndirect
+        self.lit_lengths = lit_lengths  # code lengths of the 256 literals (default: 8 bits each)
+        self.single_iac = single_iac    # keep a ONE-symbol insert&copy code (zero bits per symbol; such a meta-block runs in the
+                                        # HIP decoder's C++ command loop, never in the assembly loop)
 
     def emit(self, b, is_last, out_len_hint):
         mlen = self.mlen if self.mlen is not None else out_len_hint
@@ -290,11 +293,15 @@ class MetaBlock:
         b.put(0, 2)   # context mode LSB6 (irrelevant: one tree)
         b.put(0, 1)   # NTREESL = 1
         b.put(0, 1)   # NTREESD = 1
-        lit = complex_code(b, [8] * 256)
+        lit = complex_code(b, self.lit_lengths or [8] * 256, zero_run_17=self.lit_lengths is not None)
         syms = sorted({iac_symbol(len(l), c if c else 2)[0] for l, c, d in self.commands})
-        if len(syms) == 1:
+        if len(syms) == 1 and not self.single_iac:
             syms.append(syms[0] + 1 if syms[0] + 1 < 704 else syms[0] - 1)  # (a 1-symbol insert&copy code never enters the asm loop)
-        iac = complex_code(b, uniform_lengths(704, syms), zero_run_17=True)
+        if len(syms) == 1:
+            simple_code(b, syms, 10)
+            iac = {syms[0]: (0, 0)}
+        else:
+            iac = complex_code(b, uniform_lengths(704, syms), zero_run_17=True)
         dalpha = 16 + self.ndirect + (48 << self.npostfix)
         dist = complex_code(b, uniform_lengths(dalpha), zero_run_17=False)
         for lits, cl, d in self.commands:
@@ -649,7 +656,7 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
     return b.bytes(), bytes(out)
 
 
-def periodic_stream_parts(seed, commands=700, literals=90):
+def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac=False):
     """A stream of ANY length in constant memory: (prefix, unit, final, unit_output).  stream = prefix + unit * K + final decodes
     to unit_output * K.  The prefix is the stream header and an empty metadata block (which pads to a byte boundary); a unit is
     one compressed meta-block -- `commands` x (`literals` random bytes at 8 bits each, then a copy of 4 from inside the unit,
@@ -666,6 +673,34 @@ def periodic_stream_parts(seed, commands=700, literals=90):
     stream_header(b, 22)
     empty_metadata(b)
     prefix = b.bytes()
+    if raw and literals > (1 << 20):
+        # ONE uncompressed meta-block of literals - 2^20 bytes (5 length nibbles): no pause point inside it, and longer than the margin a
+        # slice of the pulled reader keeps to the end of its resident input -- some of them run into that end
+        data = rng.randbytes(literals - (1 << 20))
+        b = Bits()
+        b.put(0, 1); b.put(1, 2); b.put(len(data) - 1, 20); b.put(1, 1)  # ISLAST = 0, MNIBBLES = 5, MLEN - 1, ISUNCOMPRESSED
+        b.put(0, (-b.n) % 8)
+        b.put_bytes(data)
+        return prefix, b.bytes(), b"\x03", data
+    if raw and literals > 65536:
+        # one command of `literals` bytes + a copy of 4, the literals drawn from the two 15-BIT symbols of a code with lengths
+        # 1, 2, .., 14, 15, 15: almost two compressed bytes per output byte, and a single command far longer than the margin a
+        # slice of the pulled reader keeps to the end of its resident input
+        lens = [0] * 256
+        for k in range(14):
+            lens[k] = k + 1
+        lens[14] = lens[15] = 15
+        data = bytes(rng.choice((14, 15)) for _ in range(literals))
+        b = Bits()
+        MetaBlock([(data, 4, 8)], mlen=len(data) + 4, lit_lengths=lens, single_iac=single_iac).emit(b, False, len(data) + 4)
+        empty_metadata(b)
+        return prefix, b.bytes(), b"\x03", data + data[-8:-4]
+    if raw:  # (raw=True: the unit is one UNCOMPRESSED meta-block of 64 KiB -- more compressed bytes than output bytes)
+        data = rng.randbytes(1 << 16)
+        b = Bits()
+        raw_block(b, data)
+        assert b.n % 8 == 0
+        return prefix, b.bytes(), b"\x03", data
     cmds, out = [], bytearray()
     for k in range(commands):
         lits = rng.randbytes(literals)

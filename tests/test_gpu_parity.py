@@ -299,6 +299,101 @@ def test_pulled_reader_holds_a_window_of_input_and_of_output(ctx, tmp_path):
     assert int(out.stdout.split()[3]) >= 49 * len(parts[3])  # (the prefix: at least every whole unit before the cut, bar the last)
 
 
+def _periodic_source(parts, K, chunk=250001):
+    """A file-like reader over prefix + unit x K + final (tests/craft.py periodic_stream_parts), never materialised."""
+    import io
+    p_, u_, f_ = parts[:3]
+
+    class Src(io.RawIOBase):
+        def __init__(self):
+            self.at, self.total = 0, len(p_) + len(u_) * K + len(f_)
+
+        def read(self, n=-1):
+            n = min(n if n >= 0 else 1 << 20, self.total - self.at, chunk)
+            out = bytearray()
+            while len(out) < n:
+                a = self.at + len(out)
+                if a < len(p_):
+                    piece = p_[a:a + n - len(out)]
+                elif a < len(p_) + len(u_) * K:
+                    o = (a - len(p_)) % len(u_)
+                    piece = u_[o:o + n - len(out)]
+                else:
+                    o = a - len(p_) - len(u_) * K
+                    piece = f_[o:o + n - len(out)]
+                out += piece
+            self.at += len(out)
+            return bytes(out)
+
+    return Src()
+
+
+def _read_periodic(d, unit_out):
+    got, two = 0, unit_out * 2
+    while True:
+        chunk = d.read(len(unit_out))
+        if not chunk:
+            return got
+        o = got % len(unit_out)
+        assert chunk == two[o:o + len(chunk)], got
+        got += len(chunk)
+
+
+def test_pulled_reader_on_input_heavy_streams():
+    """(a) Uncompressed 64-KiB meta-blocks only: no command boundary ever comes -- the framing segment itself has to stop between
+    two meta-blocks when the slice is full or the resident input runs low.  (b) Commands of 200 KiB of literals at 15 bits each
+    (375 KiB of input per command, two compressed bytes per output byte): the loop hands back inside a literal run, so a slice
+    pauses in the MIDDLE of such a command when the resident input runs low.  (c) Uncompressed meta-blocks of 600 KiB under a
+    2 MiB input window: nothing can pause inside one and it is longer than the margin a slice keeps to the resident end -- the
+    framing segment pauses in front of the one that does not fit.  (d) The commands of (b) in meta-blocks that run in the C++ loop
+    (a whole command per call): one of them straddles the end of the resident input (UnexpectedEOF like any truncated stream) -- the
+    kernel takes the command back, the slice pauses in front of it and it runs again with more input resident; the context counts
+    those.  (e) 6 MiB of text in
+    meta-blocks of 2 MiB under a 1 MiB window: the slice pauses behind the assembly loop's exit at the end of the resident input.
+    All bit-exact."""
+    import craft
+    from brotli_rs_amd import brx
+    c2 = brx_knobs.context(0)
+    try:
+        parts = craft.periodic_stream_parts(13, raw=True)
+        d = brx.Decompressor(_periodic_source(parts, 640), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 640 * len(parts[3])  # 40 MiB
+        d.close()
+        parts = craft.periodic_stream_parts(14, raw=True, literals=200 << 10)
+        assert oracle.decode(parts[0] + parts[1] * 2 + parts[2], 0, cap=1 << 20)[1] == parts[3] * 2
+        d = brx.Decompressor(_periodic_source(parts, 150), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 150 * len(parts[3])  # 30 MiB out of 55 MiB
+        d.close()
+        parts = craft.periodic_stream_parts(15, raw=True, literals=(1 << 20) + 600 * 1024 + 77)
+        assert oracle.decode(parts[0] + parts[1] * 2 + parts[2], 0, cap=2 << 20)[1] == parts[3] * 2
+        c2.set_option("reader_window", 2 << 20)
+        d = brx.Decompressor(_periodic_source(parts, 60), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 60 * len(parts[3])  # 35 MiB: the framing segment pauses in FRONT of a block that does not fit
+        d.close()
+        # (d) the commands of (b) in meta-blocks that do NOT qualify for the assembly loop (a one-symbol insert&copy code): the C++
+        # loop takes a whole command per call, 375 KiB of input with a margin of 64 KiB to the end of a 2 MiB window
+        parts = craft.periodic_stream_parts(16, raw=True, literals=200 << 10, single_iac=True)
+        assert oracle.decode(parts[0] + parts[1] * 2 + parts[2], 0, cap=1 << 20)[1] == parts[3] * 2
+        before = c2.stream_short_slices()
+        d = brx.Decompressor(_periodic_source(parts, 60), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 60 * len(parts[3])  # 12 MiB out of 22 MiB
+        d.close()
+        assert c2.stream_short_slices() > before, (before, c2.stream_short_slices())
+        # (e) text in meta-blocks of 2 MiB (the adaptive generator) under a 1 MiB window: the assembly loop runs up to the end of the
+        # resident input and hands the straddling command back; the slice pauses in front of it
+        import io
+        src = (_read("lcet10.txt") + _read("plrabn12.txt") + _read("alice29.txt")) * 6
+        st = c2.generate_batch([src], metablock_bytes=2 << 20, adaptive=True)[0]
+        assert len(st) > (2 << 20) and oracle.decode(st, 0, cap=len(src) + 64)[1] == src  # (round 4: the generator's codes of meta-blocks >= 512 KiB were over-subscribed)
+        c2.set_option("reader_window", 1 << 20)
+        d = brx.Decompressor(io.BytesIO(st), c2, streaming=True)
+        out = d.read()
+        d.close()
+        assert out == src
+    finally:
+        c2.close()
+
+
 def test_python_decompressor_streaming_mode(ctx):
     """brx.Decompressor(reader, streaming=True): pulled input; trailing bytes behind the stream's end are the reference's
     ExpectedEndOfStream even when they only arrive after the decoder has finished with what was resident."""
