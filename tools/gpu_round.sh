@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=${TAG:-r01}
 echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-echo "== pytest gpu, level 1 next to the regular kernel on every launch"; BRX_FORCE_OVERLAP=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+echo "== pytest gpu, classification pre-pass + all levels next to each other on every launch (plan B)"; BRX_PLAN_B=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 echo "== bench"; timeout 600 python bench.py --steps ${STEPS:-10} --warmup 2 ${BENCH_ARGS:-} 2>&1 | tail -3 | tee gpurun_out/bench_${TAG}.json
 if [ "${PROF:-1}" = "1" ]; then
   cd /tmp && export TMPDIR=/tmp
