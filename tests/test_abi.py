@@ -116,3 +116,11 @@ def test_assembly_loop_passes_the_wait_state_lint():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py"), os.path.join(ROOT, "brotli-rs_amd", "csrc", "brx_lens.S")],
                        capture_output=True, text=True, env=dict(os.environ, ASM_DEFS="LDS_LENS=8960"))
     assert r.returncode == 0 and "0 finding(s)" in r.stdout, r.stdout + r.stderr
+
+
+def test_python_option_numbers_are_the_header_s():
+    """brx.OPTIONS (ctypes side) names exactly the BRX_OPTION_* values of include/brx.h."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "brx.h")).read()
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"^\s+BRX_OPTION_([A-Z_]+)\s*=\s*(\d+),?\s", hdr, flags=re.M)}
+    assert enum == brx.OPTIONS, (enum, brx.OPTIONS)

@@ -254,6 +254,32 @@ def test_truncation_sweep_through_the_first_headers(levels):
         c2.close()
 
 
+def test_per_stream_trace_of_a_launch():
+    """BRX_OPTION_TRACE: one record per stream -- start < end on the GPU's realtime counter, the level of the kernel that decoded
+    it, its workgroup; streams the lean instance took have all-zero records.  Nothing is recorded (and the call fails cleanly)
+    without the option."""
+    from brotli_rs_amd import brx
+    c2 = brx_knobs.context(0)
+    try:
+        streams = [_read("alice29.txt.compressed"), _read("mapsdatazrh.compressed"), _read("quickfox.compressed"), _read("monkey.compressed")] * 8
+        c2.decode_batch(streams, 1 << 19)
+        with pytest.raises(brx.BrxError):
+            c2.last_trace(len(streams))
+        c2.set_option("trace", 1)
+        outs, status, out_len = c2.decode_batch(streams, 1 << 19)
+        assert not any(int(x) for x in status)
+        t = c2.last_trace(len(streams))
+        for i in range(len(streams)):
+            if i % 4 == 2:  # quickfox: 47 bytes, the lean instance
+                assert not t[i].any()
+                continue
+            assert 0 < t[i, 0] < t[i, 1], (i, t[i])
+            assert int(t[i, 2]) >> 32 == (2 if i % 4 == 1 else 0), (i, int(t[i, 2]) >> 32)  # (the context's second launch: it classifies first now, mapsdatazrh runs at its own level)
+            assert (int(t[i, 3]) & 0xffffffff) < (int(t[i, 3]) >> 32)  # workgroup index < grid size
+    finally:
+        c2.close()
+
+
 def _level1_stream(seed=77, n_cmds=500):
     """(compressed, expected) of a stream whose one meta-block needs more table memory than the regular kernel holds and no more
     than level 1 does (tests/craft.py growing_tables_stream: 105 literal trees).  (Until round 4 lcet10.txt was that stream: with
