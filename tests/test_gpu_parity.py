@@ -1163,7 +1163,7 @@ def test_pinned_buffers_are_used_in_place(ctx):
 def test_bounded_memory_stream_of_70_MiB(ctx):
     """The Read facade in bounded mode: a 70 MiB stream (4.4 MiB compressed: chosen automatically,
     inputs >= 4 MiB) decoded slice by slice by the resumable kernel into a ~21 MiB sliding device window; the reader sees
-    the bytes as the slices complete.  Device memory in use must stay under 40 MiB above the baseline (22 MiB of output window, 8 MiB of input window, the slab and its checkpoint -- whatever the stream's length, on both sides).  Also a small
+    the bytes as the slices complete.  Device memory in use must stay under 40 MiB above the baseline (22 MiB of output window, 8 MiB of input window, the slab -- whatever the stream's length, on both sides).  Also a small
     stream forced into bounded mode, and a corrupted long stream: everything decoded before the error is served, then
     the oracle's error."""
     import craft
