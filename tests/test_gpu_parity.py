@@ -254,6 +254,37 @@ def test_truncation_sweep_through_the_first_headers(levels):
         c2.close()
 
 
+@pytest.mark.parametrize("n_each", [1, 3, 40])
+def test_plan_b_with_every_class_in_one_small_batch(n_each):
+    """Launch plan B (forced) on batches that hold every class at once -- a short stream for the lean instance, alice29 (regular),
+    a crafted level-1 stream, mapsdatazrh (level 2), a crafted 256-tree stream (level 3), a reject vector -- from one of each to
+    forty of each: the per-stream trace says which instance decoded what (level 1 joins level 2 when classes mix), everything
+    is the oracle's."""
+    import craft
+    c2 = brx_knobs.context(0, levels=2, trace=1)
+    try:
+        l1 = _level1_stream(91, 300)[0]
+        l3 = craft.growing_tables_stream(92, [250], mode=1, n_cmds=200)[0]
+        kinds = [_read("quickfox.compressed"), _read("alice29.txt.compressed"), l1, _read("mapsdatazrh.compressed"), l3, bytes.fromhex("a103")]
+        streams = [k_ for _ in range(n_each) for k_ in kinds]
+        want = [oracle.decode(s_, 0, cap=1 << 19) for s_ in streams]
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, 1 << 19)
+            bad = [(i, w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if w[0] != st or (st == 0 and o != w[1])]
+            assert not bad, bad[:8]
+            t = c2.last_trace(len(streams))
+            levels = [int(t[i, 2]) >> 32 for i in range(len(streams))]
+            for i in range(len(streams)):
+                k = i % len(kinds)
+                if k == 0:
+                    assert not t[i].any()  # the lean instance
+                else:
+                    assert levels[i] == {1: 0, 2: 2, 3: 2, 4: 3, 5: 0}[k], (i, k, levels[i])
+            assert c2.last_wide_streams(1) == 3 * n_each and c2.last_wide_streams(3) == n_each and c2.last_redo_bytes() == 0
+    finally:
+        c2.close()
+
+
 def test_per_stream_trace_of_a_launch():
     """BRX_OPTION_TRACE: one record per stream -- start < end on the GPU's realtime counter, the level of the kernel that decoded
     it, its workgroup; streams the lean instance took have all-zero records.  Nothing is recorded (and the call fails cleanly)
