@@ -1017,8 +1017,7 @@ FI void periodic_fill(Dec &d, Lds &s, u32 P, u32 nblocks) {
             }
         } else {
             const bool both = d.mirror != nullptr;
-            u32 k = 0;
-            for (; k < nblocks; k++) {
+            for (u32 k = 0; k < nblocks; k++) {
                 o += step;
                 o = o >= P ? o - P : o;
                 const u32x4 qn = *(const u32x4 *)&s.ring[(base + o) & RMASK]; // (one read more than needed at the end)
