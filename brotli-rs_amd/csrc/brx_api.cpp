@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -502,6 +503,9 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.counter_idx = 0u;
     a.late_only = 0u;
     a.big_bytes = 0u;
+    a.start_total = 0u;
+    a.start_value = 0u;
+    a.start_flag = nullptr;
     a.sw_threshold = c->loop_build >= 0 ? 0u : c->max_grid / 16u * BRX_SW_WAVES_PER_CU;
     uint32_t *regions = nullptr; // this launch's BRX_LIST_REGIONS regions of defer_cap words
     if (!c->no_defer && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS) {
@@ -628,16 +632,33 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         uint32_t g[4] = {std::min<uint32_t>(plan.grid[0], grid), plan.grid[1], plan.grid[2], plan.grid[3]};
         const uint32_t *mask = plan.mask;
         const int narrowest = g[0] ? 0 : g[1] ? 1 : g[2] ? 2 : 3;
+        uint32_t started = 0;
+        hc[12] = 0u;
         for (int k = 3; k >= 1; k--) {
             if (g[k] == 0u) continue;
             BrxKernelArgs aw = a;
             aw.cls = nullptr;
             aw.list_mask = mask[k];
             aw.counter_idx = (uint32_t)k;
+            started += g[k];
+            aw.start_total = started;
+            aw.start_value = (a.launch_seq << 2) | (uint32_t)k;
+            aw.start_flag = k == narrowest ? nullptr : c->d_handed + 4u + 16u * (uint32_t)ring_slot + 12u;
             hipStream_t sw = k == narrowest ? st : c->s_wide[k - 1];
             if (sw != st) HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork[ring_slot], 0));
             if (k == 1) brx_launch_decode_l1(aw, g[k], sw); else if (k == 2) brx_launch_decode_l2(aw, g[k], sw); else brx_launch_decode_l3(aw, g[k], sw);
             if (sw != st) { HIP_TRY(hipEventRecord(c->ev_join[ring_slot][k - 1], sw)); joined[k - 1] = true; }
+            if (aw.start_flag != nullptr) {
+                // Widest first, and the next kernel only once this one's workgroups are all resident (its last one to start says
+                // so in pinned host memory; ~10 us): which of two launches on two HIP streams gets to the CUs first is a race, and
+                // narrow workgroups that win it sit three or four to a 40-KiB part of the LDS until they all have left -- the
+                // wider kernel then runs BEHIND them (8192 mixed streams: 60 or 110 ms from one launch to the next).  A kernel that
+                // does not report within 2 ms (the chip is busy with somebody else's work) is not waited for any longer.
+                const auto t0 = std::chrono::steady_clock::now();
+                while (*(volatile uint32_t *)&hc[12] != aw.start_value) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                }
+            }
         }
         if (g[0] != 0u) brx_launch_decode(a, g[0], st);
     } else {

@@ -119,7 +119,10 @@ struct BrxKernelArgs {
     uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..15 zeroed in-stream before the launch:
                             // [k] ticket counter of the level-k kernel (k = 0..3), [4] tickets of the catch-all launch, [5 + j]
                             // streams in list j (j = 0..2: classified for level j + 1; j = 3: the late list), [9] tickets of the
-                            // classification pre-pass, [10] streams the lean kernel listed, [11] bytes decoded twice (see below)
+                            // classification pre-pass, [10] streams the lean kernel listed, [11] bytes decoded twice (see below),
+                            // [12] / [13] pre-pass: sizes (units of 64 B) / number of the streams that stay with the regular kernel,
+                            // [14] plan B: workgroups of the wider kernels that have started, [15] lean kernel: sizes of the streams
+                            // it listed (units of 64 B)
     // Streams whose meta-block tables spill a kernel's LDS table memory are not decoded there: they are LISTED for the level
     // whose table memory holds them (the need is known exactly once the header is parsed) and decoded by that level's kernel.
     //   lists 0..2 (region j of `defer`): streams of level j + 1 that have produced no output yet -- decoded from their start;
@@ -143,6 +146,9 @@ struct BrxKernelArgs {
     uint32_t big_bytes;     // regular kernel, plan B: 0, or the mean compressed size of its streams -- the queue is then walked twice, first
                             // for the streams of at least this size, then for the smaller ones (the long jobs start first, no sort);
                             // the pre-pass leaves the sum (in units of 64 B) and the count in words 12 / 13 of the counter line
+    uint32_t start_total;   // plan B, wider kernels: the workgroup that brings word 14 of the counter line to this value writes
+    uint32_t start_value;   // start_value to *start_flag (pinned host memory): every workgroup launched so far is resident, the host
+    volatile uint32_t *start_flag; // may launch the next, narrower kernel (nullptr: no such hand-shake)
     uint32_t late_only;     // kernels below level 3: 1 = every hand-up goes to the late list (plan B: the class lists are being read)
     uint32_t tiny_bytes;    // compressed streams up to this size run their commands in the C++ loop alone (BRX_TINY_STREAM_BYTES)
     uint32_t sw_threshold;  // wider kernels: up to this many listed streams they run the sparse-launch build of the loop

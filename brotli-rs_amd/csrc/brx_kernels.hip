@@ -2073,6 +2073,16 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #define generic_commands(m_) generic_commands((m_), wc.v_ic, wc.v_lut0, wc.v_lut1, wc.v_lut2)
     u32 *const counter = a.work_counter + a.counter_idx;
 #if BRX_LEVEL > 0
+    // (plan B: the host launches the next, narrower kernel only once every workgroup of the wider ones is resident -- workgroups
+    // of 10 KiB that arrive first take three or four to a 40-KiB part of a CU's LDS and leave no room for a 20-KiB one there until
+    // they all have left: brx_api.cpp launch())
+    if (a.start_flag != nullptr && lane == 0u) {
+        const u32 t = atomicAdd(a.work_counter + 14, 1u);
+        if (t + 1u == a.start_total) {
+            __threadfence_system();
+            *a.start_flag = a.start_value;
+        }
+    }
     // A wider kernel decodes the lists of `list_mask` one behind the other: lists 0..2 hold streams to be decoded from their
     // start, list 3 (late) streams to be resumed from a state record.
     if (a.defer == nullptr) return;
@@ -2090,9 +2100,22 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #else
     // (behind the lean instance, BrxKernelArgs::s_list: queue slots [0, n) are this launch's own, the slots beyond are the
     // streams the lean kernel listed -- the large ones and the small ones it gave up on)
-    const u32 n_streams = a.n + (a.s_list != nullptr ? rfl(__builtin_nontemporal_load(&a.work_counter[10])) : 0u);
+    const u32 n_listed = a.s_list != nullptr ? rfl(__builtin_nontemporal_load(&a.work_counter[10])) : 0u;
+    const u32 n_streams = a.n + n_listed;
     if (n_streams == 0u) return;
     const bool sw_loop = a.loop_build != 0u;
+    // Long jobs first, without a sort: when more streams are queued than workgroups run (the later ones start as the first ones
+    // finish), the queue is walked twice -- first for the streams of at least the mean compressed size, then for the smaller ones.
+    // A heterogeneous batch in the caller's order otherwise ends with its longest streams starting last (8192 streams of four
+    // texts: 45.5 ms, longest first 33.4 ms; profiles/r04_order_ab.txt).  The mean: from the host (plan B: the pre-pass's
+    // statistics of the streams that stay here), or -- device pointers, no queue order from the host -- from the lean kernel in
+    // front, which saw every stream's size when it classified them (word 15 of the counter line: the sum in units of 64 B).
+    u32 big = a.big_bytes;
+    if (big == 0u && a.order == nullptr && a.cls == nullptr && a.n == 0u && n_listed != 0u && a.prepass == 0u) {
+        const u64 sum = (u64)rfl(__builtin_nontemporal_load(&a.work_counter[15])) << 6;
+        big = (u32)(sum / n_listed > 0xffffffffull ? 0xffffffffull : sum / n_listed);
+    }
+    const bool two_walk = big != 0u && n_streams > gridDim.x;
 #endif
     // Work queue.  A wave's FIRST stream is its workgroup index, no atomic: 4096 waves adding to one address from eight
     // XCDs serialise at ~13 ns each (4096 EMPTY streams took 106 us that way, most of what config 3 took).  Later streams
@@ -2112,7 +2135,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if ((sid | 63u) < gridDim.x) sid ^= (sid >> 3) & 7u;
         } else {
 #if BRX_LEVEL == 0
-            if (n_streams <= gridDim.x && a.big_bytes == 0u) break; // one stream per wave: nothing is queued
+            if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
 #else
             if (n_streams <= gridDim.x) break; // one stream per wave: nothing is queued
 #endif
@@ -2122,7 +2145,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
         }
 #if BRX_LEVEL == 0
-        if (a.big_bytes != 0u && sid >= n_streams) { // second walk over the queue: the smaller streams
+        if (two_walk && sid >= n_streams) { // second walk over the queue: the smaller streams
             sid -= n_streams;
             pass2 = true;
         }
@@ -2146,7 +2169,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
 #if BRX_LEVEL == 0
-        if (a.big_bytes != 0u && ((i1 >= i0 ? i1 - i0 : 0ull) >= (u64)a.big_bytes) == pass2) continue; // the other walk's
+        if (two_walk && ((i1 >= i0 ? i1 - i0 : 0ull) >= (u64)big) == pass2) continue; // the other walk's
 #endif
         {
             Dec d;

@@ -319,6 +319,12 @@ __global__ __launch_bounds__(BRX_WAVE, 8) void brx_decode_kernel_s(BrxKernelArgs
             if (m != 0ull) {
                 const u32 base = rdl(atomicAdd(listed, lane == 0u ? (u32)__builtin_popcountll(m) : 0u), 0);
                 if (big) a.s_list[base + lanes_below(m)] = sid;
+                // (the sizes of the streams left to the regular kernel, summed in units of 64 B: it starts the longer half of an
+                // oversubscribed queue first -- brx_kernels.hip, two_walk)
+                u32 units = 0u;
+                if (big && sid < a.n) { const u64 len = a.in_off[sid + 1u] - a.in_off[sid]; units = len >> 6 > 0xfffffull ? 0xfffffu : (u32)(len >> 6); }
+                for (u32 o = 32u; o != 0u; o >>= 1) units += (u32)__shfl_xor((int)units, (int)o);
+                if (lane == 0u) (void)atomicAdd(a.work_counter + 15, units);
             }
         }
     }
