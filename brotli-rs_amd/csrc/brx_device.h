@@ -143,8 +143,8 @@ struct BrxKernelArgs {
     uint32_t prepass;       // regular kernel only: 1 = classify (first meta-block header) and write cls / lists 0..2, decode nothing
     uint32_t list_mask;     // wider kernels: the lists this launch decodes (bit j = list j)
     uint32_t counter_idx;   // the word of the counter line this launch takes its tickets from
-    uint32_t big_bytes;     // regular kernel, plan B: 0, or the mean compressed size of its streams -- the queue is then walked twice, first
-                            // for the streams of at least this size, then for the smaller ones (the long jobs start first, no sort);
+    uint32_t big_bytes;     // regular kernel, plan B: 0, or the mean compressed size of its streams -- an oversubscribed queue is then walked
+                            // four times: sizes >= 2 x this, >= this, >= half of it, the rest (the long jobs start first, no sort);
                             // the pre-pass leaves the sum (in units of 64 B) and the count in words 12 / 13 of the counter line
     uint32_t start_total;   // plan B, wider kernels: the workgroup that brings word 14 of the counter line to this value writes
     uint32_t start_value;   // start_value to *start_flag (pinned host memory): every workgroup launched so far is resident, the host

@@ -2105,7 +2105,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     if (n_streams == 0u) return;
     const bool sw_loop = a.loop_build != 0u;
     // Long jobs first, without a sort: when more streams are queued than workgroups run (the later ones start as the first ones
-    // finish), the queue is walked twice -- first for the streams of at least the mean compressed size, then for the smaller ones.
+    // finish), the queue is walked four times -- for the streams of at least twice the mean compressed size, of at least the mean,
+    // of at least half of it, then the rest.
     // A heterogeneous batch in the caller's order otherwise ends with its longest streams starting last (8192 streams of four
     // texts: 45.5 ms, longest first 33.4 ms; profiles/r04_order_ab.txt).  The mean: from the host (plan B: the pre-pass's
     // statistics of the streams that stay here), or -- device pointers, no queue order from the host -- from the lean kernel in
@@ -2125,7 +2126,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     bool first = true;
     for (;;) {
         u32 sid;
-        bool pass2 = false;
+        u32 walk = 0u;
         if (first) {
             first = false;
             // (workgroup i runs on XCD i % 8: with slot = i a batch whose streams repeat with a period of 2, 4 or 8 -- every fourth
@@ -2145,9 +2146,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             sid = gridDim.x + rdl(atomicAdd(counter, lane == 0u ? 1u : 0u), 0);
         }
 #if BRX_LEVEL == 0
-        if (two_walk && sid >= n_streams) { // second walk over the queue: the smaller streams
-            sid -= n_streams;
-            pass2 = true;
+        if (two_walk && sid >= n_streams) { // the later walks over the queue: the smaller streams
+            walk = sid / n_streams;
+            sid -= walk * n_streams;
+            if (walk > 3u) break;
         }
 #endif
         if (sid >= n_streams) break;
@@ -2169,7 +2171,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         const u64 i0 = a.in_off[sid], i1 = a.in_off[sid + 1u];
         const u64 o0 = a.out_off[sid], o1 = a.out_off[sid + 1u];
 #if BRX_LEVEL == 0
-        if (two_walk && ((i1 >= i0 ? i1 - i0 : 0ull) >= (u64)big) == pass2) continue; // the other walk's
+        if (two_walk) { // walk 0: sizes >= 2 x mean, 1: [mean, 2 x mean), 2: [mean / 2, mean), 3: the rest
+            const u64 len = i1 >= i0 ? i1 - i0 : 0ull;
+            const u32 mine = len >= 2ull * big ? 0u : len >= (u64)big ? 1u : len >= (u64)(big >> 1) ? 2u : 3u;
+            if (mine != walk) continue; // another walk's
+        }
 #endif
         {
             Dec d;
