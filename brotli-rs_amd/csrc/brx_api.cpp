@@ -76,7 +76,7 @@ struct brx_ctx {
     uint8_t *d_lut = nullptr;
     BrxTransform *d_xforms = nullptr;
     uint32_t *d_iac = nullptr;
-    uint32_t *d_counters = nullptr; // BRX_COUNTER_RING x 64 B
+    uint32_t *d_counters = nullptr; // BRX_COUNTER_RING x 128 B
     uint64_t launch_seq = 0;
     // streams whose tables spill the regular kernel's LDS are listed here by it and decoded by the wide kernel launched
     // right behind (BrxKernelArgs::defer): BRX_COUNTER_RING lists of defer_cap stream indices, one per launch in flight
@@ -244,11 +244,11 @@ static int ctx_init(brx_ctx *c, int device) {
     HIP_TRY(hipMalloc(&c->d_dict, sizeof BRX_DICT));
     HIP_TRY(hipMalloc(&c->d_lut, sizeof BRX_CONTEXT_LUT));
     HIP_TRY(hipMalloc(&c->d_xforms, 121 * sizeof(BrxTransform)));
-    HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 64u));
+    HIP_TRY(hipMalloc(&c->d_counters, BRX_COUNTER_RING * 128u));
     HIP_TRY(hipHostMalloc((void **)&c->h_handed, 16 + 64 * BRX_COUNTER_RING, hipHostMallocMapped)); // (word 0: handed_seq; from word 4: 16 words per launch slot, plan B's counts)
     *c->h_handed = 0u;
     HIP_TRY(hipHostGetDevicePointer((void **)&c->d_handed, c->h_handed, 0));
-    HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 64u));
+    HIP_TRY(hipMemset(c->d_counters, 0, BRX_COUNTER_RING * 128u));
     HIP_TRY(hipMalloc(&c->d_pool, sizeof(BrxSlabPool)));
     HIP_TRY(hipMemset(c->d_pool, 0, sizeof(BrxSlabPool)));
     HIP_TRY(hipMemcpy(c->d_dict, BRX_DICT, sizeof BRX_DICT, hipMemcpyHostToDevice));
@@ -489,7 +489,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     // room and the build with the shorter dependent chain wins; fuller CUs take the one that spares the scalar ALU
     a.loop_build = c->loop_build >= 0 ? (uint32_t)c->loop_build : (grid <= c->max_grid / 16u * BRX_SW_WAVES_PER_CU ? 1u : 0u);
     const size_t ring_slot = (size_t)(c->launch_seq++ % BRX_COUNTER_RING);
-    a.work_counter = c->d_counters + ring_slot * 16u; // one 64-B line per launch
+    a.work_counter = c->d_counters + ring_slot * 32u; // one 128-B line per launch
     // streams whose tables spill a kernel's LDS table memory are listed for the level that holds them (not in the resumable and
     // bring-up modes): BrxKernelArgs::defer
     a.tiny_bytes = c->tiny_bytes;
@@ -588,7 +588,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
     const bool lately = c->force_plan_b || (seen != 0u && a.launch_seq - seen <= 64u);
     const bool plan_b = a.defer != nullptr && may_overlap && !c->no_plan_b && lately;
-    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, 128, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     if (lean) {
         BrxKernelArgs as = a;

@@ -116,13 +116,14 @@ struct BrxKernelArgs {
     uint32_t n;
     const uint32_t *order;  // work-queue order (queue slot -> stream index), nullptr = identity
     uint32_t debug_stop;    // 0 = normal; >0 = bring-up bisection points in the kernel
-    uint32_t *work_counter; // this launch's own 64-B line (ring in brx_ctx), words 0..15 zeroed in-stream before the launch:
+    uint32_t *work_counter; // this launch's own 128-B line (ring in brx_ctx), words 0..31 zeroed in-stream before the launch:
                             // [k] ticket counter of the level-k kernel (k = 0..3), [4] tickets of the catch-all launch, [5 + j]
                             // streams in list j (j = 0..2: classified for level j + 1; j = 3: the late list), [9] tickets of the
                             // classification pre-pass, [10] streams the lean kernel listed, [11] bytes decoded twice (see below),
                             // [12] / [13] pre-pass: sizes (units of 64 B) / number of the streams that stay with the regular kernel,
                             // [14] plan B: workgroups of the wider kernels that have started, [15] lean kernel: sizes of the streams
-                            // it listed (units of 64 B)
+                            // it listed (units of 64 B), [16] / [17] the largest of those sizes / 0xfffff - the smallest (lean
+                            // kernel and pre-pass: which walks over an oversubscribed queue can have members at all)
     // Streams whose meta-block tables spill a kernel's LDS table memory are not decoded there: they are LISTED for the level
     // whose table memory holds them (the need is known exactly once the header is parsed) and decoded by that level's kernel.
     //   lists 0..2 (region j of `defer`): streams of level j + 1 that have produced no output yet -- decoded from their start;

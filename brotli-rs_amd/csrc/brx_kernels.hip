@@ -2117,6 +2117,22 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         big = (u32)(sum / n_listed > 0xffffffffull ? 0xffffffffull : sum / n_listed);
     }
     const bool two_walk = big != 0u && n_streams > gridDim.x;
+    // ... and only the walks that can have members are made: every ticket is an atomic on ONE address (~13 ns each, serialised),
+    // and 16 384 equal streams walked four times are 49 152 tickets that find nothing (16 384 x monkey: 0.98 -> 1.43 ms).  Whoever
+    // summed the sizes also kept the largest and the smallest (words 16 / 17, units of 64 B).
+    u32 wlist = 0x3210u, nwalks = 4u;
+    if (two_walk) {
+        const u32 w16 = rfl(__builtin_nontemporal_load(&a.work_counter[16])), w17 = rfl(__builtin_nontemporal_load(&a.work_counter[17]));
+        if (w17 != 0u) { // (0: nobody recorded them)
+            const u64 max_end = ((u64)w16 + 1ull) << 6, min_len = (u64)(0xfffffu - w17) << 6; // max < max_end, min >= min_len
+            const bool has0 = w16 >= 0xfffffu || max_end > 2ull * big, has2 = min_len < (u64)big, has3 = min_len < (u64)(big >> 1);
+            wlist = 0u, nwalks = 0u;
+            if (has0) wlist |= 0u << (4u * nwalks++);
+            wlist |= 1u << (4u * nwalks++);
+            if (has2) wlist |= 2u << (4u * nwalks++);
+            if (has3) wlist |= 3u << (4u * nwalks++);
+        }
+    }
 #endif
     // Work queue.  A wave's FIRST stream is its workgroup index, no atomic: 4096 waves adding to one address from eight
     // XCDs serialise at ~13 ns each (4096 EMPTY streams took 106 us that way, most of what config 3 took).  Later streams
@@ -2126,7 +2142,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     bool first = true;
     for (;;) {
         u32 sid;
-        u32 walk = 0u;
+        u32 walk = 0u; // (index into the list of walks that are made)
         if (first) {
             first = false;
             // (workgroup i runs on XCD i % 8: with slot = i a batch whose streams repeat with a period of 2, 4 or 8 -- every fourth
@@ -2149,7 +2165,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         if (two_walk && sid >= n_streams) { // the later walks over the queue: the smaller streams
             walk = sid / n_streams;
             sid -= walk * n_streams;
-            if (walk > 3u) break;
+            if (walk >= nwalks) break;
         }
 #endif
         if (sid >= n_streams) break;
@@ -2174,7 +2190,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         if (two_walk) { // walk 0: sizes >= 2 x mean, 1: [mean, 2 x mean), 2: [mean / 2, mean), 3: the rest
             const u64 len = i1 >= i0 ? i1 - i0 : 0ull;
             const u32 mine = len >= 2ull * big ? 0u : len >= (u64)big ? 1u : len >= (u64)(big >> 1) ? 2u : 3u;
-            if (mine != walk) continue; // another walk's
+            if (mine != ((wlist >> (4u * walk)) & 15u)) continue; // another walk's
         }
 #endif
         {
@@ -2357,8 +2373,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if (lane == 0u) a.cls[sid] = (u8)c;
             if (c == 0u && lane == 0u) { // (the regular kernel's own streams: their mean size splits its queue, BrxKernelArgs::big_bytes)
                 const u64 len = i1 >= i0 ? i1 - i0 : 0ull;
-                (void)atomicAdd(a.work_counter + 12, (u32)(len >> 6 > 0xfffffull ? 0xfffffull : len >> 6));
+                const u32 units = (u32)(len >> 6 > 0xfffffull ? 0xfffffull : len >> 6);
+                (void)atomicAdd(a.work_counter + 12, units);
                 (void)atomicAdd(a.work_counter + 13, 1u);
+                (void)atomicMax(a.work_counter + 16, units);
+                (void)atomicMax(a.work_counter + 17, 0xfffffu - units);
             }
             if (c != 0u) {
                 const u32 slot = rdl(atomicAdd(a.work_counter + 4 + c, lane == 0u ? 1u : 0u), 0);

@@ -323,8 +323,17 @@ __global__ __launch_bounds__(BRX_WAVE, 8) void brx_decode_kernel_s(BrxKernelArgs
                 // oversubscribed queue first -- brx_kernels.hip, two_walk)
                 u32 units = 0u;
                 if (big && sid < a.n) { const u64 len = a.in_off[sid + 1u] - a.in_off[sid]; units = len >> 6 > 0xfffffull ? 0xfffffu : (u32)(len >> 6); }
-                for (u32 o = 32u; o != 0u; o >>= 1) units += (u32)__shfl_xor((int)units, (int)o);
-                if (lane == 0u) (void)atomicAdd(a.work_counter + 15, units);
+                u32 umax = units, umin = big && sid < a.n ? 0xfffffu - units : 0u; // (0xfffff - size: the smallest as a maximum)
+                for (u32 o = 32u; o != 0u; o >>= 1) {
+                    units += (u32)__shfl_xor((int)units, (int)o);
+                    umax = max(umax, (u32)__shfl_xor((int)umax, (int)o));
+                    umin = max(umin, (u32)__shfl_xor((int)umin, (int)o));
+                }
+                if (lane == 0u) {
+                    (void)atomicAdd(a.work_counter + 15, units);
+                    (void)atomicMax(a.work_counter + 16, umax);
+                    (void)atomicMax(a.work_counter + 17, umin);
+                }
             }
         }
     }
