@@ -154,6 +154,7 @@
 #define VDHOFF v10
 #define VB4 v11
 #define VPEND v12
+#define VITAB v23               // lane l: context info of bytes 4l .. 4l+3 under the current context mode (= LDS_ITAB)
 #define VDICTINFO v13
 #define VQ v[14:17]
 #define VT0 v18
@@ -702,6 +703,7 @@
 .Lit_not3:
     v_lshlrev_b32 VT0, 2, VLANE
     ds_write_b32 VT0, VT1 offset:LDS_ITAB
+    v_mov_b32 VITAB, VT1                                // (resident copy: LIT_CTX_ENTRY)
     // up to 8 literal trees, one context mode: limits and bases live in v70..v85 (pair t = tree t, reached through M0),
     // lane 16 of a tree's limits carries the LDS address of its symbol list.  A one-symbol tree becomes a real table:
     // limit[0] = all ones ("matches" at length 0, no bits), a two-entry list [x, x].
@@ -1249,14 +1251,11 @@
 //   mx  the other modes: the six bits of the p1 share need no mask there (MA2 = 0x3f)
 // (.Lhave_lits jumps to .Llit_r_entry_*) pending bytes into the ring, then the context of the first literal straight into the
 // scalar registers of the loop -- .Lland_ctx without the detour through the vector-side form
-.macro LIT_CTX_ENTRY v
-.Llit_r_entry_\v:
-    s_cmp_eq_u32 PFREE, 0
-    s_cbranch_scc1 .Llit_r_entry_nopend_\v               // (out of line, LIT_CTX_ENTRY_AUX: only there can this be the stream's start)
-    LAND_BODY 0                                         // (PBASE: the run's end sets it, nothing reads it in between)
-.Llit_r_entry_ring_\v:
-    s_add_u32 T6, POS, SKEW
-    v_bfe_u32 VPA, T6, 0, 11
+// The two bytes in front of a run that follows a copy are the LAST TWO PENDING ones (a copy is at least 2 bytes long, a
+// dictionary word 4): they are read from their lanes of VPEND, and their context info from its lane of VITAB (4 bytes per
+// lane) -- no trip to the ring and none to the info table in front of the run's first literal (two dependent LDS round
+// trips less per run; the landing's store is no longer waited for by anything).  -DBRX_CTX_RING: the bytes from the ring.
+.macro LIT_CTX_RING_BYTES                               // T6 / T7 = context info of the last two bytes of the ring
     v_add_u32 VT0, -1, VPA
     v_add_u32 VT1, -2, VPA
     v_and_b32 VT0, RMASK, VT0
@@ -1269,6 +1268,35 @@
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 T6, VT3
     v_readfirstlane_b32 T7, VT4
+.endm
+.macro LIT_CTX_ENTRY v
+.Llit_r_entry_\v:
+    s_cmp_eq_u32 PFREE, 0
+    s_cbranch_scc1 .Llit_r_entry_nopend_\v               // (out of line, LIT_CTX_ENTRY_AUX: only there can this be the stream's start)
+#ifdef BRX_CTX_RING
+    LAND_BODY 0                                         // (PBASE: the run's end sets it, nothing reads it in between)
+.Llit_r_entry_ring_\v:
+    s_add_u32 T6, POS, SKEW
+    v_bfe_u32 VPA, T6, 0, 11
+    LIT_CTX_RING_BYTES
+#else
+    s_sub_u32 T4, PFREE, 1                              // lanes of the last two pending bytes
+    s_sub_u32 T5, PFREE, 2
+    LAND_BODY 0                                         // (PBASE: the run's end sets it, nothing reads it in between)
+    v_readlane_b32 T6, VPEND, T4                        // p1 (the landing has waited for the copies' loads)
+    v_readlane_b32 T7, VPEND, T5                        // p2
+    s_add_u32 T0, POS, SKEW
+    v_bfe_u32 VPA, T0, 0, 11
+    s_lshr_b32 T0, T6, 2                                // info(p) = byte p & 3 of lane p >> 2 of VITAB
+    s_lshr_b32 T1, T7, 2
+    v_readlane_b32 T0, VITAB, T0
+    v_readlane_b32 T1, VITAB, T1
+    s_lshl_b32 T6, T6, 3                                // (a shift takes the low five bits of its count: 8 * (p & 3))
+    s_lshl_b32 T7, T7, 3
+    s_lshr_b32 T6, T0, T6                               // (bits 8.. are the neighbours' info: only fields of bits 7:0 are taken below)
+    s_lshr_b32 T7, T1, T7
+#endif
+.Llit_r_ctx_have_\v:
     s_bfe_u32 T1, T6, 0x60002
     s_and_b32 T1, T1, MA2
     s_bfe_u32 T5, T6, BFEBI                             // p1's share as a later p2
@@ -1277,6 +1305,13 @@
 .Llit_r_go_\v:
 .endm
 .macro LIT_CTX_ENTRY_AUX v
+#ifndef BRX_CTX_RING
+.Llit_r_entry_ring_\v:                                  // nothing pending (a landing, a flush or a long copy came in between): the ring has the bytes
+    s_add_u32 T6, POS, SKEW
+    v_bfe_u32 VPA, T6, 0, 11
+    LIT_CTX_RING_BYTES
+    s_branch .Llit_r_ctx_have_\v
+#endif
 .Llit_r_entry_nopend_\v:
     s_cmp_lt_u32 POS, 2                                 // (a copy is at least 2 bytes long: nothing is pending at the stream's start)
     s_cbranch_scc0 .Llit_r_entry_ring_\v
