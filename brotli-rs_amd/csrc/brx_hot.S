@@ -28,7 +28,7 @@
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
 // command and hands back: block switches, copies longer than 512 bytes (or long and closer than 64 bytes), any error
-// (the C++ side re-decodes and raises it), the last 256 bits of the stream (so no end-of-input test is needed here:
+// (the C++ side re-decodes and raises it), the last END_MARGIN dwords of the stream (so no end-of-input test is needed here:
 // every bit consumed below is a real bit), a ragged first flush block, extra-bit fields wider than the window.
 //
 // Preconditions (the HC_START call of generic_commands() sets mbw[MBW_ASM] and rewrites the tables): every literal and
@@ -75,6 +75,14 @@
 #define INP s[42:43]
 #define WENDM1 s44
 #define WSAFE s45
+// The loop has no end-of-input test: it is poisoned when the refill pulls in dword WSAFE - 1 = (bitend >> 5) - END_MARGIN - 1,
+// the cursor then at most at bitend - 32 * END_MARGIN - 32, and leaves at the next insert&copy symbol or literal run.  Until
+// then it takes at most 24 + 24 (insert / copy extra bits) + 15 + 15 + 24 (a distance block switch: type, count, its extra
+// bits) + 15 + 24 (distance symbol, extra bits) = 141 bits: four dwords would do, five are kept (eight until round 4: a
+// stream's last 36 bytes went through the C++ loop, a third of what a 400-byte stream takes).
+#ifndef END_MARGIN
+#define END_MARGIN 5
+#endif
 #define CBASE s46
 #define DIST s47
 #define RSRC s[48:51]
@@ -521,7 +529,7 @@
 #endif
     s_sub_u32 WENDM1, T0, 1
     s_lshr_b32 WSAFE, T2, 5
-    s_sub_u32 WSAFE, WSAFE, 8
+    s_sub_u32 WSAFE, WSAFE, END_MARGIN
     s_cselect_b32 WSAFE, 0, WSAFE                       // borrow -> 0
     s_lshr_b32 CBASE, T1, 5                             // first staged dword = the one holding the cursor
     s_and_b32 T3, T1, 31                                // bit offset inside it
@@ -1625,7 +1633,7 @@
     s_setpc_b64 LINKC
 
 // Refill reached lane WLSTOP: either the staged chunk is used up (roll the two chunks, request the next one) or
-// the cursor is within 256 bits of the end of the stream (poison the block counters so that the loop leaves at
+// the cursor is within END_MARGIN dwords of the end of the stream (poison the block counters so that the loop leaves at
 // its next R0 / R1 test; the C++ side finishes the stream with the exact end-of-input rules).
 .Lspecial:
     s_cmp_lg_u32 WL, 64
