@@ -528,7 +528,7 @@ def main():
             strong = {"streams_total": n, "streams_per_gpu": n, "ms_per_step": round(ms_per_step, 4), "value": round(value, 1),
                       "unit": "MB/s", "note": "N = 1: the strong-scaling batch is the weak one"}
         strong["what"] = ("the SAME %d-stream batch split over N GPUs (BASELINE.json's metric as worded).  One wavefront decodes one stream, so "
-                          "a GPU's time is bounded below by ONE stream alone (profiles/r03_sweep.txt: 256 .. 4096 x alice29 take 7.6 .. 10 ms): "
+                          "a GPU's time is bounded below by ONE stream alone (profiles/r04_sweep.txt: 256 .. 4096 x alice29 take 6.6 .. 8.3 ms): "
                           "N GPUs buy at most that ratio on a 4096-stream batch; throughput scales with N only at >= 4096 streams per GPU "
                           "(`value`, weak)" % strong["streams_total"])
         res["strong"] = strong
