@@ -254,6 +254,46 @@ def test_truncation_sweep_through_the_first_headers(levels):
         c2.close()
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("build", [0, 1])
+def test_truncation_sweep_through_the_last_bytes(build):
+    """The assembly loop has no end-of-input test: it hands the stream's last dwords to the C++ loop (END_MARGIN in brx_hot.S, five
+    dwords since round 4 -- the bound on what the loop can still take once it has been told is derived there).  Streams cut at EVERY
+    byte of their last 120 bytes -- and inside the cut's last byte at every other cut -- must end with the oracle's status and, where
+    that is 0 (a cut that only lost padding), the oracle's bytes; the bytes in front of an error are the oracle's too.  Texts with
+    many literals, long insert / copy extra fields (quality 0 - 2 encoder streams), distance block switches (config 5), in both
+    builds of the loop."""
+    import glob
+    c2 = brx_knobs.context(0, loop_build=build)
+    try:
+        sources = [_read(n) for n in ("alice29.txt.compressed", "asyoulik.txt.compressed", "lcet10.txt.compressed", "plrabn12.txt.compressed",
+                                      "compressed_repeated.compressed", "monkey.compressed", "quickfox_repeated.compressed")]
+        sources += [open(os.path.join(GOLDEN, "config5", "c5_%d.compressed" % i), "rb").read() for i in (0, 1)]
+        sources += [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(GOLDEN, "enc", "*.compressed")))[::6]]
+        total = 0
+        for data in sources:
+            cap = max(1 << 16, 24 * len(data))
+            full = oracle.decode(data, 0, cap=cap)
+            if full[0] != 0:
+                continue
+            cap = len(full[1]) + 64
+            cuts = []
+            for k in range(max(1, len(data) - 120), len(data) + 1):
+                cuts.append(data[:k])
+                if k % 2 == 0:
+                    for j in (2, 5):
+                        cuts.append(data[:k - 1] + bytes([data[k - 1] & ((1 << j) - 1)]))
+            want = [oracle.decode(s_, 0, cap=cap) for s_ in cuts]
+            outs, status, out_len = c2.decode_batch(cuts, cap)
+            bad = [(i, len(cuts[i]), w[0], int(st), int(ol), len(w[1])) for i, (w, o, st, ol) in enumerate(zip(want, outs, status, out_len))
+                   if w[0] != st or (st == 0 and o != w[1]) or (st != 0 and o[:min(len(o), len(w[1]))] != w[1][:min(len(o), len(w[1]))])]
+            assert not bad, (len(data), bad[:8])
+            total += len(cuts)
+        assert total > 3000
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("n_each", [1, 3, 40])
 def test_plan_b_with_every_class_in_one_small_batch(n_each):
     """Launch plan B (forced) on batches that hold every class at once -- a short stream for the lean instance, alice29 (regular),
