@@ -464,7 +464,7 @@ static int ensure_order(brx_ctx *c, uint32_t n) {
 static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, const uint64_t *d_in_off, uint32_t n,
                   uint8_t *d_out, const uint64_t *d_out_off, uint64_t *d_out_len, int32_t *d_status,
                   const uint32_t *d_order = nullptr, BrxResume *d_resume = nullptr, const BrxSlabPool *d_own_pool = nullptr,
-                  uint8_t *d_out_mirror = nullptr, bool may_overlap = false, uint32_t n_large = 0xffffffffu) {
+                  uint8_t *d_out_mirror = nullptr, bool may_plan_b = false, uint32_t n_large = 0xffffffffu) {
     BrxKernelArgs a;
     a.out_mirror = d_out_mirror;
     a.order = d_order;
@@ -587,7 +587,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.handed_seq = c->d_handed;
     const uint32_t seen = c->h_handed ? *(volatile uint32_t *)c->h_handed : 0u;
     const bool lately = c->force_plan_b || (seen != 0u && a.launch_seq - seen <= 64u);
-    const bool plan_b = a.defer != nullptr && may_overlap && !c->no_plan_b && lately;
+    const bool plan_b = a.defer != nullptr && may_plan_b && !c->no_plan_b && lately;
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, 128, st));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], st));
     if (lean) {
