@@ -2057,11 +2057,21 @@ __device__ __noinline__ void seg_resume() {
     Lds &s = g_lds;
     Dec d;
     dec_load(d, s);
-    const u32 vend = (d.pos + d.a + 15u) & ~15u;
+    const u32 top = d.pos + d.a; // (ring slot of a byte = (its position + a) mod the ring size: 16-byte units of ring and slot coincide)
+    const u32 vend = (top + 15u) & ~15u;
     for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) {
         const u32 v = vend - BRX_RING_BYTES + 1024u * j + 16u * d.lane;
         const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(d.out_rsrc, v - d.a, 0, 0);
         *(u32x4 *)&s.ring[v & RMASK] = q;
+    }
+    // The 16-byte unit that holds `top` came with whatever lies BEHIND the stream's last byte in its upper part; those slots
+    // belong to the OLDEST bytes of the window (positions top - 2048 ...): a copy from 2033 .. 2048 bytes back right after the
+    // resume read them (found by the round-4 soak: tools/wide_fuzz.py 3 43, three wrong bytes, only with an output slot that is
+    // not 16-byte aligned; tests/golden/regress_late/r04_wide43_1_90).
+    const u32 k = top & 15u;
+    if (k != 0u && d.lane >= k && d.lane < 16u) {
+        const u32 v = vend - 16u + d.lane;
+        s.ring[v & RMASK] = (u8)__builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, v - BRX_RING_BYTES - d.a, 0, 0);
     }
 }
 #endif

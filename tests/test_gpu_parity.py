@@ -1053,6 +1053,30 @@ def test_later_meta_block_that_outgrows_its_level_is_resumed_not_restarted(level
         c2.close()
 
 
+@pytest.mark.parametrize("levels", [0, 2])
+def test_late_resume_with_every_alignment_of_the_output_slot(levels):
+    """A stream that is handed up with its state gets its 2 KiB ring back from its own output; ring and output agree in 16-byte
+    units, so with an output slot that is not 16-byte aligned the unit holding the resume position is half newest bytes, half
+    OLDEST bytes of the window.  Round 4's soak (tools/wide_fuzz.py 3 43) found the oldest ones missing: a libbrotlienc stream
+    (quality 11, 9 meta-blocks; tests/golden/regress_late/) whose eighth meta-block outgrows level 1 and starts with a copy from
+    2 040 bytes back decoded three wrong bytes, status 0 -- in 15 of 16 alignments.  Sixteen copies, one per alignment, both
+    launch plans (plan A decodes them in the catch-all from their start; plan B resumes them)."""
+    s_ = open(os.path.join(GOLDEN, "regress_late", "r04_wide43_1_90.compressed"), "rb").read()
+    st, exp = oracle.decode(s_, 0, cap=1 << 20)
+    assert st == 0 and len(exp) == 869459
+    c2 = brx_knobs.context(0, levels=levels)
+    try:
+        cap = len(exp) + (1 - len(exp)) % 16 + 16  # = 1 (mod 16): stream i's slot starts at i (mod 16)
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch([s_] * 16, cap)
+            bad = [(i, int(t)) for i, (o, t) in enumerate(zip(outs, status)) if t != 0 or o != exp]
+            assert not bad, bad
+            if levels == 2:
+                assert c2.last_late_streams() == 16 and c2.last_redo_bytes() == 0
+    finally:
+        c2.close()
+
+
 def test_farcopy_streams(ctx):
     """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
     streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
