@@ -596,17 +596,29 @@ def odd_long_stream(seed, rounds, first=1 << 16, mib=4, tail=2, wbits=22):
     return b.bytes(), bytes(out)
 
 
-def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
+def _explicit_distance(dist):
+    """(distance code, number of extra bits, extra bits) of `dist` under NPOSTFIX = 0, NDIRECT = 0 (RFC 7932 section 4)"""
+    for hcode in range(48):
+        nbits = 1 + (hcode >> 1)
+        base = ((2 + (hcode & 1)) << nbits) - 4 + 1
+        if base <= dist < base + (1 << nbits):
+            return 16 + hcode, nbits, dist - base
+    raise ValueError(dist)
+
+
+def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18, first_dist=None):
     """A stream of len(trees_per_mb) compressed meta-blocks; meta-block j has NTREESL = trees_per_mb[j] literal trees (two
     symbols each, an 18-word table + a handle per tree in the HIP decoder's table memory) behind a context map over the 64
     context ids, so the table memory a meta-block needs is chosen per meta-block: a stream whose LATER meta-block outgrows the
     kernel instance that started it (the regular one holds ~88 such trees, level 1 ~121, level 2 ~222).  Commands as in
-    context_mode_stream: 6 / 7 literals, then a copy of 2 from the last distance.  Returns (stream, expected_output) -- the
-    output from an independent model of the context rules."""
+    context_mode_stream: 6 / 7 literals, then a copy of 2 from the last distance.  first_dist: the FIRST copy of every meta-block
+    but the first names that distance explicitly (and it is the last distance from then on) -- a copy from about a ring's length
+    back right behind a hand-up.  Returns (stream, expected_output) -- the output from an independent model of the context rules."""
     rng = random.Random(seed)
     b = Bits()
     stream_header(b, wbits)
     out = bytearray()
+    last = 4
     for j, nt in enumerate(trees_per_mb):
         is_last = j == len(trees_per_mb) - 1
         trees = [sorted(rng.sample(range(256), 2)) for _ in range(nt)]
@@ -639,7 +651,12 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
             simple_code(b, t, 8)
         iac = [176, 177]       # cell 2 (explicit distance): insert code 6, copy code 0 / 1
         simple_code(b, iac, 10)
-        simple_code(b, [0], 6)  # distance code 0 only: zero-bit code (= the last distance; 4 at the start of the stream)
+        far = first_dist is not None and j > 0
+        if far:
+            dcode, dn, dx = _explicit_distance(first_dist)
+            simple_code(b, [0, dcode], 6)  # one bit each: the last distance, or first_dist's code + dn extra bits
+        else:
+            simple_code(b, [0], 6)  # distance code 0 only: zero-bit code (= the last distance; 4 at the start of the stream)
         for k, ins in enumerate(cmds):
             b.put(*code_bits(iac, 176))
             b.put(ins - 6, 1)
@@ -651,8 +668,13 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18):
                 b.put(*code_bits(t, s))
                 out.append(s)
             if k != n_cmds - 1:
+                if far:
+                    b.put(*code_bits([0, dcode], dcode if k == 0 else 0))
+                    if k == 0:
+                        b.put(dx, dn)
+                        last = first_dist
                 for _ in range(2):
-                    out.append(out[-4])
+                    out.append(out[-last])
     return b.bytes(), bytes(out)
 
 

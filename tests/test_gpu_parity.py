@@ -1077,6 +1077,32 @@ def test_late_resume_with_every_alignment_of_the_output_slot(levels):
         c2.close()
 
 
+@pytest.mark.parametrize("levels", [0, 2])
+def test_copy_from_a_ring_length_back_right_behind_a_hand_up(levels):
+    """The class of the bug above, swept: hand-assembled streams (tests/craft.py growing_tables_stream, first_dist) whose third
+    meta-block outgrows the regular instance and opens with a copy from D bytes back, D = 2 020 .. 2 059 (the ring holds 2 048),
+    each at all 16 alignments of its output slot; bit-exact, all of them resumed (late list), nothing decoded twice."""
+    import craft
+    c2 = brx_knobs.context(0, levels=levels)
+    try:
+        streams, want = [], []
+        for D in range(2020, 2060):
+            st_, out_ = craft.growing_tables_stream(300 + D, [2, 2, 150], mode=D % 4, n_cmds=300, first_dist=D)
+            streams += [st_] * 16
+            want += [out_] * 16
+        w0 = oracle.decode(streams[0], 0, cap=1 << 16)
+        assert w0[0] == 0 and w0[1] == want[0]
+        cap = max(len(w) for w in want)
+        cap += (1 - cap) % 16 + 16  # = 1 (mod 16): stream i's slot starts at i (mod 16)
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, cap)
+            bad = [(i, 2020 + i // 16, i % 16, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+            assert not bad, bad[:8]
+            assert c2.last_late_streams() == len(streams) and c2.last_redo_bytes() == 0
+    finally:
+        c2.close()
+
+
 def test_farcopy_streams(ctx):
     """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
     streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
