@@ -1250,6 +1250,9 @@ def test_pinned_buffers_are_used_in_place(ctx):
              "metablock_reset", "zeros", "quickfox"]
     streams = [_read(nm + ".compressed") for nm in names] * 3
     streams += [craft.farcopy_stream(3, 8192, 1 << 16)[0], bytes.fromhex("a103")]
+    # (streams that change instance under way: the first part of their output is stored by one wave, the rest by another)
+    streams += [craft.growing_tables_stream(400 + k, sh, mode=k % 4, n_cmds=300, first_dist=fd)[0]
+                for k, (sh, fd) in enumerate([([2, 2, 150], 2040), ([2, 2, 105, 2, 150], 2047), ([2, 130, 240], None), ([2, 2, 150], 2033)])]
     bad = bytearray(_read("alice29.txt.compressed"))
     bad[30000] ^= 0x40
     streams.append(bytes(bad))

@@ -2,7 +2,9 @@
 """One-off soak of the wide-LDS kernel on a GPU box: libbrotlienc streams of LARGE text inputs at high quality (the ones
 whose meta-blocks carry more prefix-code tables than the regular kernel's LDS table memory holds), decoded in ragged
 batches next to small streams, compared with the original bytes; corrupted variants (bit flips / truncation) compared
-with the oracle.  Prints how many streams of each batch the wide kernel took.  Usage: wide_fuzz.py [rounds] [seed]"""
+with the oracle.  Prints how many streams of each batch the wide kernel took.  Usage: wide_fuzz.py [rounds] [seed] [late]
+("late": forced flushes every 20 .. 64 KiB, so that the table need changes from meta-block to meta-block and streams are handed
+up under way, with their state -- the late list -- at many positions and alignments)"""
 import os
 import random
 import sys
@@ -19,6 +21,7 @@ import brx_knobs  # noqa: E402
 G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+LATE = len(sys.argv) > 3 and sys.argv[3] == "late"
 texts = [open(os.path.join(G, f), "rb").read() for f in ("lcet10.txt", "plrabn12.txt", "alice29.txt", "asyoulik.txt", "mapsdatazrh")]
 corpus = b"".join(texts)
 assert brotli_enc.available()
@@ -41,11 +44,11 @@ for r in range(rounds):
         npf = rng.choice([None, None, 0, 1, 2, 3])
         nd = None if npf is None else rng.randrange(0, 16) << npf
         streams.append(brotli_enc.compress(data, quality=q, lgwin=rng.randrange(16, 25), mode=rng.randrange(3), npostfix=npf,
-                                           ndirect=nd, flush_every=rng.choice([0, 0, 0, 100000])))
+                                           ndirect=nd, flush_every=rng.choice([20000, 30011, 40000, 65536] if LATE else [0, 0, 0, 100000])))
         datas.append(data)
     caps = [len(x) + rng.randrange(0, 40) for x in datas]
     outs, status, out_len = ctx.decode_batch(streams, caps)
-    wide = [ctx.last_wide_streams(k) for k in (1, 2, 3)]
+    wide = [ctx.last_wide_streams(k) for k in (1, 2, 3)] + ["late %d" % ctx.last_late_streams()]
     for i, (d, o, st) in enumerate(zip(datas, outs, status)):
         if st != 0 or o != d:
             bad += 1
