@@ -56,9 +56,7 @@
 // EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup + lane 16, which carries the symbol-list
 // address of a resident tree).  Everything uniform needs one lane; copies, flushes and input staging set their own mask.
 // Fewer switching lanes = less power = a higher clock on the loaded chip (DVFS, MI355X_MICROARCH.md).
-#ifndef XLOOP
 #define XLOOP 0x1ffff
-#endif
 
 // ---- SGPRs (s36-s38: scratch during entry)
 #define NPOST s4
