@@ -53,9 +53,9 @@
 #define LDS_CMH (9472+LDS_GROW)    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
 #define SYMOFF 68       // symbol list of a tree: after its 17 header words (brx_kernels.hip, "Table layout in table memory")
 #define INFOOFF 64      // the header's info word: kind | max_len << 8 | x << 16
-// EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup + lane 16, which carries the symbol-list
-// address of a resident tree).  Everything uniform needs one lane; copies, flushes and input staging set their own mask.
-// Fewer switching lanes = less power = a higher clock on the loaded chip (DVFS, MI355X_MICROARCH.md).
+// EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup, + 1).  Everything uniform needs one lane; copies,
+// flushes and input staging set their own mask.  Against all 64 lanes: -6.5 % at 4096 streams (round 2; why is not settled: the
+// clock is 2.395 GHz under the headline load either way, and 32 lanes cost the same as 17 -- round 4, profiles/EXPERIMENTS.md).
 #define XLOOP 0x1ffff
 
 // ---- SGPRs (s36-s38: scratch during entry)
