@@ -263,6 +263,10 @@ class Context:
         """Slices of bounded / pulled streams of this context that paused in front of an item the resident input did not hold."""
         return int(self._lib.brx_last_timing(self._h, 8))
 
+    def stream_regrown(self):
+        """Slices of bounded / pulled streams of this context run again with a larger output buffer (one command beyond the slack)."""
+        return int(self._lib.brx_last_timing(self._h, 9))
+
     def last_lean_listed(self):
         """Streams of the most recent launch that the lean instance (short streams, 32 waves per CU) left to the regular kernel:
         the ones larger than its limit plus the short ones it gave up on (errors, block switches, large tables)."""

@@ -98,6 +98,7 @@ struct brx_ctx {
     unsigned grid_cap = 0;
     bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
     size_t reader_window = (8u << 20);            // BRX_OPTION_READER_WINDOW: compressed bytes a bounded / pulled stream keeps resident
+    uint64_t stream_regrown = 0;                  // bounded streams: slices run again with a larger output buffer (one command beyond the slack; brx_last_timing 9)
     uint64_t stream_short_slices = 0;             // slices of bounded streams that paused in front of an item the resident input did not hold (brx_last_timing 8)
     bool trace_on = false;                        // BRX_OPTION_TRACE: per-stream start / end / place of the most recent launch (brx_last_trace)
     unsigned long long *d_trace = nullptr;
@@ -429,20 +430,21 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 
 // Room for the lists of n stream indices each of every launch in flight (grown rarely: nobody may be using the old lists).
 static int ensure_defer(brx_ctx *c, uint32_t n) {
-    if (c->d_defer && c->defer_cap >= n) return BRX_SUCCESS;
+    if (c->d_defer && c->d_handup && c->defer_cap >= n) return BRX_SUCCESS;
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(c->d_defer);
     c->d_defer = nullptr;
     c->defer_cap = 0;
     size_t cap = 4096;
     while (cap < n) cap <<= 1;
-    hipError_t e = hipMalloc(&c->d_defer, cap * 4u * BRX_LIST_REGIONS * BRX_COUNTER_RING); // (brx_device.h: lists 0..2, late, lean, class bytes)
-    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e);
-    c->defer_cap = cap;
-    if (!c->d_handup) {
+    hipError_t e;
+    if (!c->d_handup) { // (first: a launch must never see lists without the state records that go with them)
         e = hipMalloc(&c->d_handup, (size_t)BRX_COUNTER_RING * BRX_LATE_CAP * 16u * 4u);
-        if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "state-record allocation failed", e);
+        if (e != hipSuccess) { c->d_handup = nullptr; return fail(BRX_ERR_OUT_OF_MEMORY, "state-record allocation failed", e); }
     }
+    e = hipMalloc(&c->d_defer, cap * 4u * BRX_LIST_REGIONS * BRX_COUNTER_RING); // (brx_device.h: lists 0..2, late, lean, class bytes)
+    if (e != hipSuccess) { c->d_defer = nullptr; return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e); }
+    c->defer_cap = cap;
     return BRX_SUCCESS;
 }
 
@@ -881,6 +883,7 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: slices run again with a larger output buffer
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
     if (which >= 2 && which <= 7) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
                                     // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
@@ -1074,6 +1077,8 @@ struct brx_stream {
     size_t mem_at = 0;             // ... how much of `in` has been pulled
     bool src_eof = false;
     bool no_progress = false, stalled = false; // the last slice paused where it started / ... and the window could not be improved
+    bool pull_broken = false;                  // the read callback returned more than it was given room for
+    size_t buf_size = 0;                       // size of d_buf: BRX_BOUNDED_BUFSIZE, more once a single command needed more
     uint8_t *d_inwin = nullptr, *d_buf = nullptr;
     size_t in_window = (8u << 20);     // size of d_inwin (the context's reader_window when the stream started decoding)
     size_t in_fill = 0, in_cursor = 0; // bytes resident in d_inwin; the decoder's cursor in it (after the last good slice)
@@ -1095,6 +1100,9 @@ struct brx_stream {
 #define BRX_IN_KEEP 4096u             // ... of which this much below the cursor stays (the kernel stages 256-byte chunks behind it)
 #define BRX_IN_STAGE (1u << 20)       // host staging chunk of the pulls
 #define BRX_IN_MARGIN_DIV 32u         // a slice pauses window / 32 (256 KiB) in front of the resident end while the source has more
+#define BRX_IN_WINDOW_MAX ((size_t)256u << 20) // the input window grows up to this when one item needs more than it holds
+#define BRX_BOUNDED_BUF_MAX ((size_t)BRX_BOUNDED_BUFSIZE + ((size_t)48u << 20)) // ... the output buffer when one command produces more than the slack
+                                      // (an insert or a copy is < 2^24 + 2^22 bytes each, an uncompressed meta-block <= 2^24)
 
 static void bounded_release(brx_stream *s) {
     if (!s->d_buf && !s->d_inwin) return;
@@ -1115,17 +1123,17 @@ static int bounded_init(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     s->in_window = c->reader_window;
-    const size_t bufsize = BRX_BOUNDED_BUFSIZE;
-    HIP_TRY(hipMalloc(&s->d_inwin, (size_t)BRX_IN_WINDOW + 16));
-    HIP_TRY(hipMalloc(&s->d_buf, bufsize));
+    s->buf_size = BRX_BOUNDED_BUFSIZE;
+    HIP_TRY(hipMalloc(&s->d_inwin, s->in_window + 16)); // (the option's size, not the default's: ADVICE r4)
+    HIP_TRY(hipMalloc(&s->d_buf, s->buf_size));
     HIP_TRY(hipMalloc(&s->d_slab, (size_t)BRX_SCRATCH_WORDS * 4u));
     const size_t rec_bytes = (sizeof(BrxResume) + 255u) & ~(size_t)255;
     uint8_t *small = nullptr;
-    HIP_TRY(hipMalloc(&small, 2 * rec_bytes + 1024));
+    HIP_TRY(hipMalloc(&small, rec_bytes + 1024));
     s->d_rec = (BrxResume *)small;
-    s->d_pool = (BrxSlabPool *)(small + 2 * rec_bytes);
-    s->d_bitmap = (uint32_t *)(small + 2 * rec_bytes + 256);
-    s->d_meta = (uint64_t *)(small + 2 * rec_bytes + 512);
+    s->d_pool = (BrxSlabPool *)(small + rec_bytes);
+    s->d_bitmap = (uint32_t *)(small + rec_bytes + 256);
+    s->d_meta = (uint64_t *)(small + rec_bytes + 512);
     HIP_TRY(hipMemset(s->d_rec, 0, 32));
     const uint32_t only_slab_0 = 0xfffffffeu; // a private pool of ONE slab that survives between the slices
     HIP_TRY(hipMemcpy(s->d_bitmap, &only_slab_0, 4, hipMemcpyHostToDevice));
@@ -1135,9 +1143,26 @@ static int bounded_init(brx_stream *s) {
     return BRX_SUCCESS;
 }
 
-// Pull compressed bytes: up to `cap` into buf, 0 = the source is exhausted.
-static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap) {
-    if (s->read_fn) return s->read_fn(s->read_user, buf, cap);
+// Pull compressed bytes: up to `cap` into buf, 0 = the source is exhausted.  A pulled source is the caller's code: it runs with
+// the context's lock RELEASED -- it may itself read from another brx_stream / Decompressor of the same context (nested readers;
+// with the lock held that thread would wait for itself) -- and what it returns is checked against the room it was given.
+static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap, std::unique_lock<std::mutex> &lk) {
+    if (s->read_fn) {
+        lk.unlock();
+        size_t got = 0;
+        try {
+            got = s->read_fn(s->read_user, buf, cap);
+        } catch (...) {
+            lk.lock();
+            throw;
+        }
+        lk.lock();
+        if (got > cap) {
+            s->pull_broken = true;
+            return 0;
+        }
+        return got;
+    }
     const size_t k = std::min(cap, s->in.size() - s->mem_at);
     if (k) memcpy(buf, s->in.data() + s->mem_at, k);
     s->mem_at += k;
@@ -1145,7 +1170,7 @@ static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap) {
 }
 
 // Move the input window up to the cursor (when that frees at least 1 MiB) and fill it from the source.
-static int bounded_refill(brx_stream *s) {
+static int bounded_refill(brx_stream *s, std::unique_lock<std::mutex> &lk) {
     brx_ctx *c = s->ctx;
     if (s->in_cursor >= BRX_IN_KEEP + s->in_window / 8u) {
         const size_t delta = (s->in_cursor - BRX_IN_KEEP) & ~(size_t)15, keep = s->in_fill - delta;
@@ -1158,7 +1183,8 @@ static int bounded_refill(brx_stream *s) {
         s->in_slide_pending += delta;
     }
     while (!s->src_eof && s->in_fill < s->in_window) {
-        const size_t got = stream_pull(s, s->stage.data(), std::min<size_t>(s->stage.size(), s->in_window - s->in_fill));
+        const size_t got = stream_pull(s, s->stage.data(), std::min<size_t>(s->stage.size(), s->in_window - s->in_fill), lk);
+        if (s->pull_broken) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_stream_read: the read callback returned more bytes than it was given room for");
         if (got == 0) {
             s->src_eof = true;
             break;
@@ -1170,11 +1196,53 @@ static int bounded_refill(brx_stream *s) {
     return BRX_SUCCESS;
 }
 
+// One item (a header, an uncompressed meta-block, one command) needs more compressed bytes than the input window holds: a
+// window twice the size, same content.  (Before round 5 such a slice ran with "this is all there is" and reported UnexpectedEOF.)
+static int bounded_grow_in(brx_stream *s) {
+    brx_ctx *c = s->ctx;
+    if (s->in_window >= BRX_IN_WINDOW_MAX)
+        return fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: one item of the stream needs more than 256 MiB of compressed input resident");
+    const size_t bigger = std::min(s->in_window * 2u, BRX_IN_WINDOW_MAX);
+    uint8_t *nb = nullptr;
+    hipError_t e = hipMalloc(&nb, bigger + 16);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: input window allocation failed", e);
+    if (hipMemcpyAsync(nb, s->d_inwin, s->in_fill, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(nb);
+        return fail(BRX_ERR_HIP, "brx_stream_read: input window copy failed");
+    }
+    (void)hipFree(s->d_inwin);
+    s->d_inwin = nb;
+    s->in_window = bigger;
+    return BRX_SUCCESS;
+}
+
+// One command produces more than the output buffer has room for behind the window (a long copy, a long insert, an uncompressed
+// meta-block): a buffer that holds it, same content.  `need_abs` = the stream position the command runs to.
+static int bounded_grow_out(brx_stream *s, uint64_t need_abs) {
+    brx_ctx *c = s->ctx;
+    if (need_abs <= s->shift) return BRX_ERR_OUT_OF_MEMORY;
+    size_t want = (size_t)(need_abs - s->shift) + BRX_BOUNDED_SLACK;
+    want = (want + 0xfffffu) & ~(size_t)0xfffffu;
+    if (want <= s->buf_size || want > BRX_BOUNDED_BUF_MAX) return BRX_ERR_OUT_OF_MEMORY;
+    uint8_t *nb = nullptr;
+    hipError_t e = hipMalloc(&nb, want);
+    if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: output window allocation failed", e);
+    if (hipMemcpyAsync(nb, s->d_buf, (size_t)(s->pos - s->shift), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(nb);
+        return fail(BRX_ERR_HIP, "brx_stream_read: output window copy failed");
+    }
+    (void)hipFree(s->d_buf);
+    s->d_buf = nb;
+    s->buf_size = want;
+    return BRX_SUCCESS;
+}
+
 // Decode the next slice: up to BRX_BOUNDED_CHUNK more bytes (to the next command boundary past it).
-static int bounded_step(brx_stream *s) {
+static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t bufsize = BRX_BOUNDED_BUFSIZE;
     if (s->pos - s->shift >= (uint64_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN) {
         // slide the window: keep the last BRX_BOUNDED_WINDOW bytes (every back-reference reaches at most that far); the
         // base moves by a multiple of 16 so the kernel's 16-byte store alignment (its ring skew) is unchanged.  The move is
@@ -1196,17 +1264,26 @@ static int bounded_step(brx_stream *s) {
     if (!s->src_eof && (s->in_fill - s->in_cursor < s->in_window / 2u || s->no_progress)) {
         const size_t fill0 = s->in_fill; // (a slice that paused at its in_low comes here too)
         const uint64_t slide0 = s->in_slide_pending;
-        int rc = bounded_refill(s);
+        int rc = bounded_refill(s, lk);
         if (rc) return rc;
-        if (s->no_progress && s->in_fill == fill0 && s->in_slide_pending == slide0) s->stalled = true;
+        if (s->no_progress && !s->src_eof && s->in_fill == fill0 && s->in_slide_pending == slide0) {
+            // the slice paused where it had started and the window can neither move nor take more: ONE item needs more input
+            // than the window holds -- a bigger window (only when that fails does the slice run as if this were all there is)
+            rc = bounded_grow_in(s);
+            if (rc == BRX_SUCCESS) rc = bounded_refill(s, lk);
+            if (rc) return rc;
+        }
     }
     s->no_progress = false;
-    const uint64_t cap_abs = std::min<uint64_t>(s->shift + bufsize, BRX_STREAM_LIMIT);
+    const uint64_t cap_abs = std::min<uint64_t>(s->shift + s->buf_size, BRX_STREAM_LIMIT);
     const uint64_t pause_at = s->pos + BRX_BOUNDED_CHUNK;
     uint8_t *virt = (uint8_t *)((uintptr_t)s->d_buf - (uintptr_t)s->shift); // address of output byte 0, were it still resident
     {
         uint64_t meta[4] = {0, s->in_fill, 0, cap_abs};
         HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
+        uint32_t rec_state0 = 0, bitmap0 = 0; // (what a slice that fails for room must find again: see below)
+        HIP_TRY(hipMemcpyAsync(&rec_state0, &s->d_rec->state, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&bitmap0, s->d_bitmap, 4, hipMemcpyDeviceToHost, c->stream));
         // While the source has more, the slice pauses a margin (1/32 of the window: 256 KiB) short of the resident end -- at a
         // command or meta-block boundary, or in the middle of a literal run -- and a segment that still runs into that end (a
         // header, an uncompressed block, one whole command of the C++ loop) is taken back by the kernel itself: the slice
@@ -1226,16 +1303,28 @@ static int bounded_step(brx_stream *s) {
         HIP_TRY(hipMemcpyAsync(&cur, &s->d_rec->lds[BRX_RESUME_CURSOR_WORD], 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const int32_t st = (int32_t)(res[1] & 0xffffffffu);
+        if (st == BRX_OUTPUT_TOO_SMALL) {
+            // One command larger than the room behind the window.  The failed slice has written no state (the record is stored at a
+            // pause only) bar two things: it marked the record finished and gave its slab back -- both are put back as they were,
+            // the buffer grows to what the command asked for (res[0]), and the same slice runs again.  Only a command beyond
+            // BRX_BOUNDED_BUF_MAX (none the format allows) or a failed allocation leaves through the caller's fallback.
+            int rc2 = bounded_grow_out(s, res[0]);
+            if (rc2) return BRX_ERR_OUT_OF_MEMORY;
+            HIP_TRY(hipMemcpyAsync(&s->d_rec->state, &rec_state0, 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(s->d_bitmap, &bitmap0, 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->stream_regrown++;
+            return BRX_SUCCESS; // (pos, cursors and in_slide_pending as they were: brx_stream_read calls again)
+        }
         s->in_slide_pending = 0;
         s->stalled = false;
-        if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // one command larger than the slack (caller falls back)
         s->pos = res[0];
         if (st != BRX_PAUSED) {
             s->finished = true;
             s->status = st;
             if (st == BRX_OK && !s->src_eof) { // bytes behind the end of the stream (StreamEnd, src/lib.rs:2155-2167)?
                 uint8_t probe;
-                if (stream_pull(s, &probe, 1) != 0) s->status = BRX_EXPECTED_END_OF_STREAM;
+                if (stream_pull(s, &probe, 1, lk) != 0) s->status = BRX_EXPECTED_END_OF_STREAM;
                 else s->src_eof = true;
             }
         } else {
@@ -1365,7 +1454,7 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
     if (s->bounded) {
         brx_ctx *c = s->ctx;
         if (!c) return -(int64_t)1000 + BRX_ERR_INVALID_ARGUMENT;
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::unique_lock<std::mutex> lk(c->mu);
         for (;;) {
             if (s->lib_rc != BRX_SUCCESS) return -(int64_t)1000 + s->lib_rc;
             if (s->delivered < s->pos) {
@@ -1387,11 +1476,11 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
                 int rc = bounded_init(s);
                 if (rc) { bounded_release(s); s->lib_rc = rc; continue; }
             }
-            int rc = bounded_step(s);
+            int rc = bounded_step(s, lk);
             if (rc == BRX_ERR_OUT_OF_MEMORY && !s->finished && s->read_fn != nullptr) {
                 // (over a reader the compressed bytes behind the window are gone: no second way)
                 bounded_release(s);
-                s->lib_rc = fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: one command produces more than the bounded reader's slack (1 MiB); decode this stream from memory (brx_stream_new)");
+                s->lib_rc = fail(BRX_ERR_OUT_OF_MEMORY, "brx_stream_read: one item of the stream needs more device memory than the bounded reader may take (or an allocation failed); decode this stream from memory (brx_stream_new)");
                 continue;
             }
             if (rc == BRX_ERR_OUT_OF_MEMORY && !s->finished) {

@@ -89,10 +89,11 @@ struct BrxDeviceTables {
 // The compressed input is a sliding window too (the reference pulls its input through a BufReader as it decodes,
 // src/bitreader/mod.rs:21-53): in_off[sid] .. in_off[sid + 1] is what is resident NOW; when the host has moved the window up by
 // `in_slide` bytes (a multiple of 16) since the last slice, the parked cursor moves down with it.  A slice pauses early when its
-// cursor comes within a margin of the resident end while the source has more (`in_low`); one that still runs into the end -- a
-// single command or header longer than the margin -- reports UnexpectedEOF like any truncated stream, and the host, knowing that
-// more input exists, puts the record back to what it was before the slice and runs it again with more input resident
-// (brx_api.cpp, bounded_step).
+// cursor comes within a margin of the resident end while the source has more (`in_low`); a segment that still runs into the end -- a
+// single command or header longer than the margin -- is taken back by the kernel itself (BRX_ST_RESTORE in brx_kernels.hip): the
+// slice pauses in FRONT of it and the next one runs it with more input resident.  The record is written at a pause only; a slice
+// that ends for good marks it finished (state 2) and leaves `lds` alone (brx_api.cpp, bounded_step, relies on that when a slice
+// fails for room: it puts `state` back and runs the slice again with a larger buffer).
 struct BrxResume {
     uint32_t state;  // 0 = fresh stream, 1 = paused (lds valid), 2 = finished
     uint32_t phase;  // where to resume (kernel-internal)

@@ -134,15 +134,35 @@
 #define T6 s90
 #define T7 s91
 #define CLEN s96
+// -DBRX_SLOTS (the sparse-launch build only: it reads the window from SGPRs in every lane): the literal loop works on a CACHE
+// OF FOUR TREES in one register pair -- lanes 16 s .. 16 s + 15 = the tree in slot s -- and is software-pipelined over it: one
+// compare + one fetch decode the next literal under ALL FOUR candidate trees while the previous literal's entry is still on its
+// way back from LDS; once that entry is there its context picks the slot.  The LDS round trip leaves the per-literal chain.
+#if defined(BRX_WIN_SGPR) && !defined(BRX_PROF) && !defined(BRX_NO_SLOTS)
+#define BRX_SLOTS
+#endif
+// Meta-blocks with more than SLOT_OVER + 1 literal trees take the tree cache; up to eight trees fit the registers of the resident
+// loop, which is the faster one on text (few literals per run: profiles/r05_slots_ab.txt).
+#ifndef SLOT_OVER
+#define SLOT_OVER 7
+#endif
 #ifndef BRX_PROF
 #define LITJ s[20:21]           // where an insert's literals go (.Lhave_lits): the loop of the meta-block's literal mode
 #define LITJLO s20
 #define LITJHI s21
+#ifdef BRX_SLOTS
+#define BFEBI s29               // BFEB for a bare context-info byte (offset - 8)
+#define VCCB s[22:23]           // compare masks of the two literals in flight (SL_COMPARE)
+#define VCCA s[30:31]
+#define SLOTT s11               // byte s = index of the literal tree in slot s, 0xff = none
+                                // (FLAGS bits 17:16: the slot the next tree goes to, round robin)
+#else
 #define BFEBI s22               // BFEB for a bare context-info byte (offset - 8)
+#endif
 #endif
 #define LINKB s[98:99]
 #define LINKC s[100:101]
-// FLAGS bits: 0 = block counters poisoned (near the end of the input), 3 = one literal tree, resident in VLITL / VLITB,
+// FLAGS bits (17:16: BRX_SLOTS, the cache's next slot): 0 = block counters poisoned (near the end of the input), 3 = one literal tree, resident in VLITL / VLITB, 6 = more than 8 literal trees: the tree cache (BRX_SLOTS),
 // 4 = the literal block types differ in context mode (literal entries are plain bytes), 5 = <= 8 literal trees, resident
 // in v70..v85
 // ---- VGPRs (v40-v47 are callee-saved in the AMDGPU calling convention: using them would make the wrapper spill them)
@@ -212,6 +232,15 @@
 #define VDTREES1 v88
 #define VD3L v93                // (the pair of distance context 3 by name)
 #define VD3B v94
+#ifdef BRX_SLOTS
+#define VQL v96                 // the four cached literal trees: limits (as counts) ...
+#define VQB v97                 // ... and folded bases, lanes 16 s .. 16 s + 15 = slot s
+#define VSLOT v98               // lane c: 16 * slot of the tree of context id c, 0x80 = that tree is not cached
+#define VSA v99                 // the candidates' entries of the two literals in flight
+#define VSB v100
+#define VLITS v101              // the entries of a run's literals (lane = RUN at the time), stored to the ring at the run's end
+#define VNLANE v102             // ~lane
+#endif
 #ifndef BRX_NO_SPEC
 #define BRX_DIST_RESIDENT
 #endif
@@ -715,8 +744,15 @@
     // up to 8 literal trees, one context mode: limits and bases live in v70..v85 (pair t = tree t, reached through M0),
     // lane 16 of a tree's limits carries the LDS address of its symbol list.  A one-symbol tree becomes a real table:
     // limit[0] = all ones ("matches" at length 0, no bits), a two-entry list [x, x].
+#ifdef BRX_SLOTS
+    v_not_b32 VNLANE, VLANE
+#endif
     s_bitcmp1_b32 FLAGS, 4
     s_cbranch_scc1 .Lent_no_r
+#ifdef BRX_SLOTS
+    s_cmp_gt_u32 s13, SLOT_OVER
+    s_cbranch_scc1 .Lent_slots
+#endif
     s_cmp_gt_u32 s13, 7
     s_cbranch_scc1 .Lent_no_r
     s_bitset1_b32 FLAGS, 5
@@ -756,6 +792,25 @@
     s_add_u32 T6, T6, 1
     s_cmp_le_u32 T6, s13
     s_cbranch_scc1 .Lent_r_loop
+#ifdef BRX_SLOTS
+    s_branch .Lent_no_r
+    // more than 8 literal trees (one context mode): the tree cache of the pipelined literal loop -- trees 0 .. 3 go in at once,
+    // the others when a literal first needs them (.Lslot_fill)
+.Lent_slots:
+    s_bitset1_b32 FLAGS, 6
+    v_lshrrev_b32 VCMAP, 1, VCMIDX                      // (VCMIDX = 4 * tree index per context id)
+    s_mov_b32 SLOTT, -1
+    v_mov_b32 VSLOT, 0x80
+    v_mov_b32 VQL, 0
+    v_mov_b32 VQB, 0
+    s_mov_b32 T7, 0
+.Lent_s_loop:
+    s_mov_b32 T6, T7
+    s_call_b64 LINKB, .Lslot_fill
+    s_add_u32 T7, T7, 1
+    s_cmp_lt_u32 T7, 4
+    s_cbranch_scc1 .Lent_s_loop
+#endif
 .Lent_no_r:
     // one literal tree (and a general one): keep it in registers, no contexts
     s_cmp_lg_u32 s13, 0
@@ -841,6 +896,13 @@
     s_cselect_b32 T1, 0x1c, -1                          // (... of context mode 3: MB = 0x1c)
     s_cmp_eq_u32 T1, MB
     s_cselect_b32 T0, .Llit_r_entry_m3-.Llitj_base, T0
+#ifdef BRX_SLOTS
+    s_bitcmp1_b32 FLAGS, 6
+    s_cselect_b32 T0, .Llit_r_entry_sx-.Llitj_base, T0
+    s_cselect_b32 T1, 0x1c, -1
+    s_cmp_eq_u32 T1, MB
+    s_cselect_b32 T0, .Llit_r_entry_s3-.Llitj_base, T0
+#endif
     s_bitcmp1_b32 FLAGS, 3
     s_cselect_b32 T0, .Lhave_lits1-.Llitj_base, T0
     s_add_u32 LITJLO, LITJLO, T0
@@ -1439,6 +1501,178 @@
     LIT_CTX_ENTRY_AUX mx
     LIT_RF_STUB 44, 45
     LIT_RF_STUB 45, 45
+#ifdef BRX_SLOTS
+// ---- the pipelined loop over the tree cache.  One compare + one fetch (SL_COMPARE) decode the literal at the window's low end
+// under all four cached trees at once: group s of 16 lanes = slot s, its compare bits = bits 16 s .. of the mask, its
+// candidates' entries fetched per lane as in LOOKUP2F.  SL_SELECT picks the group of the literal's context (VSLOT), takes
+// the code's bits, and the NEXT literal's SL_COMPARE is issued before this literal's entry is waited for (SL_FINISH: entry,
+// context of the next literal).  Two literals are in flight (VSA / VSB, VCCA / VCCB: the loop is unrolled twice).
+// The entries are collected in VLITS and go to the ring with one store at the run's end.  A context whose tree is not
+// cached leaves through \miss: the tree replaces the oldest one, the compare is issued again.
+// A run is at most 63 literals and at most what the input is sure to hold in front of its last END_MARGIN dwords (2 literals per
+// dword: a literal's code is <= 15 bits) -- inside a run .Lspecial only ever rolls the staging, EXEC = all lanes throughout;
+// the literals next to the end of the input take the per-literal loop.
+.macro SL_COMPARE vs, vccp
+    v_bfrev_b32 VR, WINLO
+    v_lshrrev_b32 VI, VSH, VR
+    v_cmp_lt_u32 \vccp, VI, VQL
+    v_lshl_add_u32 VI, VI, 1, VQB
+    ds_read_u16 \vs, VI
+.endm
+.macro SL_SELECT vccp, rid, miss
+    v_readlane_b32 T6, VSLOT, T4                        // 16 * slot of this literal's tree
+    s_bitcmp1_b32 T6, 7
+    s_cbranch_scc1 \miss
+    s_lshr_b64 T01, \vccp, T6
+    s_ff1_i32_b32 CLEN, T0                              // code length = the group's lowest matching lane
+    s_add_u32 T6, T6, CLEN                              // lane of the entry
+    TAKE CLEN, \rid
+.endm
+.macro SL_FINISH_M3 vs, cnt, cur, prev
+    s_waitcnt lgkmcnt(\cnt)
+    v_readlane_b32 T0, \vs, T6                          // byte | context info << 8
+    s_bfe_u32 \cur, T0, 0x3000d                         // lut2 of this literal (context info bits 7:5 = bits 4:2)
+    s_lshl3_add_u32 T4, \cur, \prev                     // context id of the next one
+    v_writelane_b32 VLITS, T0, m0
+.endm
+.macro SL_FINISH_MX vs, cnt
+    s_waitcnt lgkmcnt(\cnt)
+    v_readlane_b32 T0, \vs, T6
+    s_bfe_u32 T1, T0, 0x6000a                           // context info of this literal >> 2: its share as p1
+    s_or_b32 T4, T1, T5                                 // context id of the next one
+    s_bfe_u32 T5, T0, BFEB                              // ... and this literal's share of the one after, as a field of the entry
+    v_writelane_b32 VLITS, T0, m0
+.endm
+.macro SL_RF_STUB id                                    // (lane WLSTOP inside a run is the end of the staged chunk, never the end
+.Lrf_stub_\id:                                          // of the input: SL_RUN; .Lspecial rolls the staging and nothing else)
+    REFILL_CORE
+    s_cbranch_scc1 .Lrf_back_\id
+    s_call_b64 LINKA, .Lspecial
+    s_mov_b64 exec, -1
+    s_branch .Lrf_back_\id
+.endm
+.macro SL_MISS v, ph, vs, vccp
+.Lsl_miss_\ph\()_\v:
+    v_readlane_b32 T6, VCMAP, T4
+    s_lshr_b32 T6, T6, 1
+    s_call_b64 LINKB, .Lslot_fill
+    SL_COMPARE \vs, \vccp
+    s_branch .Lsl_\ph\()_\v
+.endm
+// the run's setup (RUN = number of literals - 1; M0 counts them down), its end, its out-of-line decisions
+.macro SL_RUN v
+.Llit_r_run_\v:
+    s_sub_u32 T6, FLUSHAT, POS                          // (a copy may have ended exactly on the flush block: flush first)
+    s_cbranch_scc1 .Lflush_stub_lit_r_\v
+    s_min_u32 T6, T6, LBLEN
+    s_add_u32 T0, CBASE, WL
+    s_add_u32 T0, T0, 1
+    s_sub_u32 T0, WSAFE, T0                             // refills before the one that pulls in dword WSAFE - 1 (that one poisons the loop) ...
+    s_cselect_b32 T0, 0, T0
+    s_lshl_b32 T0, T0, 1                                // ... each good for two literals (a literal's code is <= 15 bits)
+    s_min_u32 T0, T0, 63
+    s_min_u32 T6, T6, T0
+    s_min_u32 RUN, INS, T6
+    s_cmp_eq_u32 T6, 0
+    s_cbranch_scc1 .Lsl_slow_\v
+    s_sub_u32 INS, INS, RUN
+    s_sub_u32 LBLEN, LBLEN, RUN
+    s_add_u32 POS, POS, RUN
+    s_sub_u32 RUN, RUN, 1
+    s_mov_b32 m0, RUN                                   // the loop counts M0 down (the lane select of v_writelane next to an SGPR operand)
+    s_mov_b64 exec, -1
+    SL_COMPARE VSA, VCCA
+.endm
+.macro SL_RUN_END v
+.Lsl_end_\v:
+    // literal k of the run sits in lane (RUN - 1 - k) & 63 of VLITS, k = 0 .. RUN: lanes 0 .. RUN - 1 and lane 63
+    s_bfm_b64 exec, RUN, 0
+    s_bitset1_b32 exec_hi, 31
+    s_add_u32 T0, POS, SKEW
+    s_sub_u32 T0, T0, RUN
+    s_sub_u32 T0, T0, 1                                 // ring position of the run's first literal
+    v_add_u32 VT0, RUN, VNLANE
+    v_and_b32 VT0, 63, VT0
+    v_add_u32 VT0, T0, VT0
+    v_and_b32 VT0, RMASK, VT0
+    ds_write_b8 VT0, VLITS
+    s_mov_b64 exec, XLOOP
+    LIT_RUN_END .Llit_r_run_\v, .Lflush_stub_lit_r_\v
+.Lsl_slow_\v:
+    s_cmp_eq_u32 LBLEN, 0
+    s_cbranch_scc1 .Llsw_\v
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc1 .Lflush_stub_lit_r_\v
+    // the end of the input is near: the rest of this insert takes the per-literal loop (it knows how to leave when the block
+    // counters get poisoned) -- its context state is the vector-side form of T4 / T5
+    s_lshl_b32 T0, T4, 2
+    s_lshl_b32 T1, T5, 2
+    v_mov_b32 VC, T0
+    v_mov_b32 VB4, T1
+    ds_read_b32 VH, VC offset:LDS_CMH
+    s_add_u32 T0, POS, SKEW
+    v_bfe_u32 VPA, T0, 0, 11
+    s_sub_u32 INS, INS, 1
+    s_branch .Llit_u
+.endm
+// ---- context mode 3 (T7 / T5: this literal's share and the previous one's swap roles from literal to literal)
+    LIT_CTX_ENTRY s3
+    SL_RUN s3
+.Lsl_a_s3:
+    SL_SELECT VCCA, 50, .Lsl_miss_a_s3
+    s_sub_u32 m0, m0, 1
+    s_cbranch_scc1 .Lsl_last_a_s3
+    SL_COMPARE VSB, VCCB
+    SL_FINISH_M3 VSA, 1, T7, T5
+.Lsl_b_s3:
+    SL_SELECT VCCB, 51, .Lsl_miss_b_s3
+    s_sub_u32 m0, m0, 1
+    s_cbranch_scc1 .Lsl_last_b_s3
+    SL_COMPARE VSA, VCCA
+    SL_FINISH_M3 VSB, 1, T5, T7
+    s_branch .Lsl_a_s3
+.Lsl_last_a_s3:
+    SL_FINISH_M3 VSA, 0, T7, T5
+    s_mov_b32 T5, T7                                    // (the next run starts with the previous share in T5 again)
+    s_branch .Lsl_end_s3
+.Lsl_last_b_s3:
+    SL_FINISH_M3 VSB, 0, T5, T7
+    SL_RUN_END s3
+    SL_MISS s3, a, VSA, VCCA
+    SL_MISS s3, b, VSB, VCCB
+    LIT_RUN_AUX s3
+    LIT_CTX_ENTRY_AUX s3
+    SL_RF_STUB 50
+    SL_RF_STUB 51
+// ---- the other modes
+    LIT_CTX_ENTRY sx
+    SL_RUN sx
+.Lsl_a_sx:
+    SL_SELECT VCCA, 52, .Lsl_miss_a_sx
+    s_sub_u32 m0, m0, 1
+    s_cbranch_scc1 .Lsl_last_a_sx
+    SL_COMPARE VSB, VCCB
+    SL_FINISH_MX VSA, 1
+.Lsl_b_sx:
+    SL_SELECT VCCB, 53, .Lsl_miss_b_sx
+    s_sub_u32 m0, m0, 1
+    s_cbranch_scc1 .Lsl_last_b_sx
+    SL_COMPARE VSA, VCCA
+    SL_FINISH_MX VSB, 1
+    s_branch .Lsl_a_sx
+.Lsl_last_a_sx:
+    SL_FINISH_MX VSA, 0
+    s_branch .Lsl_end_sx
+.Lsl_last_b_sx:
+    SL_FINISH_MX VSB, 0
+    SL_RUN_END sx
+    SL_MISS sx, a, VSA, VCCA
+    SL_MISS sx, b, VSB, VCCB
+    LIT_RUN_AUX sx
+    LIT_CTX_ENTRY_AUX sx
+    SL_RF_STUB 52
+    SL_RF_STUB 53
+#endif
 #endif
 .Lafter_lits:
     s_mov_b32 INS, 0
@@ -1569,6 +1803,72 @@
     s_cbranch_scc1 \lbl
     s_mov_b64 exec, XLOOP
 .endm
+#ifdef BRX_SLOTS
+// Literal tree T6 takes the next slot of the cache (round robin): the contexts of the tree that leaves are marked 0x80 in VSLOT,
+// those of the new one get its slot; its header words -> limits as counts / folded bases in the slot's 16 lanes (as the entry
+// code does for a resident tree).  Clobbers T0, T1, T6, CLEN, VT0, VT1, vcc; returns with EXEC = all lanes.
+.Lslot_fill:
+    s_mov_b64 exec, -1
+    s_bfe_u32 T1, FLAGS, 0x20010                        // the slot
+    s_add_u32 FLAGS, FLAGS, 0x10000
+    s_bitset0_b32 FLAGS, 18
+    s_lshl_b32 CLEN, T1, 3
+    s_lshr_b32 T0, SLOTT, CLEN
+    s_and_b32 T0, T0, 0xff                              // the tree that leaves (0xff: none)
+    s_lshl_b32 T0, T0, 1                                // (VCMAP holds 2 * tree index; 0x1fe matches nothing)
+    v_mov_b32 VT0, 0x80
+    v_cmp_eq_u32 vcc, T0, VCMAP
+    v_cndmask_b32 VSLOT, VSLOT, VT0, vcc
+    s_lshl_b32 T0, T6, 1
+    s_lshl_b32 T1, T1, 4
+    v_mov_b32 VT0, T1
+    v_cmp_eq_u32 vcc, T0, VCMAP
+    v_cndmask_b32 VSLOT, VSLOT, VT0, vcc
+    s_lshl_b32 T0, 0xff, CLEN
+    s_andn2_b32 SLOTT, SLOTT, T0
+    s_lshl_b32 T0, T6, CLEN
+    s_or_b32 SLOTT, SLOTT, T0
+    v_readlane_b32 T0, VLHOFF, T6                       // the tree's descriptor
+    s_bfm_b64 exec, 16, T1                              // the slot's lanes
+    s_cmp_lt_i32 T0, 0
+    s_cbranch_scc1 .Lslot_fill_single
+    v_add_u32 VT0, T0, VLANE4
+    ds_read_b32 VQL, VT0
+    s_add_u32 T0, T0, SYMOFF
+    s_waitcnt lgkmcnt(0)
+    SPLIT_TREE VQL, VQB
+    v_lshl_add_u32 VQB, VQB, 1, T0
+    TO_COUNTS VQL, VT1
+    s_mov_b64 exec, -1
+    s_setpc_b64 LINKB
+.Lslot_fill_single:                                     // a one-symbol tree: "matches" at length 0 (no bits), a two-entry list [x, x]
+    s_and_b32 T0, T0, 0xffff                            // x = byte | context info << 8
+    s_lshl_b32 CLEN, T0, 16
+    s_or_b32 T0, T0, CLEN
+    s_lshr_b32 CLEN, T1, 2
+    s_add_u32 CLEN, CLEN, LDS_SPARE                     // 4 bytes per slot
+    v_mov_b32 VT0, CLEN
+    v_mov_b32 VT1, T0
+    ds_write_b32 VT0, VT1
+    v_mov_b32 VQB, CLEN
+    v_mov_b32 VQL, 0
+    v_writelane_b32 VQL, -1, T1                         // the slot's lane 0
+    s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, -1
+    s_setpc_b64 LINKB
+// The context map row changed (a literal block switch): VT4 = tree index per context id -> VCMAP, VSLOT.  EXEC = all lanes.
+.macro SLOT_REMAP
+    v_lshlrev_b32 VCMAP, 1, VT4
+    v_mov_b32 VSLOT, 0x80
+    .irp sl, 0, 1, 2, 3
+    s_bfe_u32 T2, SLOTT, 0x80000 + 8 * \sl
+    s_lshl_b32 T2, T2, 1
+    v_mov_b32 VT0, 16 * \sl
+    v_cmp_eq_u32 vcc, T2, VCMAP
+    v_cndmask_b32 VSLOT, VSLOT, VT0, vcc
+    .endr
+.endm
+#endif
 .Lland:
     s_cmp_eq_u32 PFREE, 0
     s_cbranch_scc1 .Lland_chk
@@ -2064,8 +2364,9 @@
     s_bitcmp1_b32 FLAGS, 0                              // (poisoned during the switch: see .Lx_r0_switch)
     s_cselect_b32 LBLEN_REAL, LBLEN, LBLEN_REAL
     s_cselect_b32 LBLEN, 0, LBLEN
-    s_bitcmp1_b32 FLAGS, 5
-    s_cbranch_scc0 .Lsw_L_done                          // one literal tree: no context map
+    s_and_b32 T2, FLAGS, 0x60
+    s_cmp_eq_u32 T2, 0
+    s_cbranch_scc1 .Lsw_L_done                          // one literal tree: no context map
     ds_read_b32 v20, VZERO offset:LDS_MBW+12            // cml: byte address of the literal context map
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 T2, v20
@@ -2075,6 +2376,19 @@
     v_add_u32 VT0, T2, VLANE
     ds_read_u8 VT4, VT0 offset:LDS_TM                   // lane c: tree index of context id c
     s_waitcnt lgkmcnt(0)
+#ifdef BRX_SLOTS
+    s_bitcmp1_b32 FLAGS, 6
+    s_cbranch_scc0 .Lsw_L_resident
+    SLOT_REMAP
+    v_lshlrev_b32 VT4, 2, VT4                           // ... and the descriptor table of the per-literal loop (SL_RUN_END)
+    ds_bpermute_b32 VT4, VT4, VLHOFF
+    v_lshlrev_b32 VT3, 2, VLANE
+    s_waitcnt lgkmcnt(0)
+    ds_write_b32 VT3, VT4 offset:LDS_CMH
+    s_mov_b64 exec, XLOOP
+    s_setpc_b64 LINKB
+.Lsw_L_resident:
+#endif
     v_lshlrev_b32 VCMAP, 1, VT4
     s_mov_b64 exec, XLOOP
 .Lsw_L_done:
@@ -2099,6 +2413,12 @@
     v_add_u32 VT0, T2, VLANE
     ds_read_u8 VT4, VT0 offset:LDS_TM
     s_waitcnt lgkmcnt(0)
+#ifdef BRX_SLOTS
+    s_bitcmp1_b32 FLAGS, 6
+    s_cbranch_scc0 .Lx_lsu_noslots
+    SLOT_REMAP
+.Lx_lsu_noslots:
+#endif
     v_lshlrev_b32 VT4, 2, VT4
     ds_bpermute_b32 VT4, VT4, VLHOFF
     v_lshlrev_b32 VT3, 2, VLANE

@@ -1544,7 +1544,7 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
           "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", \
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
           "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", \
-          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "m0"
+          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "s11", "m0"
 // Two builds of the same loop (brx_hot.S, "Two builds of this file"): the bit window in VGPRs -- for a full chip, where
 // the CU's one scalar ALU is the busiest unit -- or in SGPRs -- for launches that leave the CUs mostly empty, where the
 // shortest dependent chain wins.  BrxKernelArgs::loop_build picks one per launch.
@@ -2105,8 +2105,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     cnt2 = cnt2 < a.defer_cap ? cnt2 : a.defer_cap; cnt3 = cnt3 < a.late_cap ? cnt3 : a.late_cap;
     const u32 n_streams = cnt0 + cnt1 + cnt2 + cnt3;
     if (n_streams == 0u) return;
-    // few streams per CU: the sparse-launch build of the loop (level 3 never has more than 4 per CU)
-    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold || (BRX_LEVEL == 3 && a.sw_threshold != 0u);
+    // few streams per CU: the sparse-launch build of the loop (levels 2 / 3 never have more than 8 / 4 per CU -- and their
+    // streams are the many-tree ones, whose literals take that build's tree cache: 4096 x mapsdatazrh 61 -> 45 ms,
+    // profiles/r05_slots_ab.txt)
+    const bool sw_loop = a.loop_build != 0u || n_streams <= a.sw_threshold || (BRX_LEVEL >= 2 && a.sw_threshold != 0u);
 #else
     // (behind the lean instance, BrxKernelArgs::s_list: queue slots [0, n) are this launch's own, the slots beyond are the
     // streams the lean kernel listed -- the large ones and the small ones it gave up on)

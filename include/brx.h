@@ -173,7 +173,9 @@ const char *brx_last_error(void);
  *   6        streams that were handed up at a LATER meta-block, with their decoder state (resumed there, not restarted)
  *   7        output bytes decoded twice because of hand-overs (0 = every such stream was resumed where it stood)
  *   8        (since the context was made) slices of bounded / pulled streams that paused in front of an item -- a header, an
- *            uncompressed block, a command -- that the RESIDENT input did not hold, to run it with more (brx_stream_new_reader) */
+ *            uncompressed block, a command -- that the RESIDENT input did not hold, to run it with more (brx_stream_new_reader)
+ *   9        (since the context was made) slices of bounded / pulled streams run again with a larger output buffer because ONE
+ *            command produced more than the room behind the window (the buffer grows to what the command needs) */
 double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Diagnostics (BRX_OPTION_TRACE = 1): 4 words per stream of the most recent launch -- start and end of its decode on the GPU's
@@ -244,8 +246,9 @@ brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
  * sliding window on the device, so the output resident at any time is bounded by the largest Brotli window (16 MiB) plus
  * one slice plus slack (~22 MiB) however large the stream (like the reference's Decompressor, whose state is its window,
  * src/lib.rs:377-394, 1560-1567).  Reads see decoded bytes as the slices complete; an invalid stream serves everything
- * decoded before the error.  A stream with a single command larger than the slack (a > 1 MiB copy or uncompressed
- * meta-block) falls back to whole-stream decoding. */
+ * decoded before the error.  A single command that produces more than the slack (a > 1 MiB copy, insert or uncompressed
+ * meta-block) makes the buffer grow to what that command needs (at most ~48 MiB more: brx_last_timing 9 counts such slices);
+ * only if that allocation fails does the stream fall back to whole-stream decoding. */
 brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
 /* The bounded reader over a SOURCE instead of a buffer: the reference's Decompressor::new(r: R) with R: Read
  * (src/lib.rs:398-410), which pulls its input through a BufReader as it decodes (src/bitreader/mod.rs:21-53).  `read` is called
@@ -253,8 +256,11 @@ brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
  * 0 = end of input (and is not called again).  Compressed input is held in a sliding 8 MiB device window the same way the
  * output is (BRX_OPTION_READER_WINDOW): a stream of any length decodes with about 32 MiB of buffers on the device and 1 MiB on the
  * host.  A slice pauses before its resident input runs out -- in front of the header, uncompressed block or command that would
- * not fit -- and goes on once more is resident.  Limits: one command may not produce more than the reader's slack (1 MiB; such a
- * stream needs brx_stream_new) nor consume more compressed bytes than the window holds. */
+ * not fit -- and goes on once more is resident.  One item that needs more than the window holds (an uncompressed meta-block is
+ * up to 16 MiB) makes the window grow, doubling up to 256 MiB; one command that produces more than the slack makes the output
+ * buffer grow (see above).  `read` runs with the context's lock released: it may itself read from another brx_stream of the
+ * same context (a Decompressor over a Decompressor).  A callback that returns more than `cap` fails the stream
+ * (BRX_ERR_INVALID_ARGUMENT).  The context must outlive every read. */
 typedef size_t (*brx_read_fn)(void *user, uint8_t *buf, size_t cap);
 brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, void *user);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);

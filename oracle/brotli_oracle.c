@@ -869,7 +869,10 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
             }
             unsigned idx = cmap_l[bt * 64 + cid];
             unsigned s;
+            const uint64_t tr_lb = d->br.pos; /* (trace only) */
             lk = pcode_lookup(&lit[idx], &d->br, &s);
+            if (g_trace > 1) /* analysis aid (BRO_TRACE=2): block type, context id, tree, code length of every literal */
+                fprintf(stderr, "LIT %u %u %u %u\n", bt, cid, idx, (unsigned)(d->br.pos - tr_lb));
             if (lk == LK_NONE) { rc = BRO_PARSE_ERROR_INSERT_LITERALS; goto out; }
             if (lk == LK_EOF) { rc = BRO_UNEXPECTED_EOF; goto out; }
             d->out[d->pos + k] = (uint8_t)s;
@@ -999,7 +1002,8 @@ out:
 int bro_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len, unsigned flags,
                bro_stats *stats) {
     bro_init();
-    g_trace = getenv("BRO_TRACE") != NULL; /* read once per stream: keeps the command loop free of libc calls */
+    g_trace = getenv("BRO_TRACE") ? atoi(getenv("BRO_TRACE")) : 0;
+    if (getenv("BRO_TRACE") && !g_trace) g_trace = 1; /* read once per stream: keeps the command loop free of libc calls */
     Dec d;
     memset(&d, 0, sizeof d);
     d.br.p = in;

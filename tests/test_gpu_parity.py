@@ -493,6 +493,73 @@ def test_pulled_reader_on_input_heavy_streams():
         c2.close()
 
 
+def test_pulled_reader_grows_its_windows():
+    """Round 5.  (a) BRX_OPTION_READER_WINDOW beyond the 8 MiB default: the device window is allocated at the option's
+    size (40 MiB of uncompressed meta-blocks through a 32 MiB window: it fills past 8 MiB at once).  (b) One item that needs more
+    input than the window holds -- uncompressed meta-blocks of 1.6 MiB under a 1 MiB window: the window doubles (before, such a
+    stream stalled and came out as UnexpectedEOF).  (c) One command that produces more than the reader's slack -- a copy of
+    7 MiB + 5 in every unit (more than the 5 .. 6 MiB a full window leaves in the buffer): the output buffer grows to what the command needs and the slice runs again (before: a library error
+    over a reader); the context counts those slices.  (d) A read callback that itself reads from another stream of the SAME context
+    (a Decompressor over a Decompressor: the callback runs with the context's lock released)."""
+    import craft
+    import io
+    from brotli_rs_amd import brx
+    c2 = brx_knobs.context(0)
+    try:
+        parts = craft.periodic_stream_parts(13, raw=True)
+        c2.set_option("reader_window", 32 << 20)
+        d = brx.Decompressor(_periodic_source(parts, 640, chunk=1 << 20), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 640 * len(parts[3])  # 40 MiB
+        d.close()
+        parts = craft.periodic_stream_parts(15, raw=True, literals=(1 << 20) + 600 * 1024 + 77)
+        c2.set_option("reader_window", 1 << 20)
+        d = brx.Decompressor(_periodic_source(parts, 12), c2, streaming=True)
+        assert _read_periodic(d, parts[3]) == 12 * len(parts[3])
+        d.close()
+        c2.set_option("reader_window", 8 << 20)
+        # (c) 64 literals, then a copy of 7 MiB + 5 from 8 back (a periodic fill), one meta-block per unit
+        lits = bytes(range(64, 128))
+        n = (7 << 20) + 5
+        b = craft.Bits()
+        craft.stream_header(b, 22)
+        b.put(0, 1); b.put(3, 2); b.put(0, 1); b.put(0, 2); b.put(0, (-b.n) % 8)  # empty metadata block: byte boundary
+        prefix = b.bytes()
+        b = craft.Bits()
+        craft.MetaBlock([(lits, n, 8)], mlen=len(lits) + n).emit(b, False, len(lits) + n)
+        b.put(0, 1); b.put(3, 2); b.put(0, 1); b.put(0, 2); b.put(0, (-b.n) % 8)
+        unit = b.bytes()
+        unit_out = lits + (lits[-8:] * (n // 8 + 1))[:n]
+        st, o = oracle.decode(prefix + unit * 2 + b"\x03", 0, cap=2 * len(unit_out) + 64)
+        assert st == 0 and o == unit_out * 2
+        before = c2.stream_regrown()
+        d = brx.Decompressor(_periodic_source((prefix, unit, b"\x03"), 6), c2, streaming=True)
+        assert _read_periodic(d, unit_out) == 6 * len(unit_out)
+        d.close()
+        assert c2.stream_regrown() > before
+        # (d) nested readers on one context
+        inner = _read("alice29.txt.compressed")
+        outer_plain = inner * 3  # the outer stream decodes to three copies of the INNER COMPRESSED stream ...
+        outer = c2.generate_batch([outer_plain], metablock_bytes=1 << 16, adaptive=True)[0]
+        assert oracle.decode(outer, 0, cap=len(outer_plain) + 64)[1] == outer_plain
+        d_outer = brx.Decompressor(io.BytesIO(outer), c2, streaming=True)
+
+        class First(io.RawIOBase):  # ... of which the inner decompressor reads exactly the first
+            left = len(inner)
+
+            def read(self, k=-1):
+                k = min(self.left, k if k >= 0 else 1 << 16)
+                got = d_outer.read(k) if k else b""
+                self.left -= len(got)
+                return got
+
+        d_inner = brx.Decompressor(First(), c2, streaming=True)
+        assert d_inner.read() == _read("alice29.txt")
+        d_inner.close()
+        d_outer.close()
+    finally:
+        c2.close()
+
+
 def test_python_decompressor_streaming_mode(ctx):
     """brx.Decompressor(reader, streaming=True): pulled input; trailing bytes behind the stream's end are the reference's
     ExpectedEndOfStream even when they only arrive after the decoder has finished with what was resident."""

@@ -79,6 +79,8 @@ def parse_operand(tok):
         return ("s", S_EXEC, 2)
     if tok == "exec_lo":
         return ("s", S_EXEC, 1)
+    if tok == "exec_hi":
+        return ("s", S_EXEC + 1, 1)
     m = re.fullmatch(r"gpr_idx\(([A-Z0-9,]*)\)", tok)
     if m:
         bits = {"SRC0": 1, "SRC1": 2, "SRC2": 4, "DST": 8}
@@ -521,6 +523,8 @@ class Wave:
             else:
                 r = (a.astype(np.uint64) * b.astype(np.uint64)).astype(np.uint32)
             self.vset(ops[0], r)
+        elif op == "v_not_b32":
+            self.vset(ops[0], ~self.vsrc(ops[1]))
         elif op == "v_lshl_add_u32":
             self.vset(ops[0], (self.vsrc(ops[1]) << (self.vsrc(ops[2]) & U32(31))) + self.vsrc(ops[3]))
         elif op == "v_add_lshl_u32":
