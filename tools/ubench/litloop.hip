@@ -31,7 +31,8 @@ typedef unsigned int u32;
                      "s_waitcnt lgkmcnt(0)\n s_memtime %1\n s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, -1\n"     \
                      : "=s"(t0), "=s"(t1) : : "vcc", "scc", "memory", "m0", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
                        "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", \
-                       "v19", "v20", "v21", "v22", "v30", "v31", "v32", "v33");                              \
+                       "v19", "v20", "v21", "v22", "v30", "v31", "v32", "v33", "v9", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
+                       "v50", "v51", "v52", "v53", "v54");                              \
         if (threadIdx.x == 0) out[0] = t1 - t0;                                                              \
     }
 
@@ -135,6 +136,60 @@ KERNEL(k_slot_nomiss, "-1",
     SL_FINISH("v17", "1", "s64", "s65")
     "s_branch 1b\n8:\n")
 
+// ---- the design SURVEY 7 step 6 / VERDICT r4 #1 name: lanes = bit offsets x candidate trees.  One BATCH decodes the literal
+// that would start at every bit offset 0 .. 31 of the window under each candidate tree (per lane: the canonical compare as a
+// running minimum over the 15 length words, then ONE fetch), then the true chain is WALKED with v_readlane: entry | length <<
+// 16 of (tree, offset), context -> tree of the next literal, offset += length.  v40 .. v54: word[L] = limit[L] << 16 | base << 4
+// | L of the lane's tree (here: every code 5 bits long).  OFFS lanes per tree; a batch is good for offsets <= LIMIT.
+#define OP_PRE                                                                                              \
+    "v_mov_b32 v40, 1\n v_mov_b32 v41, 2\n v_mov_b32 v42, 3\n v_mov_b32 v43, 4\n"                          \
+    "v_mov_b32 v44, 0x80000005\n v_mov_b32 v45, 0x80000006\n v_mov_b32 v46, 0x80000007\n v_mov_b32 v47, 0x80000008\n" \
+    "v_mov_b32 v48, 0x80000009\n v_mov_b32 v49, 0x8000000a\n v_mov_b32 v50, 0x8000000b\n v_mov_b32 v51, 0x8000000c\n" \
+    "v_mov_b32 v52, 0x8000000d\n v_mov_b32 v53, 0x8000000e\n v_mov_b32 v54, 0x8000000f\n"
+#define OP_BATCH(offmask)                                                                                   \
+    "v_and_b32 v9, " offmask ", v20\n"                                                                      \
+    "v_lshrrev_b64 v[14:15], v9, s[60:61]\n v_bfrev_b32 v14, v14\n v_lshrrev_b32 v16, 1, v14\n v_or_b32 v16, 0xffff, v16\n v_add_u32 v16, 1, v16\n" \
+    "v_sub_u32 v18, v40, v16\n v_sub_u32 v19, v41, v16\n v_min_u32 v17, v18, v19\n"                        \
+    "v_sub_u32 v18, v42, v16\n v_sub_u32 v19, v43, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v44, v16\n v_sub_u32 v19, v45, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v46, v16\n v_sub_u32 v19, v47, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v48, v16\n v_sub_u32 v19, v49, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v50, v16\n v_sub_u32 v19, v51, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v52, v16\n v_sub_u32 v19, v53, v16\n v_min3_u32 v17, v17, v18, v19\n"                  \
+    "v_sub_u32 v18, v54, v16\n v_min_u32 v17, v17, v18\n"                                                  \
+    "v_add_u32 v17, v17, v16\n v_and_b32 v18, 15, v17\n v_bfe_i32 v19, v17, 4, 12\n v_sub_u32 v22, 32, v18\n" \
+    "v_lshrrev_b32 v22, v22, v14\n v_add_u32 v22, v22, v19\n v_lshl_add_u32 v22, v22, 1, v12\n v_and_b32 v22, 0x7fe, v22\n" \
+    "ds_read_u16 v21, v22\n s_waitcnt lgkmcnt(0)\n v_lshl_or_b32 v21, v18, 16, v21\n s_mov_b32 s70, 0\n"
+// one walk step, context modelling (mode 3): s66 = lanes-per-tree * slot of the current literal's tree, s70 = its bit offset
+#define OP_STEP_CTX(endlbl)                                                                                 \
+    "s_add_u32 s67, s66, s70\n v_readlane_b32 s69, v21, s67\n s_bfe_u32 s65, s69, 0x3000d\n s_lshl3_add_u32 s63, s65, s64\n s_and_b32 s63, s63, 63\n" \
+    "v_readlane_b32 s66, v13, s63\n s_bfe_u32 s68, s69, 0x40010\n s_add_u32 s70, s70, s68\n v_writelane_b32 v31, s69, m0\n" \
+    "s_mov_b32 s64, s65\n s_sub_u32 m0, m0, 1\n s_cbranch_scc1 8f\n s_cmp_gt_u32 s70, s71\n s_cbranch_scc1 " endlbl "\n"
+// one walk step, one tree (no contexts)
+#define OP_STEP_ONE(endlbl)                                                                                 \
+    "v_readlane_b32 s69, v21, s70\n s_bfe_u32 s68, s69, 0x40010\n s_add_u32 s70, s70, s68\n v_writelane_b32 v31, s69, m0\n" \
+    "s_sub_u32 m0, m0, 1\n s_cbranch_scc1 8f\n s_cmp_gt_u32 s70, s71\n s_cbranch_scc1 " endlbl "\n"
+#define OP_TAKE "2:\n s_lshr_b64 s[60:61], s[60:61], s70\n s_or_b32 s61, s61, 0x9e370000\n s_sub_u32 s62, s62, s70\n s_cbranch_scc1 9f\n9:\n"
+#define OP_KERNEL(NAME, LIMIT, OFFMASK, SLOTSH, STEP)                                                        \
+    KERNEL(NAME, "-1", OP_PRE "s_mov_b32 s71, " LIMIT "\n v_lshrrev_b32 v13, " SLOTSH ", v13\n s_mov_b32 s66, 0\n" \
+    "1:\n" OP_BATCH(OFFMASK)                                                                                \
+    STEP("2f") STEP("2f") STEP("2f") STEP("2f") STEP("2f") STEP("2f") STEP("2f") STEP("2f")                 \
+    OP_TAKE "s_branch 1b\n8:\n")
+// (v13 = 16 * (lane & 3) from PRE: >> 0 = 16 lanes per tree, 4 trees; << 1 would be 32 lanes per tree -- PRE's v13 is 16 * slot,
+// the two-tree kernels mask it to one bit: slot in {0, 1} -> 0 / 32)
+OP_KERNEL(k_op_one_17, "17", "31", "8", OP_STEP_ONE)
+OP_KERNEL(k_op_one_31, "31", "31", "8", OP_STEP_ONE)
+OP_KERNEL(k_op_ctx4_12, "12", "15", "0", OP_STEP_CTX)
+__global__ void k_dummy() {}
+KERNEL(k_op_ctx2_17, "-1", OP_PRE "s_mov_b32 s71, 17\n v_and_b32 v13, 16, v13\n v_lshlrev_b32 v13, 1, v13\n s_mov_b32 s66, 0\n"
+    "1:\n" OP_BATCH("31")
+    OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f")
+    OP_TAKE "s_branch 1b\n8:\n")
+KERNEL(k_op_ctx2_31, "-1", OP_PRE "s_mov_b32 s71, 31\n v_and_b32 v13, 16, v13\n v_lshlrev_b32 v13, 1, v13\n s_mov_b32 s66, 0\n"
+    "1:\n" OP_BATCH("31")
+    OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f")
+    OP_TAKE "s_branch 1b\n8:\n")
+
 int main() {
     u64 *o;
     hipMalloc(&o, 64);
@@ -147,5 +202,10 @@ int main() {
     RUN(k_slot_vcc, "  ... compare into vcc + s_mov_b64");
     RUN(k_slot_17, "  ... EXEC = 17 lanes");
     RUN(k_slot_nomiss, "  ... no miss test");
+    RUN(k_op_one_17, "offsets x trees: ONE tree, batch good for offsets <= 17 (4 literals of 5 bits)");
+    RUN(k_op_one_31, "  ... for offsets <= 31 (7 literals)");
+    RUN(k_op_ctx2_17, "offsets x trees: 2 trees x 32 offsets, context walk, offsets <= 17 (4 literals)");
+    RUN(k_op_ctx2_31, "  ... offsets <= 31 (7 literals)");
+    RUN(k_op_ctx4_12, "offsets x trees: 4 trees x 16 offsets, context walk, offsets <= 12 (3 literals)");
     return 0;
 }
