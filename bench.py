@@ -299,6 +299,15 @@ class Batch:
         ctx.decode_batch_device(self.blob.data_ptr(), self.in_off.data_ptr(), self.n, self.out.data_ptr(), self.out_off.data_ptr(),
                                 self.out_len.data_ptr(), self.status.data_ptr(), timing=timing)
 
+    def poison(self, torch):
+        """Overwrite every output slot, length and status, so that a verify() afterwards proves that the NEXT step wrote them (without
+        this the bytes of the warm-up would satisfy it: VERDICT r4).  Waits for the fill: the decode runs on the context's own HIP stream."""
+        self.out.fill_(0xA5)
+        self.out_len.fill_(-1)
+        self.status.fill_(-1)
+        if self.out.is_cuda:
+            torch.cuda.synchronize()
+
     def verify(self, torch):
         """status, lengths, and every stream's bytes (checksum of checksums by equality)"""
         ok = bool((self.status == 0).all().item())
@@ -323,12 +332,16 @@ class Batch:
 def timed_pass(ctx, batch, steps, warmup, barrier):
     """W untimed steps, barrier + synchronize, exactly K timed steps (HIP events around each kernel, on the stream it is
     launched on), barrier + synchronize.  Returns (wall seconds, kernel ms of every step)."""
+    import torch
     for _ in range(warmup):
         batch.step(ctx)
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        if k == steps - 1:
+            batch.poison(torch)  # inside the timed wall time (one device fill, ~0.1 % of a default run), outside the kernel's HIP events:
+                                 # what verify() sees afterwards is the LAST TIMED step's output
         batch.step(ctx, timing=True)
         kernel_ms.append(0.0 if STUB else ctx.last_timing_ms(1))
     barrier()
@@ -518,7 +531,7 @@ def main():
                           "streams_per_gpu": n,
                           "in_bytes_per_stream": int(lens.mean()), "out_bytes_per_stream": out_bytes_gpu // n,
                           "sharding": "independent streams, contiguous index range per rank, no data-path collective"},
-               "bit_exact": ok, "kernel_ms_per_rank": [round(v, 4) for v in kavg_ranks]}
+               "bit_exact": ok, "bit_exact_of": "the last timed step (outputs, lengths and status poisoned in front of it)", "kernel_ms_per_rank": [round(v, 4) for v in kavg_ranks]}
         if not STUB and brx_knobs.options_from_env():
             res["options"] = brx_knobs.options_from_env()  # (non-default library options of this run, tests/brx_knobs.py)
         if STUB:
