@@ -556,11 +556,30 @@ def main():
             dist.destroy_process_group()
         sys.exit(0 if ok else 2)
 
+    # Every collective of this run is behind us.  What follows is rank 0's alone and takes a while (CPU baseline ~12 s, rocprofv3
+    # child passes, single-stream launches): the other ranks must not sit in an RCCL call meanwhile (its watchdog would end the job) --
+    # the group is taken down HERE, together, and they leave.  (VERDICT r4 #6b)
+    used_rccl = dist.is_initialized()
+    if used_rccl:
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        dist.destroy_process_group()  # (RCCL prints its library path to stdout around here: the JSON line goes last)
+    if rank != 0:
+        ctx.close()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0 if ok else 2)  # (no interpreter teardown: RCCL's destructor prints to stdout, the contract is ONE JSON line)
+
     if rank == 0:
         import oracle_py
         cb = None
         if not args.no_cpu_baseline:
-            cb, _ = cpu_baseline(comp, expect, args.cpu_seconds)
+            try:
+                cb, _ = cpu_baseline(comp, expect, args.cpu_seconds)
+            except Exception as e:  # (a leg of rank 0 never takes the line down with it)
+                res["cpu_baseline_error"] = repr(e)[:200]
         # ALGORITHMIC bytes per stream: compressed in + decompressed out + window-copy bytes read +
         # dictionary bytes read; per launch = summed over the streams of one GPU.
         alg_launch = batch.byte_model("alg")
@@ -572,7 +591,10 @@ def main():
         # profiles/hbm_traffic.json is used -- only if it is of THIS kernel (kernel_source_id), else traffic = null.
         traffic, traffic_src, traffic_detail = None, None, None
         if not args.no_traffic and world == 1 and not under_profiler() and not STUB:
-            traffic, traffic_detail = measured_traffic(args.workload, args.streams)
+            try:
+                traffic, traffic_detail = measured_traffic(args.workload, args.streams)
+            except Exception as e:
+                traffic, traffic_detail = None, repr(e)[:200]
             if traffic is not None:
                 traffic_src = "in-run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes, 2 launches each)"
             else:
@@ -678,9 +700,6 @@ def main():
             except Exception:
                 pass
     ctx.close()
-    used_rccl = dist.is_initialized()
-    if used_rccl:
-        dist.destroy_process_group()  # (RCCL prints its library path to stdout around here: the JSON line goes last)
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(res), flush=True)

@@ -1,7 +1,8 @@
 """Sharding a batch of independent Brotli streams over the GPUs of one node.
 
 Streams share no state (one reference `Decompressor` owns everything it touches, src/lib.rs:378-394), so the
-batch partitions trivially: rank r of G takes the contiguous index range [r*N/G, (r+1)*N/G).  There is NO
+batch partitions trivially: rank r of G takes the contiguous index range [r*N/G, (r+1)*N/G) -- or, for ragged batches
+(`decode_sharded(balance=True)`), the streams dealt by compressed size so that every rank carries about the same bytes.  There is NO
 collective inside the decode.  RCCL (torch.distributed backend "nccl") is used only to move data in and out, one
 exchange each way, as grouped point-to-point transfers of RAGGED device buffers (`dist.batch_isend_irecv` =
 ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd): `scatter_ragged` hands every rank exactly its slice of the
@@ -28,6 +29,66 @@ def shard_range(n: int, rank: int, world: int):
 
 def shard_ranges(n: int, world: int):
     return [shard_range(n, r, world) for r in range(world)]
+
+
+def balanced_order(sizes, world: int):
+    """SURVEY 8e for HETEROGENEOUS batches: an order of the streams under which the contiguous ranges of `shard_range` carry about
+    equal compressed bytes -- sort by compressed size (largest first: a GPU's time follows its longest streams and its total), deal
+    to the ranks in snake order 0 .. G-1, G-1 .. 0, a rank that has its count is skipped.  Returns perm (int64[n]): position k of
+    the new order holds stream perm[k] of the caller's.  Homogeneous batches gain nothing from it (the default stays contiguous)."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    n = int(sizes.size)
+    want = [hi - lo for lo, hi in shard_ranges(n, world)]
+    buckets = [[] for _ in range(world)]
+    order = np.argsort(-sizes, kind="stable")
+    r, step = 0, 1
+    for i in order:
+        for _ in range(2 * world):  # next rank (snake) that still has room
+            if len(buckets[r]) < want[r]:
+                break
+            nr = r + step
+            if nr < 0 or nr >= world:
+                step = -step
+            else:
+                r = nr
+        buckets[r].append(int(i))
+        nr = r + step
+        if nr < 0 or nr >= world:
+            step = -step
+        else:
+            r = nr
+    perm = np.array([i for b in buckets for i in b], dtype=np.int64)
+    assert perm.size == n and all(len(b) == w for b, w in zip(buckets, want))
+    return perm
+
+
+def reorder_ragged(data, offsets, perm):
+    """The ragged batch (data uint8[total], offsets int64[n+1]) with its items in the order perm: (data', offsets').  Index gather on
+    the tensors' device, in pieces of <= 64 MiB (as `compact`)."""
+    dev = data.device
+    perm_t = torch.as_tensor(perm, dtype=torch.int64, device=dev)
+    n = int(perm_t.numel())
+    lens = (offsets[1:] - offsets[:-1]).to(torch.int64)[perm_t]
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if n:
+        offs[1:] = torch.cumsum(lens, 0)
+    total = int(offs[-1].item()) if n else 0
+    dst = torch.empty(total, dtype=torch.uint8, device=dev)
+    if total == 0:
+        return dst, offs
+    src_start = offsets[:-1].to(torch.int64)[perm_t]
+    offs_h = offs.cpu().numpy()
+    piece = 64 << 20
+    i = 0
+    while i < n:
+        j = int(np.searchsorted(offs_h, offs_h[i] + piece, side="right")) - 1
+        j = min(max(j, i + 1), n)
+        p0, p1 = int(offs_h[i]), int(offs_h[j])
+        if p1 > p0:
+            idx = torch.repeat_interleave(src_start[i:j] - offs[i:j], lens[i:j]) + torch.arange(p0, p1, dtype=torch.int64, device=dev)
+            dst[p0:p1] = data[idx]
+        i = j
+    return dst, offs
 
 
 def _dev(device):
@@ -150,8 +211,10 @@ def gather_ragged(data, offsets, status, n_total: int, dst: int = 0, device=None
     return full, offs, st
 
 
-def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=None):
-    """scatter -> local decode -> gather, device resident end to end.
+def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=None, balance: bool = False):
+    """scatter -> local decode -> gather, device resident end to end.  balance=True (ragged batches): the root deals the streams to
+    the ranks by compressed size (`balanced_order`) instead of by index range, and puts the results back into the caller's order --
+    two index gathers on the root, nothing else changes (still no collective inside the decode).
 
     Root passes `data` uint8[total], `offsets` int64[n+1], `capacities` int64[n] (tensors on `device`).
     `decode_fn(in_t, in_off_t, n, out_t, out_off_t, out_len_t, status_t)` fills the last three for the n streams of the
@@ -159,6 +222,12 @@ def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=No
     and in the CPU tests a stand-in with the same signature.  Returns gather_ragged's result."""
     rank = dist.get_rank()
     dev = _dev(device)
+    perm = None
+    if balance and rank == src:
+        sizes = (offsets[1:] - offsets[:-1]).cpu().numpy()
+        perm = balanced_order(sizes, dist.get_world_size())
+        data, offsets = reorder_ragged(data, offsets, perm)
+        capacities = capacities.to(dev)[torch.as_tensor(perm, dtype=torch.int64, device=dev)]
     shard, offs, (a, b), n = scatter_ragged(data, offsets, src=src, device=dev)
     caps = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
     if rank == src:
@@ -176,7 +245,13 @@ def decode_sharded(data, offsets, capacities, decode_fn, src: int = 0, device=No
         decode_fn(shard, offs, k, out, out_off, out_len, status)
     produced = torch.where(status == 0, out_len, torch.zeros_like(out_len))  # a failed stream contributes no bytes
     cdata, coffs = compact(out, out_off, produced, ctx=getattr(decode_fn, "ctx", None))
-    return gather_ragged(cdata, coffs, status, n, dst=src, device=dev)
+    full, offs_all, st_all = gather_ragged(cdata, coffs, status, n, dst=src, device=dev)
+    if perm is not None and full is not None:  # back into the caller's order: position perm[k] takes item k
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.size, dtype=np.int64)
+        full, offs_all = reorder_ragged(full, offs_all, inv)
+        st_all = st_all[torch.as_tensor(inv, dtype=torch.int64, device=st_all.device)]
+    return full, offs_all, st_all
 
 
 # ---- convenience for callers that hold Python byte strings ----------------------------------------------------------

@@ -31,6 +31,9 @@ def test_gpus_2_starts_two_ranks():
     assert len(res["kernel_ms_per_rank"]) == 2
     assert res["strong"]["streams_per_gpu"] == 4 and res["strong"]["streams_total"] == 8
     assert res["scaling"] == "weak" and res["bit_exact"] is True
+    assert len(res["strong"]["kernel_ms_per_rank"]) == 2 and res["strong"]["unit"] == "MB/s" and "what" in res["strong"]
+    assert res["steps"] == 2 and res["warmup"] == 1 and res["higher_is_better"] is True and res["vs_baseline"] is None
+    assert "poisoned" in res["bit_exact_of"]
 
 
 def test_gpus_2_without_two_gpus_fails_loudly():

@@ -64,7 +64,7 @@ def _check(names, data, offs, st):
     return ok
 
 
-def _worker(rank, world, port, result_path, backend):
+def _worker(rank, world, port, result_path, backend, balance=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -89,7 +89,7 @@ def _worker(rank, world, port, result_path, backend):
         fn = shard.hip_decode_fn(ctx)
     else:
         fn = _oracle_decode_fn()
-    out, out_offs, st = shard.decode_sharded(data, offs, caps, fn, src=0, device=dev)
+    out, out_offs, st = shard.decode_sharded(data, offs, caps, fn, src=0, device=dev, balance=balance)
     if rank == 0:
         with open(result_path, "w") as f:
             f.write("ok" if _check(names, out, out_offs, st) else "bad")
@@ -132,6 +132,47 @@ def test_scatter_decode_gather_world3_uneven(tmp_path):
     port = _free_port()
     result = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(3, port, result, "gloo"), nprocs=3, join=True)
+    assert open(result).read() == "ok"
+
+
+def test_balanced_order_deals_by_compressed_size():
+    """ragged batches are dealt by size.  A batch sorted by size (the worst case for contiguous ranges) ends up within a
+    few percent of equal bytes per rank; the counts are those of the contiguous ranges; every stream appears exactly once."""
+    from brotli_rs_amd import shard
+    rng = np.random.default_rng(5)
+    for n, world in ((52, 2), (52, 3), (4096, 8), (7, 8), (0, 4), (1000, 3)):
+        sizes = np.sort(rng.integers(10, 500000, size=n))
+        perm = shard.balanced_order(sizes, world)
+        assert sorted(perm.tolist()) == list(range(n))
+        loads, contiguous = [], []
+        for lo, hi in shard.shard_ranges(n, world):
+            loads.append(int(sizes[perm[lo:hi]].sum()))
+            contiguous.append(int(sizes[lo:hi].sum()))
+        if n >= 50:
+            assert max(loads) <= 1.08 * (sum(loads) / world), (n, world, loads)
+            assert max(contiguous) > 1.3 * (sum(loads) / world)  # (what the index ranges would have given)
+
+
+def test_reorder_ragged_round_trip():
+    from brotli_rs_amd import shard
+    items = [bytes([i]) * (i * 7 % 23) for i in range(40)]
+    data, offs = shard.pack(items)
+    perm = np.random.default_rng(1).permutation(len(items))
+    d2, o2 = shard.reorder_ragged(data, offs, perm)
+    assert shard.unpack(d2, o2) == [items[i] for i in perm]
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(items))
+    d3, o3 = shard.reorder_ragged(d2, o2, inv)
+    assert shard.unpack(d3, o3) == items
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_decode_gather_balanced(tmp_path, world):
+    """The same ragged fixture batch dealt by compressed size: results come back in the caller's order."""
+    port = _free_port()
+    result = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, port, result, "gloo", True), nprocs=world, join=True)
     assert open(result).read() == "ok"
 
 
