@@ -263,6 +263,10 @@ class Context:
         """Slices of bounded / pulled streams of this context that paused in front of an item the resident input did not hold."""
         return int(self._lib.brx_last_timing(self._h, 8))
 
+    def last_spec_rollbacks(self):
+        """Meta-blocks of the most recent launch taken back after a speculative end (the fast loop read on past the stream's input)."""
+        return int(self._lib.brx_last_timing(self._h, 10))
+
     def stream_regrown(self):
         """Slices of bounded / pulled streams of this context run again with a larger output buffer (one command beyond the slack)."""
         return int(self._lib.brx_last_timing(self._h, 9))

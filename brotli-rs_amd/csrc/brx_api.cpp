@@ -885,15 +885,16 @@ extern "C" double brx_last_timing(brx_ctx *c, int which) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: slices run again with a larger output buffer
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
-    if (which >= 2 && which <= 7) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
+    if ((which >= 2 && which <= 7) || which == 10) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
                                     // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
                                     // regular kernel (large ones + given up); 6 = streams of the late list (handed up with their
                                     // state at a later meta-block); 7 = bytes decoded twice (0: every one of those was resumed)
         if (!c->any_launch) return -1.0;
         if (!c->last_counter) return 0.0;
-        uint32_t w[16];
+        uint32_t w[32];
         if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
-        if (hipMemcpy(w, c->last_counter, 64, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        if (hipMemcpy(w, c->last_counter, 128, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        if (which == 10) return (double)w[18]; // meta-blocks taken back after a speculative end (the stream read on past its input)
         const uint32_t late = std::min<uint32_t>(w[8], BRX_LATE_CAP);
         switch (which) {
         case 2: return (double)w[5] + w[6] + w[7] + late;

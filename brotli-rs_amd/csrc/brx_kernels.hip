@@ -356,6 +356,8 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_MIRROR 40  // (2 words) host-visible mirror of the output slot, or 0
 #define ST_PAUSE_AT 43 // (2 words) resumable mode: seg_frame stops between two meta-blocks once this many bytes are out (else ~0)
 #define ST_IN_LOW 45   // (2 words) ... or once the input cursor is this far (BrxResume::in_low; else ~0)
+#define ST_SPEC 47    // 1: batch decode -- the assembly loop may run past the end of the input (a meta-block that did is taken back and decoded
+                      // again by the C++ loop: "speculative end" in the kernel's stream loop); 0: the resumable decode, END_MARGIN applies
 #define ST_NEED 42    // after a header whose tables spilled: words of table memory the meta-block needs (Dec::need_peak)
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
 #define SEG_PAUSED 101u      // seg_frame (resumable mode): stopped between two meta-blocks, ST_PAUSE_AT reached
@@ -1706,7 +1708,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             if (!prepare_fast_tables(d, s, m, I.nbl, tm_u8(d, s, m.cmode_w * 4u), uniform)) { ok = 0u; why |= 128u; }
             else ok = uniform ? 1u : 3u; // bit 1: mixed context modes
         }
-        s.mbw[MBW_ASM] = ok;
+        s.mbw[MBW_ASM] = ok ? (ok | (rfl(s.st[ST_SPEC]) << 2)) : 0u; // bit 2: where the loop is poisoned (brx_hot.S, .Lwsafe_spec)
         if (!ok) s.pad[8] |= why;
     }
     const bool fast_tables = rfl(s.mbw[MBW_ASM]) != 0u; // symbol entries are in the assembly loop's forms
@@ -2049,9 +2051,9 @@ FI u32 level_for(u32 need) {
 // (src/lib.rs:1572-1573 resets everything of the meta-block; output position, window, the last four distances stay) plus
 // this decoder's cursor and the framing of the meta-block whose header comes next.
 enum { HU_BITPOS = 0, HU_POS = 2, HU_WINDOW = 3, HU_DIST = 4, HU_WD = 8, HU_ISLAST = 10, HU_MLEN = 11, HU_SID = 12, HU_WORDS = 16 };
-#if BRX_LEVEL > 0
 // Resume with state: the ring takes the last BRX_RING_BYTES of the stream's output back from HBM (the kernel that handed the
-// stream up flushed everything; it ran in an earlier launch, so its stores are visible).  Units beyond the output's ends read
+// stream up flushed everything; it ran in an earlier launch, so its stores are visible -- the speculative end of the stream loop
+// calls it behind a fence for this wave's own stores).  Units beyond the output's ends read
 // as zeros or stale bytes: no command reads them before it has written them.
 __device__ __noinline__ void seg_resume() {
     Lds &s = g_lds;
@@ -2074,7 +2076,6 @@ __device__ __noinline__ void seg_resume() {
         s.ring[v & RMASK] = (u8)__builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, v - BRX_RING_BYTES - d.a, 0, 0);
     }
 }
-#endif
 __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(BrxKernelArgs a) {
     Lds &s = g_lds;
     const u32 lane = threadIdx.x;
@@ -2240,6 +2241,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 s.st[ST_IACTAB] = (u32)(uintptr_t)a.t.iac; s.st[ST_IACTAB + 1] = (u32)((u64)(uintptr_t)a.t.iac >> 32);
                 s.st[ST_PAUSE_AT] = 0xffffffffu; s.st[ST_PAUSE_AT + 1] = 0xffffffffu;
                 s.st[ST_IN_LOW] = 0xffffffffu; s.st[ST_IN_LOW + 1] = 0xffffffffu;
+                s.st[ST_SPEC] = (a.resume == nullptr && a.debug_stop == 0u) ? 1u : 0u;
             }
             if (lane < 32u) s.pad[lane] = 0u;
         }
@@ -2422,8 +2424,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #endif
         st = seg_frame();
         PT_ADD(0, pd);
+        bool exact = false; // this meta-block is decoded again after a speculative end: the C++ loop alone
         while (st == SEG_NEED_HEADER) {
             hdr_bitpos = get64(s, 3);
+            const u32 st_bak = s.st[lane < 48u ? lane : 0u]; // Lds::st at the meta-block's header, one word per lane ("speculative end" below)
             st = cold_header();
             PT_ADD(1, pd);
             if (st) break;
@@ -2444,7 +2448,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 if (hand != 0u) break;
             }
 #endif
-            if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u)) {
+            if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u) || exact) {
                 // the C++ loop alone, whole meta-block per call: a bring-up mode, and the way of streams of a few dozen
                 // bytes (a handful of commands, e.g. the RLE-like fills of BASELINE configs 3 / 4): preparing the
                 // assembly loop's tables and handing over at every long copy costs more than it saves there
@@ -2492,7 +2496,26 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | ((r & 16u) ? HC_TO_END : 0u));
                 }
                 PT_ADD(3, pd);
+                // ---- speculative end (round 5).  In a batch the assembly loop is poisoned only BEHIND the end of the input (brx_hot.S,
+                // .Lwsafe_spec): a valid stream never gets there -- its last meta-block ends first, and its last bytes no longer pass
+                // through the C++ loop at 2 - 4 k cycles a symbol (a third of a 400-byte stream's time).  A stream that DID consume bits
+                // beyond its end (truncated, or corrupted so that it reads on) has decoded garbage: whatever status came of it is void.
+                // The meta-block is taken back -- everything out to HBM, Lds::st as it stood at the header (the flush cursor set to
+                // the position, a slab claimed meanwhile stays claimed), the ring reloaded from the stream's own output as for a late
+                // resume -- and decoded again by the C++ loop with the reference's exact end-of-input rules.
+                if (use_asm && rfl(s.st[ST_SPEC]) != 0u && get64(s, 3) > get64(s, 5)) {
+                    if (lane == 0u) (void)atomicAdd(a.work_counter + 18, 1u);
+                    seg_finish();
+                    __threadfence();
+                    if (lane < 48u && lane != 12u && lane != 20u && lane != 21u) s.st[lane] = st_bak;
+                    if (lane == 0u) s.st[12] = s.st[10] + s.st[11];
+                    seg_resume();
+                    exact = true;
+                    st = SEG_NEED_HEADER;
+                    continue;
+                }
             }
+            exact = false;
             if (st) break;
             st = seg_frame();
             PT_ADD(0, pd);

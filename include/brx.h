@@ -175,7 +175,10 @@ const char *brx_last_error(void);
  *   8        (since the context was made) slices of bounded / pulled streams that paused in front of an item -- a header, an
  *            uncompressed block, a command -- that the RESIDENT input did not hold, to run it with more (brx_stream_new_reader)
  *   9        (since the context was made) slices of bounded / pulled streams run again with a larger output buffer because ONE
- *            command produced more than the room behind the window (the buffer grows to what the command needs) */
+ *            command produced more than the room behind the window (the buffer grows to what the command needs)
+ *   10       meta-blocks of the most recent launch that were taken back and decoded again with the exact end-of-input rules because
+ *            the fast loop had read on past the end of the stream's input (truncated / corrupted streams only; 0 for valid ones)
+ */
 double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Diagnostics (BRX_OPTION_TRACE = 1): 4 words per stream of the most recent launch -- start and end of its decode on the GPU's
