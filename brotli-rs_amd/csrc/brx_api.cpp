@@ -751,6 +751,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
     // (measured: 4096 x alice29, 33 ms as one chunk, 40 ms as eight); chunks pay off from the second grid-full on
     const uint64_t total = (uint64_t)in_bytes + out_bytes;
     unsigned nchunks = (unsigned)std::min<uint64_t>(BRX_MAX_CHUNKS, std::max<uint64_t>(1, n / c->max_grid));
+    if (c->trace_on) nchunks = 1; // (BRX_OPTION_TRACE keeps ONE record set of ONE launch: concurrent chunk launches would mix theirs -- ADVICE r4)
     std::vector<uint32_t> cut(nchunks + 1, 0);
     {
         uint32_t i = 0;

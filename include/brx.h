@@ -151,7 +151,10 @@ int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
  *   out_len  n  decoded sizes (valid for status 0; "needed so far" for status 25)
  *   status   n  per-stream status codes (see above).  One bad stream never affects another.
  * Synchronous with respect to the host unless opts->hip_stream is given and BRX_MEM_DEVICE is set, in
- * which case the call only enqueues work on that stream.
+ * which case the call only enqueues work on that stream -- EXCEPT under launch plan B (BRX_OPTION_LEVELS = 2, or a context that
+ * met streams for the wider instances within its last 64 launches): the call then waits on the host for its classification
+ * pre-pass (0.3 .. 1 ms: it reads six counters to size the instances' grids) before it enqueues the decode kernels and returns.
+ * Everything it enqueues stays stream-ordered; only the host thread is held.  BRX_OPTION_LEVELS = 0 never waits.
  * Returns BRX_SUCCESS or a BRX_ERR_* code. */
 int brx_decode_batch(brx_ctx *ctx, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
                      const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_opts *opts);
@@ -183,7 +186,8 @@ double brx_last_timing(brx_ctx *ctx, int which);
 
 /* Diagnostics (BRX_OPTION_TRACE = 1): 4 words per stream of the most recent launch -- start and end of its decode on the GPU's
  * 100 MHz realtime counter, HW_ID register (XCC / SE / CU / SIMD / wave slot of the wave that decoded it) | kernel level << 32,
- * workgroup index | grid size << 32.  Streams decoded by the lean instance have all-zero records.  Waits for that launch. */
+ * workgroup index | grid size << 32.  Streams decoded by the lean instance have all-zero records.  Waits for that launch.
+ * While the option is on, the host-pointer path decodes a batch in ONE launch (no chunks on separate HIP streams). */
 int brx_last_trace(brx_ctx *ctx, uint64_t *dst, uint32_t n);
 
 /* Blocks until everything enqueued on the context's stream (or `hip_stream`) has finished. */
