@@ -15,7 +15,10 @@
 // brotli::InvalidData whose what() is the reference's description string (the reference returns
 // io::Error::new(ErrorKind::InvalidData, description), src/lib.rs:2177).  Two documented differences of the
 // GPU backend: the inner reader of a SHORT stream (compressed input < 4 MiB) is drained eagerly on the first read, a longer one is
-// pulled as it decodes; for a stream that fails the bytes
+// pulled as it decodes -- in bounded device memory whatever the stream holds: the reader's windows grow when ONE command produces
+// more than the room behind the output window or ONE item needs more input than the input window (brx.h, brx_stream_new_reader;
+// before round 5 such a stream failed over a reader), and the pull callback runs with the context's lock released, so R may itself
+// be a Decompressor on default_context(); for a stream that fails the bytes
 // produced before the error are delivered first, then the error (the reference delivers an unspecified prefix too,
 // SURVEY.md Q13).
 #pragma once
