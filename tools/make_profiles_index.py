@@ -7,16 +7,16 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 KINDS = [
-    (r"bench_(r\d+\w*)_(.+)_under_rocprof\.json", "bench.py line of `{1}` while rocprofv3 --kernel-trace --stats ran (pairs with `{0}_{1}_kernel_stats.csv`)"),
-    (r"bench_(r\d+\w*)_default.*\.json", "the default `python bench.py` line (what the driver runs): value, roofline incl. in-run PMC traffic, cpu_baseline, copy_path"),
-    (r"bench_(r\d+\w*)_(.+)\.json", "bench.py line of workload `{1}` (kernel ms by HIP events, chain floor, bit_exact)"),
-    (r"(r\d+\w*)_(.+)_kernel_stats\.csv", "rocprofv3 --kernel-trace --stats summary of `bench.py --workload {1}`: calls, total / average / min / max ns per kernel"),
-    (r"(r\d+\w*)_pmc.*\.(txt|csv)", "rocprofv3 --pmc SQ counters per dispatch (instructions by class, busy / wait cycles)"),
-    (r"(r\d+\w*)_sweep\.txt", "streams-per-GPU sweeps: MB/s and kernel ms from 1 to 16 384 streams"),
-    (r"(r\d+\w*)_pcie\.txt", "the host-pointer path, PCIe inclusive (pinned in place / pageable)"),
-    (r"(r\d+\w*)_residency\.txt", "per-stream start / end / CU traces of mixed batches (BRX_OPTION_TRACE)"),
-    (r"(r\d+\w*)_soak.*\.txt", "differential soak logs (fuzzers vs oracle), builder-run"),
-    (r"(r\d+\w*)_phases.*\.txt", "per-phase cycle timers of single streams (BRX_BRINGUP build)"),
+    (r"bench_(r\d+[a-z]?)_(.+)_under_rocprof\.json", "bench.py line of `{1}` while rocprofv3 --kernel-trace --stats ran (pairs with `{0}_{1}_kernel_stats.csv`)"),
+    (r"bench_(r\d+[a-z]?)_default.*\.json", "the default `python bench.py` line (what the driver runs): value, roofline incl. in-run PMC traffic, cpu_baseline, copy_path"),
+    (r"bench_(r\d+[a-z]?)_(.+)\.json", "bench.py line of workload `{1}` (kernel ms by HIP events, chain floor, bit_exact)"),
+    (r"(r\d+[a-z]?)_(.+)_kernel_stats\.csv", "rocprofv3 --kernel-trace --stats summary of `bench.py --workload {1}`: calls, total / average / min / max ns per kernel"),
+    (r"(r\d+[a-z]?)_pmc.*\.(txt|csv)", "rocprofv3 --pmc SQ counters per dispatch (instructions by class, busy / wait cycles)"),
+    (r"(r\d+[a-z]?)_sweep\.txt", "streams-per-GPU sweeps: MB/s and kernel ms from 1 to 16 384 streams"),
+    (r"(r\d+[a-z]?)_pcie\.txt", "the host-pointer path, PCIe inclusive (pinned in place / pageable)"),
+    (r"(r\d+[a-z]?)_residency\.txt", "per-stream start / end / CU traces of mixed batches (BRX_OPTION_TRACE)"),
+    (r"(r\d+[a-z]?)_soak.*\.txt", "differential soak logs (fuzzers vs oracle), builder-run"),
+    (r"(r\d+[a-z]?)_phases.*\.txt", "per-phase cycle timers of single streams (BRX_BRINGUP build)"),
     (r"hbm_traffic\.json", "HBM bytes per launch per workload from FETCH_SIZE / WRITE_SIZE passes, stamped with the kernel source id bench.py checks"),
     (r"EXPERIMENTS\.md", "the record of rounds 1 - 4: superseded numbers, everything measured and dropped"),
     (r"INDEX\.md", "this file"),
