@@ -45,6 +45,9 @@ WORKLOADS = {
     "lcet10x4096": (["lcet10.txt"], 4096),
     "plrabn12x4096": (["plrabn12.txt"], 4096),
     "mapsdatazrhx4096": (["mapsdatazrh"], 4096),
+    # 64 KiB of text at quality 11 (libbrotlienc fixtures, tests/golden/enc): 10 - 11 literal trees in one meta-block -- more than the
+    # eight the register-resident literal loop holds, small enough for the regular instance (round 5: the tree cache)
+    "text64k_q11x4096": (["enc:e042_text64k", "enc:e043_text64k", "enc:e051_text64k", "enc:e062_text64k"], 4096),
     # small streams (a launch of many short messages): 47 / 69 / 425 compressed bytes
     "quickfoxx16384": (["quickfox"], 16384),
     "ukkonooax16384": (["ukkonooa"], 16384),
@@ -68,6 +71,15 @@ def load_fixture(name):
     if name.startswith("farcopy_"):
         import craft
         return craft.farcopy_stream(int(name.split("_")[1]))
+    if name.startswith("enc:"):
+        import hashlib
+        import oracle_py
+        enc = os.path.join(os.path.dirname(GOLD), "enc")
+        comp = open(os.path.join(enc, name[4:] + ".compressed"), "rb").read()
+        st, out = oracle_py.decode(comp)[:2]
+        man = {e["name"]: e for e in json.load(open(os.path.join(enc, "manifest.json")))["streams"]}
+        assert st == 0 and hashlib.sha256(out).hexdigest() == man[name[4:]]["sha256"]
+        return comp, out
     if name.startswith("c5_"):
         import hashlib
         import oracle_py

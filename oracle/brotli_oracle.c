@@ -810,6 +810,7 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
         cmode[i] = (uint8_t)v;
     }
     if ((rc = parse_n_bltypes(d, &ntrees_l))) goto out; /* parse_n_trees_l :575 */
+    if (g_trace) fprintf(stderr, "NTL %u %u %zu\n", ntrees_l, L.nbl, mlen); /* analysis aid: literal trees, literal block types, MLEN */
     cmap_l = (uint8_t *)calloc(64 * (size_t)L.nbl, 1);
     if (!cmap_l) { rc = -1; goto out; }
     if (ntrees_l >= 2 && (rc = parse_context_map(d, ntrees_l, cmap_l, 64 * (size_t)L.nbl))) goto out;
