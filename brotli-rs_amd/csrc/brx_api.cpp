@@ -98,7 +98,7 @@ struct brx_ctx {
     unsigned grid_cap = 0;
     bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
     size_t reader_window = (8u << 20);            // BRX_OPTION_READER_WINDOW: compressed bytes a bounded / pulled stream keeps resident
-    uint64_t stream_regrown = 0;                  // bounded streams: slices run again with a larger output buffer (one command beyond the slack; brx_last_timing 9)
+    uint64_t stream_regrown = 0;                  // bounded streams: pauses in front of ONE item that did not fit the room behind the output window (brx_last_timing 9)
     uint64_t stream_short_slices = 0;             // slices of bounded streams that paused in front of an item the resident input did not hold (brx_last_timing 8)
     bool trace_on = false;                        // BRX_OPTION_TRACE: per-stream start / end / place of the most recent launch (brx_last_trace)
     unsigned long long *d_trace = nullptr;
@@ -884,7 +884,7 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: slices run again with a larger output buffer
+    if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: pauses in front of one item that needed more room behind the window
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
     if ((which >= 2 && which <= 7) || which == 10) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
                                     // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
@@ -1081,6 +1081,7 @@ struct brx_stream {
     bool no_progress = false, stalled = false; // the last slice paused where it started / ... and the window could not be improved
     bool pull_broken = false;                  // the read callback returned more than it was given room for
     size_t buf_size = 0;                       // size of d_buf: BRX_BOUNDED_BUFSIZE, more once a single command needed more
+    uint64_t want_room = 0;                    // the output position the item in front of the last pause runs to (BrxResume::need_room), or 0
     uint8_t *d_inwin = nullptr, *d_buf = nullptr;
     size_t in_window = (8u << 20);     // size of d_inwin (the context's reader_window when the stream started decoding)
     size_t in_fill = 0, in_cursor = 0; // bytes resident in d_inwin; the decoder's cursor in it (after the last good slice)
@@ -1261,6 +1262,12 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
         }
         s->shift = new_shift;
     }
+    if (s->want_room > BRX_STREAM_LIMIT) return BRX_ERR_OUT_OF_MEMORY; // (the stream runs past the 4 GiB - 256 B of the position arithmetic)
+    if (s->want_room > s->shift + s->buf_size) { // (the item the last slice paused in front of: still beyond the capacity after the slide)
+        int rc = bounded_grow_out(s, s->want_room);
+        if (rc) return BRX_ERR_OUT_OF_MEMORY;
+    }
+    s->want_room = 0;
     // the input side: keep at least half a window of compressed bytes in front of the cursor while the source has any
     const uint64_t pos0 = s->pos;
     if (!s->src_eof && (s->in_fill - s->in_cursor < s->in_window / 2u || s->no_progress)) {
@@ -1283,9 +1290,6 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
     {
         uint64_t meta[4] = {0, s->in_fill, 0, cap_abs};
         HIP_TRY(hipMemcpyAsync(s->d_meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
-        uint32_t rec_state0 = 0, bitmap0 = 0; // (what a slice that fails for room must find again: see below)
-        HIP_TRY(hipMemcpyAsync(&rec_state0, &s->d_rec->state, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&bitmap0, s->d_bitmap, 4, hipMemcpyDeviceToHost, c->stream));
         // While the source has more, the slice pauses a margin (1/32 of the window: 256 KiB) short of the resident end -- at a
         // command or meta-block boundary, or in the middle of a literal run -- and a segment that still runs into that end (a
         // header, an uncompressed block, one whole command of the C++ loop) is taken back by the kernel itself: the slice
@@ -1300,24 +1304,14 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
         int rc = launch(c, c->stream, false, s->d_inwin, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
                         (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
         if (rc) return rc;
-        uint64_t res[2] = {0, 0}, cur = 0;
+        uint64_t res[2] = {0, 0}, cur = 0, need_room = 0;
+        HIP_TRY(hipMemcpyAsync(&need_room, &s->d_rec->need_room, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res, s->d_meta + 4, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&cur, &s->d_rec->lds[BRX_RESUME_CURSOR_WORD], 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const int32_t st = (int32_t)(res[1] & 0xffffffffu);
-        if (st == BRX_OUTPUT_TOO_SMALL) {
-            // One command larger than the room behind the window.  The failed slice has written no state (the record is stored at a
-            // pause only) bar two things: it marked the record finished and gave its slab back -- both are put back as they were,
-            // the buffer grows to what the command asked for (res[0]), and the same slice runs again.  Only a command beyond
-            // BRX_BOUNDED_BUF_MAX (none the format allows) or a failed allocation leaves through the caller's fallback.
-            int rc2 = bounded_grow_out(s, res[0]);
-            if (rc2) return BRX_ERR_OUT_OF_MEMORY;
-            HIP_TRY(hipMemcpyAsync(&s->d_rec->state, &rec_state0, 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(s->d_bitmap, &bitmap0, 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->stream_regrown++;
-            return BRX_SUCCESS; // (pos, cursors and in_slide_pending as they were: brx_stream_read calls again)
-        }
+        if (st == BRX_OUTPUT_TOO_SMALL) return BRX_ERR_OUT_OF_MEMORY; // (not reached since round 5: the kernel takes such an item back and
+                                                                      // pauses in front of it -- need_room below; kept as the caller's fallback)
         s->in_slide_pending = 0;
         s->stalled = false;
         s->pos = res[0];
@@ -1331,7 +1325,12 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
             }
         } else {
             const size_t cursor = (size_t)(cur >> 3);
-            s->no_progress = cursor == s->in_cursor && res[0] == pos0;
+            // One item (a long copy or insert, an uncompressed meta-block) runs to `need_room` and did not fit behind the window: the
+            // kernel took it back and paused in front of it.  The next slice first slides the window; if the item still does not
+            // fit, the buffer grows to hold it (bounded_grow_out) -- nothing is decoded twice, nothing is put back.
+            s->want_room = need_room;
+            if (need_room) c->stream_regrown++;
+            s->no_progress = cursor == s->in_cursor && res[0] == pos0 && need_room == 0;
             if (res[0] < pause_at && cur < in_low) c->stream_short_slices++; // (paused in front of something that did not fit what was resident)
             s->in_cursor = cursor;
         }

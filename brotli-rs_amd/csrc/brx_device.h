@@ -92,8 +92,8 @@ struct BrxDeviceTables {
 // cursor comes within a margin of the resident end while the source has more (`in_low`); a segment that still runs into the end -- a
 // single command or header longer than the margin -- is taken back by the kernel itself (BRX_ST_RESTORE in brx_kernels.hip): the
 // slice pauses in FRONT of it and the next one runs it with more input resident.  The record is written at a pause only; a slice
-// that ends for good marks it finished (state 2) and leaves `lds` alone (brx_api.cpp, bounded_step, relies on that when a slice
-// fails for room: it puts `state` back and runs the slice again with a larger buffer).
+// that ends for good marks it finished (state 2) and leaves `lds` alone.  An item that does not fit the output window's capacity is taken
+// back the same way and the pause reports `need_room` (round 5: before, such a slice ended with "capacity too small").
 struct BrxResume {
     uint32_t state;  // 0 = fresh stream, 1 = paused (lds valid), 2 = finished
     uint32_t phase;  // where to resume (kernel-internal)
@@ -101,6 +101,8 @@ struct BrxResume {
     uint64_t in_slide;
     uint64_t in_low; // pause as well once the input cursor (bits from the window's first dword) is at or beyond this: the source has
                      // more, and what is resident ends soon (~0 = the resident input is all there is)
+    uint64_t need_room; // written at a pause: 0, or the output position the NEXT item (a command, an uncompressed meta-block) runs to --
+                        // it did not fit the window's capacity and was taken back; the host makes that room and goes on
     uint32_t lds[2560];
 };
 #define BRX_RESUME_CURSOR_WORD (2432u + 3u) // index into BrxResume::lds of the parked input cursor (Lds::st[3..4], bits from the

@@ -1996,6 +1996,13 @@ __device__ __noinline__ u32 seg_frame() {
         dec_store(d, s);
         return SEG_PAUSED;
     }
+    if (rc == ST_OUTPUT_TOO_SMALL && pause_at != ~0ull && mb_start != ~0ull) {
+        // (resumable mode: an uncompressed meta-block larger than the room behind the output window -- back to its first bit, pause; the
+        // host reads how far it runs from Lds::st[22] (Dec::needed) through the record and makes that room)
+        in_seek(d, mb_start);
+        dec_store(d, s);
+        return SEG_PAUSED;
+    }
     if (rc == ST_OK) { // StreamEnd :2155-2167
         if (in_byte_tail(d)) rc = ST_NON_ZERO_TRAILER_BIT;
         else if (d.bitpos < d.bitend) rc = ST_EXPECTED_END_OF_STREAM;
@@ -2284,11 +2291,13 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 s.st[ST_IN_LOW] = (u32)in_low; s.st[ST_IN_LOW + 1] = (u32)(in_low >> 32);
             }
             bool paused = false;
+            u32 need_room = 0u; // an item that did not fit the output window's capacity was taken back: the position it runs to
+            if (lane == 0u) s.st[22] = 0u;
             for (;;) {
                 if (phase == PH_FRAME) {
                     if (((u64)rfl(s.st[10]) >= pause_at || get64(s, 3) >= in_low) && rfl(s.st[ST_STARTED]) != 0u && rfl(s.st[ST_ISLAST]) == 0u) { paused = true; break; }
                     st = seg_frame();
-                    if (st == SEG_PAUSED) { paused = true; break; }
+                    if (st == SEG_PAUSED) { paused = true; need_room = rfl(s.st[22]); break; }
                     if (st != SEG_NEED_HEADER) break;
                     phase = PH_HEADER;
                 }
@@ -2318,6 +2327,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                             BRX_ST_BACKUP();
                             st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
                             if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; paused = true; break; }
+                            if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); st = HC_CONTINUE; paused = true; break; }
                             continue;
                         }
                         r = sw_loop ? asm_commands_sw() : asm_commands();
@@ -2330,6 +2340,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                         BRX_ST_BACKUP();
                         st = generic_commands(HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u)));
                         if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
+                        // (one command -- a long copy, a long insert -- that runs past the window's capacity: taken back like the one that
+                        // ran out of input; the host makes room for it, BrxResume::need_room)
+                        if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
                     }
                 }
 #undef BRX_ST_BACKUP
@@ -2341,7 +2354,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if (paused) {
                 const u32 *src = (const u32 *)&s;
                 for (u32 w = lane; w < BRX_LDS_BYTES / 4u; w += 64u) rec->lds[w] = src[w];
-                if (lane == 0u) { rec->state = 1u; rec->phase = phase; }
+                if (lane == 0u) { rec->state = 1u; rec->phase = phase; rec->need_room = need_room; }
                 st = BRX_PAUSED;
             } else {
                 const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);

@@ -177,8 +177,9 @@ const char *brx_last_error(void);
  *   7        output bytes decoded twice because of hand-overs (0 = every such stream was resumed where it stood)
  *   8        (since the context was made) slices of bounded / pulled streams that paused in front of an item -- a header, an
  *            uncompressed block, a command -- that the RESIDENT input did not hold, to run it with more (brx_stream_new_reader)
- *   9        (since the context was made) slices of bounded / pulled streams run again with a larger output buffer because ONE
- *            command produced more than the room behind the window (the buffer grows to what the command needs)
+ *   9        (since the context was made) pauses of bounded / pulled streams in front of ONE item (a long copy or insert, an uncompressed
+ *            meta-block) that did not fit the room behind the output window: the window slides, and if that is not enough the buffer
+ *            grows to hold the item
  *   10       meta-blocks of the most recent launch that were taken back and decoded again with the exact end-of-input rules because
  *            the fast loop had read on past the end of the stream's input (truncated / corrupted streams only; 0 for valid ones)
  */
@@ -254,7 +255,8 @@ brx_stream *brx_stream_new(brx_ctx *ctx, const uint8_t *in, size_t n);
  * one slice plus slack (~22 MiB) however large the stream (like the reference's Decompressor, whose state is its window,
  * src/lib.rs:377-394, 1560-1567).  Reads see decoded bytes as the slices complete; an invalid stream serves everything
  * decoded before the error.  A single command that produces more than the slack (a > 1 MiB copy, insert or uncompressed
- * meta-block) makes the buffer grow to what that command needs (at most ~48 MiB more: brx_last_timing 9 counts such slices);
+ * meta-block) is taken back by the kernel, which pauses in front of it; the window slides and, if the command still does not fit, the
+ * buffer grows to hold it (at most ~48 MiB more: brx_last_timing 9 counts such pauses);
  * only if that allocation fails does the stream fall back to whole-stream decoding. */
 brx_stream *brx_stream_new_bounded(brx_ctx *ctx, const uint8_t *in, size_t n);
 /* The bounded reader over a SOURCE instead of a buffer: the reference's Decompressor::new(r: R) with R: Read

@@ -503,8 +503,8 @@ def test_pulled_reader_grows_its_windows():
     size (40 MiB of uncompressed meta-blocks through a 32 MiB window: it fills past 8 MiB at once).  (b) One item that needs more
     input than the window holds -- uncompressed meta-blocks of 1.6 MiB under a 1 MiB window: the window doubles (before, such a
     stream stalled and came out as UnexpectedEOF).  (c) One command that produces more than the reader's slack -- a copy of
-    7 MiB + 5 in every unit (more than the 5 .. 6 MiB a full window leaves in the buffer): the output buffer grows to what the command needs and the slice runs again (before: a library error
-    over a reader); the context counts those slices.  (d) A read callback that itself reads from another stream of the SAME context
+    7 MiB + 5 in every unit (more than the 5 .. 6 MiB a full window leaves in the buffer): the kernel takes the command back and pauses in front of it, the output buffer grows to hold it (before: a library error
+    over a reader); the context counts those pauses.  (e) The same for uncompressed meta-blocks of 7 MiB.  (d) A read callback that itself reads from another stream of the SAME context
     (a Decompressor over a Decompressor: the callback runs with the context's lock released)."""
     import craft
     import io
@@ -539,6 +539,20 @@ def test_pulled_reader_grows_its_windows():
         before = c2.stream_regrown()
         d = brx.Decompressor(_periodic_source((prefix, unit, b"\x03"), 6), c2, streaming=True)
         assert _read_periodic(d, unit_out) == 6 * len(unit_out)
+        d.close()
+        assert c2.stream_regrown() > before
+        # (e) uncompressed meta-blocks of 7 MiB + 3 (MNIBBLES = 6): nothing can pause inside one, it is larger than the room behind a full
+        # output window AND (with its margin) than the 8 MiB input window -- the framing segment takes it back, both windows grow
+        import random
+        data = random.Random(77).randbytes((7 << 20) + 3)
+        b = craft.Bits()
+        b.put(0, 1); b.put(2, 2); b.put(len(data) - 1, 24); b.put(1, 1)  # ISLAST = 0, MNIBBLES = 6, MLEN - 1, ISUNCOMPRESSED
+        b.put(0, (-b.n) % 8)
+        b.put_bytes(data)
+        unit = b.bytes()
+        before = c2.stream_regrown()
+        d = brx.Decompressor(_periodic_source((prefix, unit, b"\x03"), 5, chunk=1 << 20), c2, streaming=True)
+        assert _read_periodic(d, data) == 5 * len(data)
         d.close()
         assert c2.stream_regrown() > before
         # (d) nested readers on one context
