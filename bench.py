@@ -48,6 +48,8 @@ WORKLOADS = {
     # 64 KiB of text at quality 11 (libbrotlienc fixtures, tests/golden/enc): 10 - 11 literal trees in one meta-block -- more than the
     # eight the register-resident literal loop holds, small enough for the regular instance (round 5: the tree cache)
     "text64k_q11x4096": (["enc:e042_text64k", "enc:e043_text64k", "enc:e051_text64k", "enc:e062_text64k"], 4096),
+    # 40 KB of text at quality 0 .. 4 (what a server compressing on the fly emits): ONE literal tree, no contexts, literal-heavy
+    "text40k_lowqx4096": (["enc:e000_text40k", "enc:e001_text40k", "enc:e002_text40k", "enc:e004_text40k"], 4096),
     # small streams (a launch of many short messages): 47 / 69 / 425 compressed bytes
     "quickfoxx16384": (["quickfox"], 16384),
     "ukkonooax16384": (["ukkonooa"], 16384),

@@ -1703,6 +1703,7 @@
     s_branch .Llit1
 .Llit1_run:
     LIT_RUN_SETUP .Lflush_stub_lit1, .Llsw_7
+#if defined(BRX_PROF) || defined(BRX_NO_SPEC) || defined(BRX_LIT1_SERIAL)
 .Llit1:
     LOOKUP2F VLITL, VLITB, 1, ds_read_u16, 7
     s_waitcnt lgkmcnt(0)
@@ -1717,6 +1718,53 @@
     s_cbranch_scc0 .Lafter_lits
     LIT_RUN_END .Llit1_run, .Lflush_stub_lit1
     LIT_RUN_STUBS 7, .Llit1_run, .Lflush_stub_lit1
+#else
+// Round 5: pipelined.  Without a context nothing of literal k + 1 depends on literal k's ENTRY, only on its length: the next
+// compare + fetch go out right behind the TAKE, and the entry is stored a literal later straight from its lane (EXEC = that one
+// lane: no v_readlane / v_mov) -- the LDS round trip and a VALU -> SALU hand-over leave the chain (tools/ubench/litloop.hip:
+// k_one_base / k_one_pipe_x).  VSA / VSB, T6 / T7: entries and lengths of the two literals in flight.  The refill stubs give the
+// rest of a run back as before (RUN = the literals behind the one in progress holds at both TAKEs).
+.macro LOOKUP1 vs, len, rid
+    v_bfrev_b32 VR, WSRC
+    v_lshrrev_b32 VI, VSH, VR
+    v_cmp_lt_u32 vcc, VI, VLITL
+    v_lshl_add_u32 VI, VI, 1, VLITB
+    ds_read_u16 \vs, VI
+    s_ff1_i32_b32 \len, vcc_lo
+    TAKE \len, \rid
+.endm
+.macro STORE1 vs, len, cnt
+    s_waitcnt lgkmcnt(\cnt)
+    s_lshl_b32 exec_lo, 1, \len
+    ds_write_b8 VPA, \vs
+    s_mov_b32 exec_lo, XLOOP
+    v_add_u32 VPA, 1, VPA
+.endm
+.Llit1:
+    LOOKUP1 VS, T6, 7
+.Llit1_a:
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc1 .Llit1_last_a
+    LOOKUP1 VE, T7, 16
+    STORE1 VS, T6, 1
+    s_sub_u32 RUN, RUN, 1
+    s_cbranch_scc1 .Llit1_last_b
+    LOOKUP1 VS, T6, 17
+    STORE1 VE, T7, 1
+    s_branch .Llit1_a
+.Llit1_last_b:
+    STORE1 VE, T7, 0
+    s_branch .Llit1_end
+.Llit1_last_a:
+    STORE1 VS, T6, 0
+.Llit1_end:
+    s_cmp_lg_u32 INS, 0
+    s_cbranch_scc0 .Lafter_lits
+    LIT_RUN_END .Llit1_run, .Lflush_stub_lit1
+    LIT_RUN_STUBS 7, .Llit1_run, .Lflush_stub_lit1
+    LIT_RF_STUB 16, 16
+    LIT_RF_STUB 17, 17
+#endif
 
 // ---- last-distance codes 0..15 (decode_distance :1412-1450)
 .Ldist_single:

@@ -190,6 +190,31 @@ KERNEL(k_op_ctx2_31, "-1", OP_PRE "s_mov_b32 s71, 31\n v_and_b32 v13, 16, v13\n 
     OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f") OP_STEP_CTX("2f")
     OP_TAKE "s_branch 1b\n8:\n")
 
+// ---- ONE literal tree (no contexts: quality <= 4 encoders, the 1 GiB reader test): today's loop (.Llit1 of brx_hot.S) and the same
+// pipelined -- without a context nothing of literal k + 1 depends on literal k's ENTRY, only on its length: the next compare + fetch
+// go out right behind the TAKE, the entry is picked up one literal later (v_readlane -> v_writelane, off the chain)
+KERNEL(k_one_base, "0x1ffff",
+    "1:\n"
+    "v_bfrev_b32 v14, s60\n v_lshrrev_b32 v15, v10, v14\n v_cmp_lt_u32 vcc, v15, v11\n v_lshl_add_u32 v15, v15, 1, v12\n ds_read_u16 v16, v15\n"
+    "s_ff1_i32_b32 s68, vcc_lo\n"
+    TAKE_S
+    "s_waitcnt lgkmcnt(0)\n v_readlane_b32 s69, v16, s68\n s_nop 1\n v_mov_b32 v17, s69\n ds_write_b8 v30, v17 offset:2048\n v_add_u32 v30, 1, v30\n"
+    "s_sub_u32 s66, s66, 1\n s_cbranch_scc0 1b\n")
+#define ONE_CMP(vs) "v_bfrev_b32 v14, s60\n v_lshrrev_b32 v15, v10, v14\n v_cmp_lt_u32 vcc, v15, v11\n v_lshl_add_u32 v15, v15, 1, v12\n ds_read_u16 " vs ", v15\n s_ff1_i32_b32 s68, vcc_lo\n" TAKE_S
+#define ONE_FIN(vs, len) "s_waitcnt lgkmcnt(1)\n v_readlane_b32 s69, " vs ", " len "\n"
+KERNEL(k_one_pipe, "0x1ffff",
+    ONE_CMP("v16") "s_mov_b32 s72, s68\n"
+    "1:\n"
+    ONE_CMP("v17") ONE_FIN("v16", "s72") "s_mov_b32 s72, s68\n v_writelane_b32 v31, s69, m0\n s_sub_u32 m0, m0, 1\n s_cbranch_scc1 8f\n"
+    ONE_CMP("v16") ONE_FIN("v17", "s72") "s_mov_b32 s72, s68\n v_writelane_b32 v31, s69, m0\n s_sub_u32 m0, m0, 1\n s_cbranch_scc0 1b\n8:\n")
+// ... the entry's lane written to the ring directly under a one-lane EXEC (no v_readlane / v_writelane at all)
+#define ONE_FIN_X(vs, len) "s_waitcnt lgkmcnt(1)\n s_lshl_b32 exec_lo, 1, " len "\n ds_write_b8 v30, " vs " offset:2048\n s_mov_b32 exec_lo, 0x1ffff\n v_add_u32 v30, 1, v30\n"
+KERNEL(k_one_pipe_x, "0x1ffff",
+    ONE_CMP("v16") "s_mov_b32 s72, s68\n"
+    "1:\n"
+    ONE_CMP("v17") ONE_FIN_X("v16", "s72") "s_mov_b32 s72, s68\n s_sub_u32 m0, m0, 1\n s_cbranch_scc1 8f\n"
+    ONE_CMP("v16") ONE_FIN_X("v17", "s72") "s_mov_b32 s72, s68\n s_sub_u32 m0, m0, 1\n s_cbranch_scc0 1b\n8:\n")
+
 int main() {
     u64 *o;
     hipMalloc(&o, 64);
@@ -202,6 +227,9 @@ int main() {
     RUN(k_slot_vcc, "  ... compare into vcc + s_mov_b64");
     RUN(k_slot_17, "  ... EXEC = 17 lanes");
     RUN(k_slot_nomiss, "  ... no miss test");
+    RUN(k_one_base, "ONE tree, today's loop (.Llit1)");
+    RUN(k_one_pipe, "ONE tree, pipelined: next compare + fetch behind the TAKE, entry picked up a literal later");
+    RUN(k_one_pipe_x, "  ... entry stored from its lane under a one-lane EXEC (no readlane / writelane)");
     RUN(k_op_one_17, "offsets x trees: ONE tree, batch good for offsets <= 17 (4 literals of 5 bits)");
     RUN(k_op_one_31, "  ... for offsets <= 31 (7 literals)");
     RUN(k_op_ctx2_17, "offsets x trees: 2 trees x 32 offsets, context walk, offsets <= 17 (4 literals)");
