@@ -1733,12 +1733,14 @@
     s_ff1_i32_b32 \len, vcc_lo
     TAKE \len, \rid
 .endm
-.macro STORE1 vs, len, cnt
+.macro STORE1 vs, len, cnt, off, step                   // (a run never wraps the ring: the second literal of a pair goes to offset 1)
     s_waitcnt lgkmcnt(\cnt)
     s_lshl_b32 exec_lo, 1, \len
-    ds_write_b8 VPA, \vs
+    ds_write_b8 VPA, \vs offset:\off
     s_mov_b32 exec_lo, XLOOP
-    v_add_u32 VPA, 1, VPA
+    .if \step
+    v_add_u32 VPA, \step, VPA
+    .endif
 .endm
 .Llit1:
     LOOKUP1 VS, T6, 7
@@ -1746,17 +1748,17 @@
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc1 .Llit1_last_a
     LOOKUP1 VE, T7, 16
-    STORE1 VS, T6, 1
+    STORE1 VS, T6, 1, 0, 0
     s_sub_u32 RUN, RUN, 1
     s_cbranch_scc1 .Llit1_last_b
     LOOKUP1 VS, T6, 17
-    STORE1 VE, T7, 1
+    STORE1 VE, T7, 1, 1, 2
     s_branch .Llit1_a
 .Llit1_last_b:
-    STORE1 VE, T7, 0
+    STORE1 VE, T7, 0, 1, 2
     s_branch .Llit1_end
 .Llit1_last_a:
-    STORE1 VS, T6, 0
+    STORE1 VS, T6, 0, 0, 1
 .Llit1_end:
     s_cmp_lg_u32 INS, 0
     s_cbranch_scc0 .Lafter_lits
