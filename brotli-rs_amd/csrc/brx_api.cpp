@@ -632,6 +632,8 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         // What is resident together: brx_plan.h (persistent grids that all find room at once, by 40-KiB LDS parts)
         const BrxPlanB plan = brx_plan_b(n0, cnt, c->max_grid / 4u, c->max_grid);
         uint32_t g[4] = {std::min<uint32_t>(plan.grid[0], grid), plan.grid[1], plan.grid[2], plan.grid[3]};
+        if (c->grid_cap != 0u) // (the A/B knob caps EVERY grid: the slab pool follows the capped one -- a wider kernel with more waves
+            for (int k = 1; k < 4; k++) g[k] = std::min<uint32_t>(g[k], c->grid_cap); // than slabs would starve its own waiters)
         const uint32_t *mask = plan.mask;
         const int narrowest = g[0] ? 0 : g[1] ? 1 : g[2] ? 2 : 3;
         uint32_t started = 0;
@@ -674,7 +676,12 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         ac.cls = nullptr;
         ac.list_mask = plan_b ? 8u : 15u;
         ac.counter_idx = 4u;
-        brx_launch_decode_l3(ac, std::min(n, per_cu * 4u), st);
+        // (never more waves than the slab pool has slabs -- ensure_pool(grid) above: a level-3 wave whose stream spills even there
+        // holds its slab for the whole decode, and a waiter gives up after 0.5 s: found by the round-5 soak with BRX_GRID_CAP = 64,
+        // 199 slab-class streams on a 1024-wave catch-all over 64 slabs, tools/device_fuzz.py 3 302)
+        unsigned gc = std::min(n, per_cu * 4u);
+        if (c->grid_cap != 0u) gc = std::min(gc, c->grid_cap);
+        brx_launch_decode_l3(ac, gc, st);
         HIP_TRY(hipGetLastError());
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));

@@ -230,9 +230,11 @@ FI u32 *scratch_claim(const BrxSlabPool *pool) {
     u32 w = (blockIdx.x * 7u) % nwords;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        // (a pool that stays exhausted is a bug, not a state to wait out: after 0.5 s -- 100 MHz counter -- the stream gets the
-        // watchdog status instead of the device a hang)
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) return nullptr;
+        // (a launch never has more waves than the pool has slabs -- brx_api.cpp sizes the pool by the largest grid -- so a wave only
+        // ever waits for slabs held by ANOTHER launch of the same context running next to it on another HIP stream, and for as
+        // long as that one's slab-class streams take: seconds for very large ones.  A pool that stays exhausted for 4 s -- 100 MHz
+        // counter -- is taken for a bug: the stream gets the watchdog status instead of the device a hang.  0.5 s until round 5.)
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) return nullptr;
         u32 got = 0xffffffffu;
         if (threadIdx.x == 0u) {
             const u32 cur = __hip_atomic_load(&pool->bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -22,6 +22,9 @@ PLANS = ["BRX_PLAN_A", "BRX_PLAN_B"]
 FUZZERS = [("wide_fuzz", ["2", "43", "late"]), ("wide_fuzz", ["1", "44"]), ("big_fuzz", ["2", "43"]), ("gen_fuzz", ["4", "43"]),
            ("small_fuzz", ["2", "43"]), ("device_fuzz", ["4", "43"])]
 SECTIONS = [({p: "1"}, t, a) for p in PLANS for t, a in FUZZERS]
+# round 5's extended soak found this one (pre-existing): 199 slab-class streams in a catch-all launch whose grid ignored BRX_GRID_CAP
+# while the slab pool followed it -- waiters gave up after 0.5 s and valid streams came back with status 27
+SECTIONS += [({p: "1"}, "device_fuzz", ["3", "302"]) for p in PLANS]
 SECTIONS += [({"BRX_LOOP_BUILD": str(b)}, "wide_fuzz", ["1", "45"]) for b in (0, 1)]
 SECTIONS += [({"BRX_LOOP_BUILD": str(b)}, "gen_fuzz", ["2", "46"]) for b in (0, 1)]
 SECTIONS += [({"BRX_GRID_CAP": "64"}, "wide_fuzz", ["2", "47"])]  # a pool of 64 slabs under corrupted wide streams: a slab not given back stalls this

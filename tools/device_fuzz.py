@@ -22,7 +22,8 @@ dev = torch.device("cuda:0")
 bad = 0
 for r in range(rounds):
     cap_grid = rng.choice([16, 64, 256, 1024])
-    ctx = brx_knobs.context(0, grid_cap=cap_grid, levels=rng.choice([0, 1, 2]))
+    levels = rng.choice([0, 1, 2])
+    ctx = brx_knobs.context(0, grid_cap=cap_grid, levels=levels)
     kind = r % 5
     pool = []
     for _ in range(12):  # a dozen distinct streams per round, replicated
@@ -38,7 +39,8 @@ for r in range(rounds):
             n = rng.choice([50, 5000, 40000, 41000, 80000, 300000])
         o = rng.randrange(len(corpus) - n)
         data = corpus[o:o + n]
-        pool.append((brotli_enc.compress(data, quality=rng.choice([1, 5, 9, 11]), lgwin=rng.randrange(16, 25)), data))
+        q, lw = rng.choice([1, 5, 9, 11]), rng.randrange(16, 25)
+        pool.append((brotli_enc.compress(data, quality=q, lgwin=lw), data, (q, lw)))
     nstreams = rng.choice([cap_grid + 1, 3 * cap_grid, 700, 2500])
     pick = [rng.choice(pool) if kind != 0 else pool[0] for _ in range(nstreams)]
     streams = [p[0] for p in pick]
@@ -59,7 +61,8 @@ for r in range(rounds):
             if st[i] != 0 or ol[i] != len(p[1]) or host[oo[i]:oo[i] + len(p[1])].tobytes() != p[1]:
                 bad += 1
                 if bad < 10:
-                    print("MISMATCH round", r, "rep", rep, "stream", i, "status", st[i], "len", ol[i], len(p[1]))
-    print("round", r, "kind", kind, "grid cap", cap_grid, "streams", nstreams, "done; mismatches so far", bad, flush=True)
+                    print("MISMATCH round", r, "rep", rep, "stream", i, "status", st[i], "len", ol[i], len(p[1]), "quality / lgwin", p[2], "levels", levels,
+                          "wide", [ctx.last_wide_streams(k) for k in (1, 2, 3)], "late", ctx.last_late_streams())
+    print("round", r, "kind", kind, "grid cap", cap_grid, "levels", levels, "streams", nstreams, "done; mismatches so far", bad, flush=True)
     ctx.close()
 sys.exit(1 if bad else 0)
