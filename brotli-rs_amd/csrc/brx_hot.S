@@ -49,7 +49,7 @@
 #define RING 2048
 // the code-length scratch area (Lds::lens, 768 B) is free during the command loop
 #define LDS_ITAB (8960+LDS_GROW)   // byte -> context info (filled by prepare_fast_tables)
-#define LDS_SPARE (9216+LDS_GROW)  // 8 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
+#define LDS_SPARE (9216+LDS_GROW)  // 12 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
 #define LDS_CMH (9472+LDS_GROW)    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
 #define SYMOFF 68       // symbol list of a tree: after its 17 header words (brx_kernels.hip, "Table layout in table memory")
 #define INFOOFF 64      // the header's info word: kind | max_len << 8 | x << 16
@@ -142,10 +142,10 @@
 #if defined(BRX_WIN_SGPR) && !defined(BRX_PROF) && !defined(BRX_NO_SLOTS)
 #define BRX_SLOTS
 #endif
-// Meta-blocks with more than SLOT_OVER + 1 literal trees take the tree cache; up to eight trees fit the registers of the resident
+// Meta-blocks with more than SLOT_OVER + 1 literal trees take the tree cache; up to twelve trees fit the registers of the resident
 // loop, which is the faster one on text (few literals per run: profiles/r05_slots_ab.txt).
 #ifndef SLOT_OVER
-#define SLOT_OVER 7
+#define SLOT_OVER 11
 #endif
 #ifndef BRX_PROF
 #define LITJ s[20:21]           // where an insert's literals go (.Lhave_lits): the loop of the meta-block's literal mode
@@ -164,8 +164,8 @@
 #define LINKB s[98:99]
 #define LINKC s[100:101]
 // FLAGS bits (17:16: BRX_SLOTS, the cache's next slot): 0 = block counters poisoned (near the end of the input), 3 = one literal tree, resident in VLITL / VLITB, 6 = more than 8 literal trees: the tree cache (BRX_SLOTS),
-// 4 = the literal block types differ in context mode (literal entries are plain bytes), 5 = <= 8 literal trees, resident
-// in v70..v85
+// 4 = the literal block types differ in context mode (literal entries are plain bytes), 5 = <= RESIDENT_TREES literal trees, resident
+// in v70..v93
 // ---- VGPRs (v40-v47 are callee-saved in the AMDGPU calling convention: using them would make the wrapper spill them)
 #define VZERO v0
 #define VLANE v1
@@ -221,18 +221,19 @@
 #define VIAC v[66:67]
 #define VIACL v66
 #define VIACB v67
-#define VTREES v70          // v70 .. v85: limits / bases of up to 8 resident literal trees (pairs; indexed through M0)
-#define VTREES1 v71
+#define VTREES v70          // v70 .. v93: limits / bases of up to RESIDENT_TREES (12) resident literal trees (pairs; indexed through M0).
+#define VTREES1 v71         // Eight until round 5: text at quality 11 has 9 - 11 trees from ~64 KB on (tests/golden/enc: 9 of 18 fixtures)
+#define RESIDENT_TREES 12
 #define VCMIDX v55          // (entry only) 4 * tree index per context id
-#define VCMAP v86           // lane c: 2 * tree index of context id c (the M0 value of its pair)
-// BRX_DIST_RESIDENT: limits / folded bases of the four distance-context trees of the current block type in v87..v94 (pairs,
+#define VCMAP v103          // lane c: 2 * tree index of context id c (the M0 value of its pair)
+// BRX_DIST_RESIDENT: limits / folded bases of the four distance-context trees of the current block type in v104..v111 (pairs,
 // reached through M0 like the literal trees): no LDS round trip for a tree's header in front of a distance symbol, at the price of
 // three scalar instructions per distance symbol.  Sparse launches -5 % (config 5 48.3 -> 45.9 ms), a full chip -0.7 %
 // (profiles/r03_ab.txt; each build at its own best position).  The serial-fetch A/B build (BRX_NO_SPEC) keeps the LDS form.
-#define VDTREES v87
-#define VDTREES1 v88
-#define VD3L v93                // (the pair of distance context 3 by name)
-#define VD3B v94
+#define VDTREES v104
+#define VDTREES1 v105
+#define VD3L v110               // (the pair of distance context 3 by name)
+#define VD3B v111
 #ifdef BRX_SLOTS
 #define VQL v96                 // the four cached literal trees: limits (as counts) ...
 #define VQB v97                 // ... and folded bases, lanes 16 s .. 16 s + 15 = slot s
@@ -766,7 +767,7 @@
     s_cmp_gt_u32 s13, SLOT_OVER
     s_cbranch_scc1 .Lent_slots
 #endif
-    s_cmp_gt_u32 s13, 7
+    s_cmp_gt_u32 s13, RESIDENT_TREES - 1
     s_cbranch_scc1 .Lent_no_r
     s_bitset1_b32 FLAGS, 5
     v_lshrrev_b32 VCMAP, 1, VCMIDX                      // (VCMIDX = 4 * tree index per context id)
@@ -807,7 +808,7 @@
     s_cbranch_scc1 .Lent_r_loop
 #ifdef BRX_SLOTS
     s_branch .Lent_no_r
-    // more than 8 literal trees (one context mode): the tree cache of the pipelined literal loop -- trees 0 .. 3 go in at once,
+    // more than RESIDENT_TREES literal trees (one context mode): the tree cache of the pipelined literal loop -- trees 0 .. 3 go in at once,
     // the others when a literal first needs them (.Lslot_fill)
 .Lent_slots:
     s_bitset1_b32 FLAGS, 6
@@ -2542,7 +2543,7 @@
     s_branch .Lexit
 #ifdef BRX_DIST_RESIDENT
 // limits and folded bases ((base << 2) + address of the symbol list) of the four distance-context trees named by VDH4 into
-// v87..v94.  A one-symbol tree (descriptor < 0) has no header: its pair is never used (.Ldist_special).  Clobbers T2, T3, VT0, VLB.
+// v104..v111.  A one-symbol tree (descriptor < 0) has no header: its pair is never used (.Ldist_special).  Clobbers T2, T3, VT0, VLB.
 .Lload_dtrees:
     s_mov_b32 T3, 0
     s_mov_b32 DSPEC, 0x01000115

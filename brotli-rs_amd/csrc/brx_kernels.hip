@@ -1548,7 +1548,7 @@ FI void mb_load(const Lds &s, MB &m, Cat &L, Cat &I, Cat &D) {
           "s97", "s98", "s99", "s100", "s101", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", \
           "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
           "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", \
-          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "s11", "m0"
+          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "s11", "m0"
 // Two builds of the same loop (brx_hot.S, "Two builds of this file"): the bit window in VGPRs -- for a full chip, where
 // the CU's one scalar ALU is the busiest unit -- or in SGPRs -- for launches that leave the CUs mostly empty, where the
 // shortest dependent chain wins.  BrxKernelArgs::loop_build picks one per launch.
