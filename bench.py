@@ -40,6 +40,9 @@ WORKLOADS = {
     # the LZ77 back-reference on its own (north_star: ">= 40 % of HBM peak on the copy"): hand-assembled streams, 64 KiB of
     # raw bytes then non-overlapping copies from distance >= 64 KiB doubling the output to 1 MiB (tests/craft.py)
     "farcopy_1MiBx4096": (["farcopy_0", "farcopy_1", "farcopy_2", "farcopy_3"], 4096),
+    # INCOMPRESSIBLE payloads: every encoder stores them as uncompressed meta-blocks (reference src/lib.rs:1701-1734) -- a memcpy from the
+    # compressed input to the output: 256 KiB of random bytes in 64-KiB meta-blocks, hand-assembled (tests/craft.py raw_block)
+    "raw_256KiBx4096": (["raw_0", "raw_1", "raw_2", "raw_3"], 4096),
     # the other Canterbury texts the reference holds (supplementary: bigger files, more trees per meta-block)
     "asyoulikx4096": (["asyoulik.txt"], 4096),
     "lcet10x4096": (["lcet10.txt"], 4096),
@@ -65,7 +68,7 @@ WORKLOADS = {
 }
 # workloads whose PHYSICAL HBM traffic is known by construction: every copied byte is read from HBM once ("rw") or the
 # copy is a periodic fill served from registers / LDS ("w"); for the others the physical figure is the PMC traffic
-PHYSICAL_MODEL = {"farcopy_1MiBx4096": "rw", "backward65536x4096": "w", "quickfox_repeatedx8192": "w"}
+PHYSICAL_MODEL = {"farcopy_1MiBx4096": "rw", "backward65536x4096": "w", "quickfox_repeatedx8192": "w", "raw_256KiBx4096": "w"}
 
 
 def load_fixture(name):
@@ -73,6 +76,17 @@ def load_fixture(name):
     if name.startswith("farcopy_"):
         import craft
         return craft.farcopy_stream(int(name.split("_")[1]))
+    if name.startswith("raw_"):
+        import random
+        import craft
+        data = random.Random(int(name.split("_")[1])).randbytes(256 << 10)
+        b = craft.Bits()
+        craft.stream_header(b, 22)
+        b.put(0, 1); b.put(3, 2); b.put(0, 1); b.put(0, 2); b.put(0, (-b.n) % 8)  # an empty metadata block: byte boundary
+        for o in range(0, len(data), 1 << 16):
+            craft.raw_block(b, data[o:o + (1 << 16)])
+        b.put(3, 2)  # ISLAST, ISLASTEMPTY
+        return b.bytes(), data
     if name.startswith("enc:"):
         import hashlib
         import oracle_py
@@ -364,10 +378,10 @@ def timed_pass(ctx, batch, steps, warmup, barrier):
 
 def copy_path(torch, np, dev, ctx, barrier, steps=5):
     """The LZ77 copy path in the driver-run line (north_star: the copy at >= 40 % of HBM peak): three short runs with the
-    PHYSICAL bytes known by construction -- far copies HBM -> registers -> HBM (every copied byte read once), and the two
-    fills of BASELINE configs[2] / configs[3] (in + out only)."""
+    PHYSICAL bytes known by construction -- far copies HBM -> registers -> HBM (every copied byte read once), the two
+    fills of BASELINE configs[2] / configs[3] (in + out only), and uncompressed meta-blocks (input -> registers -> output)."""
     res = {}
-    for name in ("farcopy_1MiBx4096", "backward65536x4096", "quickfox_repeatedx8192"):
+    for name in ("farcopy_1MiBx4096", "backward65536x4096", "quickfox_repeatedx8192", "raw_256KiBx4096"):
         fixtures, n = WORKLOADS[name]
         b = Batch(torch, np, dev, [load_fixture(f) for f in fixtures], n)
         dt, kms = timed_pass(ctx, b, steps, 2, barrier)

@@ -1974,7 +1974,45 @@ __device__ __noinline__ u32 seg_frame() {
                 if (in_remaining(d) < 8ull * mlen) { rc = ST_EOF; break; }
                 if (!out_room(d, mlen)) { rc = ST_OUTPUT_TOO_SMALL; break; }
                 const u8 *src = (const u8 *)d.in_words + (d.bitpos >> 3);
-                for (u32 done = 0; done < mlen; done += 64u) {
+                u32 done = 0;
+                // Round 5: an uncompressed meta-block is a memcpy (incompressible payloads are stored this way by every encoder): up to
+                // the next 16-byte boundary of the output through the ring, then INPUT -> registers -> OUTPUT, 4 KiB per step with four
+                // 16 B/lane loads in flight (the source as it falls, the destination aligned: direct_far_copy's shape), the ring
+                // re-seeded from the block's own last 2 KiB of input; the rest 64 bytes per step as before.  4096 x 256 KiB
+                // of random bytes: 537 GB/s -> see profiles/r05_raw_ab.txt.
+                if (mlen >= 8192u) {
+                    const u32 head = (16u - ((d.pos + d.a) & 15u)) & 15u;
+                    if (head) {
+                        if (d.lane < head) s.ring[(d.pos + d.lane + d.a) & RMASK] = src[d.lane];
+                        d.pos += head;
+                        done = head;
+                    }
+                    flush_range(d, s, d.vfl, d.pos + d.a); // everything up to the cursor is in HBM now (ragged head as bytes)
+                    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)d.in_words, 0, d.w_end * 4u, 0x00020000);
+                    u32 so = (u32)(d.bitpos >> 3) + done + 16u * d.lane; // byte offset of this lane's unit in the input
+                    const u32 nsteps = (mlen - done) >> 12;
+                    for (u32 k = 0; k < nsteps; k++) {
+                        const u32 dst = d.pos + 16u * d.lane;
+                        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, so, 0, 0);
+                        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, so + 1024u, 0, 0);
+                        const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, so + 2048u, 0, 0);
+                        const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, so + 3072u, 0, 0);
+                        OUT_STORE128(q0, dst);
+                        OUT_STORE128(q1, dst + 1024u);
+                        OUT_STORE128(q2, dst + 2048u);
+                        OUT_STORE128(q3, dst + 3072u);
+                        d.pos += 4096u;
+                        so += 4096u;
+                    }
+                    done += nsteps << 12;
+                    d.vfl = d.pos + d.a;
+                    for (u32 j = 0; j < BRX_RING_BYTES / 1024u; j++) { // the ring = the last 2 KiB of the output = of what was just copied
+                        const u32 back = BRX_RING_BYTES - 1024u * j - 16u * d.lane; // bytes in front of the cursor
+                        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (u32)(d.bitpos >> 3) + done - back, 0, 0);
+                        *(u32x4 *)&s.ring[(d.pos + d.a - back) & RMASK] = q;
+                    }
+                }
+                for (; done < mlen; done += 64u) {
                     u32 n = mlen - done < 64u ? mlen - done : 64u;
                     if (d.lane < n) s.ring[(d.pos + d.lane + d.a) & RMASK] = src[done + d.lane];
                     d.pos += n;

@@ -1230,6 +1230,48 @@ def test_tree_cache_of_many_tree_meta_blocks(build, mode):
         c2.close()
 
 
+def test_uncompressed_meta_blocks_bulk_copy(ctx):
+    """Round 5: an uncompressed meta-block of >= 8 KiB is copied input -> registers -> output in 4 KiB steps (the source as it falls, the
+    destination from its next 16-byte boundary on) and the ring is re-seeded from the block's own last 2 KiB.  Blocks of 8 191 ..
+    1 MiB + 5 bytes (MNIBBLES 4 / 5 / 6), two in a row, each stream at all 16 alignments of its output slot and -- through the batch's
+    concatenation -- at every input alignment; behind them a compressed meta-block whose copies reach back 1 .. 2 049 bytes and to the
+    block's start: the ring must hold exactly the last 2 KiB.  Against the oracle."""
+    import craft
+    import random
+    rng = random.Random(9)
+    streams, want = [], []
+    for n in (8191, 8192, 8193, 12345, 65536, 100001, (1 << 20) + 5):
+        data = rng.randbytes(n)
+        b = craft.Bits()
+        craft.stream_header(b, 22)
+        b.put(0, 1); b.put(3, 2); b.put(0, 1); b.put(0, 2); b.put(0, (-b.n) % 8)
+        for part in (data, data[: n // 2 + 3]):
+            nib = 4 if len(part) <= 1 << 16 else 5 if len(part) <= 1 << 20 else 6
+            b.put(0, 1); b.put(nib - 4, 2); b.put(len(part) - 1, 4 * nib); b.put(1, 1)
+            b.put(0, (-b.n) % 8)
+            b.put_bytes(part)
+        out = bytearray(data + data[: n // 2 + 3])
+        cmds = []
+        for dist in (1, 15, 16, 17, 1000, 2040, 2047, 2048, 2049, 4000, len(out) - 3):
+            lits = rng.randbytes(3)
+            out += lits
+            cmds.append((lits, 9, dist))
+            for _ in range(9):
+                out.append(out[-dist])
+        mb_len = len(out) - (n + n // 2 + 3)
+        craft.MetaBlock(cmds, mlen=mb_len).emit(b, True, mb_len)
+        st_ = b.bytes()
+        w = oracle.decode(st_, 0, cap=len(out) + 64)
+        assert w[0] == 0 and w[1] == bytes(out), n
+        streams += [st_] * 16
+        want += [bytes(out)] * 16
+    caps = [len(w) + 1 + (i % 16) for i, w in enumerate(want)]  # (ragged capacities: the slots start at every alignment)
+    for rep in range(2):
+        outs, status, out_len = ctx.decode_batch(streams, caps)
+        bad = [(i, int(t), len(o)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+        assert not bad, bad[:8]
+
+
 def test_farcopy_streams(ctx):
     """Long back-references at memory speed (direct_far_copy: HBM -> registers -> HBM, 4 KiB steps): hand-assembled
     streams of non-overlapping copies from distance >= 64 KiB (the bench's farcopy workload), smaller ones, and long
