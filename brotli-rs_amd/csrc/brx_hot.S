@@ -2177,10 +2177,18 @@
     s_load_dwordx4 s[12:15], XFP, T4                    // prefix[8], suffix[8]
     s_add_u32 T4, T4, 16
     s_load_dword s97, XFP, T4                           // plen | slen << 8 | op << 16
-    s_call_b64 LINKB, .Lland
     s_waitcnt lgkmcnt(0)
-    s_mov_b64 exec, -1
     s_bfe_u32 T1, s97, 0x80010                          // op
+    // (the landing -- it may flush, which takes T6 / T7 -- comes before the lengths are worked out: always for the two Uppercase
+    // transforms, which need the word's bytes here; for the others only when 40 more lanes are not free)
+    s_sub_u32 T4, T1, 1
+    s_cmp_lt_u32 T4, 2
+    s_cbranch_scc1 .Lxf_land
+    s_cmp_gt_u32 PFREE, 23
+    s_cbranch_scc0 .Lxf_landed
+.Lxf_land:
+    s_call_b64 LINKB, .Lland
+.Lxf_landed:
     s_and_b32 T2, s97, 0xff                             // prefix length
     s_bfe_u32 T3, s97, 0x80008                          // suffix length
     s_mov_b32 T5, 0                                     // first word byte used
@@ -2203,6 +2211,38 @@
     s_add_u32 CLEN, CLEN, T3                            // transformed length (<= 40)
     s_cmp_gt_u32 CLEN, MBLEFT
     s_cbranch_scc1 .Lx_r2                               // :2105 on the transformed length (Q4): raised by the C++ side
+    s_sub_u32 T4, T1, 1
+    s_cmp_lt_u32 T4, 2
+    s_cbranch_scc1 .Lxf_upper                           // UppercaseFirst / UppercaseAll: the word's bytes are needed HERE
+    // ---- identity / OmitFirstN / OmitLastN (round 5: four transformed words in five of quality-5..11 text; libbrotlienc leans on
+    // the dictionary, 40 % of the commands of a 4 KiB-window stream): prefix, the used part of the word and suffix JOIN THE PENDING
+    // LANES -- prefix and suffix bytes from the transform's record (SGPRs), the word's bytes by a load that nothing waits for,
+    // like an untransformed word (.Ldict_go).  Before, every such word landed everything pending and waited out its own load.
+    s_mov_b64 exec, -1
+    v_subrev_u32 VT1, PFREE, VLANE
+    v_lshlrev_b32 VT1, 3, VT1                           // 8 * (lane - first lane of the prefix)
+    s_bfm_b64 exec, T2, PFREE
+    v_lshrrev_b64 v[54:55], VT1, s[12:13]
+    v_mov_b32 VPEND, v54                                // prefix bytes
+    s_add_u32 T4, PFREE, T2                             // first lane of the word's part
+    s_add_u32 T0, T0, T5
+    s_sub_u32 T0, T0, T4                                // + lane = byte offset in the dictionary
+    s_bfm_b64 exec, T7, T4
+    v_add_u32 VT0, T0, VLANE
+    global_load_ubyte VPEND, VT0, DICTP
+    s_add_u32 T4, T4, T7                                // first lane of the suffix
+    s_mov_b64 exec, -1
+    v_subrev_u32 VT1, T4, VLANE
+    v_lshlrev_b32 VT1, 3, VT1
+    s_bfm_b64 exec, T3, T4
+    v_lshrrev_b64 v[54:55], VT1, s[14:15]
+    v_mov_b32 VPEND, v54                                // suffix bytes
+    s_mov_b64 exec, XLOOP
+    s_add_u32 PFREE, PFREE, CLEN
+    s_add_u32 POS, POS, CLEN
+    s_branch .Lcopy_tail
+.Lxf_upper:
+    s_mov_b64 exec, -1
     // the used part of the word, one byte per lane (lanes past its end repeat the last byte; they are masked off below)
     s_add_u32 T0, T0, T5
     s_max_u32 T4, T7, 1

@@ -322,6 +322,17 @@ class Wave:
                 if r in self.pend:
                     if loadish and k < (ops[0][2] if ops else 0):
                         continue  # another load into a register with a load in flight (other lanes / in-order counter)
+                    if op == "v_mov_b32" and k == 0 and r[0] == "v":
+                        # a VALU write to lanes that no load in flight will write (prefix / suffix bytes of a transformed word joining
+                        # the pending lanes): the register file is written per lane
+                        mine = self.exec_mask()
+                        clash = False
+                        for q in (self.vm_q, self.lg_q):
+                            for dsts, vals, smem, mask in q:
+                                if r in dsts and (mask is None or mine is None or bool((mask & mine).any())):
+                                    clash = True
+                        if not clash:
+                            continue
                     raise EmuError("%#x %s: register %s%d has a load in flight (missing s_waitcnt)" % (i.addr, i.text, r[0], r[1]))
         S = self.S
         if self.gpr_idx is not None and op.startswith("v_") and op != "v_mov_b32":
