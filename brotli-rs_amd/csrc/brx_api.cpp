@@ -341,7 +341,7 @@ extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
     std::lock_guard<std::mutex> lk(c->mu);
     switch (option) {
     case BRX_OPTION_COMMAND_LOOP:
-        if (value != 0 && value != 7 && value != 8) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: command loop is 0, 7 or 8");
+        if (value != 0 && value != 6 && value != 7 && value != 8) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: command loop is 0, 6, 7 or 8");
         c->debug_stop = (uint32_t)value;
         break;
     case BRX_OPTION_LOOP_BUILD:

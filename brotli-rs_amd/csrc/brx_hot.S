@@ -669,7 +669,7 @@
     v_or_b32 VT0, 0x80000000, VT0
     v_cmp_eq_u32 vcc, 1, VT2
     v_cndmask_b32 VLHOFF, VLHOFF, VT0, vcc
-    v_and_b32 VT2, 3, VT1
+    v_and_b32 VT2, 7, VT1                               // (kind 5: a one-symbol explicit-distance code made a table, prepare_fast_tables: general here)
     v_lshrrev_b32 VT1, 16, VT1
     v_or_b32 VT1, 0x80000000, VT1
     v_cmp_eq_u32 vcc, 1, VT2

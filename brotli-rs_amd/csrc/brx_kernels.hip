@@ -358,7 +358,7 @@ FI u32 in_byte_tail(Dec &d) {
 #define ST_MIRROR 40  // (2 words) host-visible mirror of the output slot, or 0
 #define ST_PAUSE_AT 43 // (2 words) resumable mode: seg_frame stops between two meta-blocks once this many bytes are out (else ~0)
 #define ST_IN_LOW 45   // (2 words) ... or once the input cursor is this far (BrxResume::in_low; else ~0)
-#define ST_SPEC 47    // 1: batch decode -- the assembly loop may run past the end of the input (a meta-block that did is taken back and decoded
+#define ST_SPEC 47    // bit 1: option command_loop = 6 (no meta-block qualifies for the assembly loop); bit 0 = 1: batch decode -- the assembly loop may run past the end of the input (a meta-block that did is taken back and decoded
                       // again by the C++ loop: "speculative end" in the kernel's stream loop); 0: the resumable decode, END_MARGIN applies
 #define ST_NEED 42    // after a header whose tables spilled: words of table memory the meta-block needs (Dec::need_peak)
 #define SEG_NEED_HEADER 100u // seg_frame: a compressed meta-block follows (anything < 100 is a final status)
@@ -480,6 +480,7 @@ template <bool INL, bool WIDE> FI u32 decode_sym_as(Dec &d, const Lds &s, u32 h,
     if (kind == 0u) return LK_NONE;
     if (kind == 1u) {
         sym = h0 >> 16;
+        if (WIDE && sym == 0xffffu) sym = rfl(tm_ld32<INL>(d, s, h + 13u)); // (prepare_fast_tables: a one-symbol explicit-distance code)
         return LK_OK;
     }
     u64 rem = in_remaining(d);
@@ -1616,24 +1617,52 @@ FI u32 distance_payload(u32 code, u32 npostfix, u32 ndirect) {
 // Rewrite the symbol entries of a qualifying meta-block (all tables resident in LDS) into the assembly loop's forms.
 // `uniform`: every literal block type has context mode `mode`, so the literal entries can carry the context info;
 // otherwise they stay plain bytes and the loop looks the info up per literal (table rebuilt at every block switch).
-// Returns false (nothing rewritten) for the one shape that has no payload form: a ONE-symbol distance tree whose symbol
-// is not a last-distance code (its 16-bit slot in the info word cannot hold a base).
+// Always true since round 5 (the one shape that had no payload form -- a ONE-symbol distance tree whose symbol is not a last-distance
+// code: its 16-bit slot in the info word cannot hold a base -- is materialised as a table, below).
 FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mode, bool uniform) {
     const u8 *lut = (const u8 *)d.t_lut;
     for (u32 t = 0; t < m.ntd; t++) {
-        const u32 info = rfl(s.tm[rfl(s.tm[m.hd + t]) + BRX_HDR_INFO]);
-        if ((info & 3u) == 1u && (info >> 16) >= 16u) return false;
-    }
-    for (u32 t = 0; t < m.ntd; t++) {
         const u32 h = rfl(s.tm[m.hd + t]);
         const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
-        if ((info & 3u) != 2u) continue; // (a one-symbol tree keeps the plain code in its info word)
+        if ((info & 3u) == 1u && (info >> 16) >= 16u) {
+            // A ONE-symbol distance code that names an EXPLICIT distance (every copy of the meta-block at one distance code: records,
+            // low-entropy data; profiles/r05_fixture_rates.txt, e094_lowent).  Its payload does not fit the info word's 16 bits;
+            // until round 5 such a meta-block stayed in the C++ loop.  Now the tree becomes a table the assembly loop's ordinary
+            // lookup reads (as the one-symbol insert&copy code below): header[0] always matches at length 0, base -4 puts its two
+            // candidate entries (32-bit) into header words 13 / 14 = the payload; kind bit 2 tells the assembly loop "general",
+            // the C++ lookup still sees kind 1 and finds the marker 0xffff: the payload is in word 13 (decode_sym_as).
+            const u32 pay = distance_payload(info >> 16, m.npostfix, m.ndirect);
+            if (d.lane == 0u) {
+                s.tm[h] = 0xffff0000u | ((0u - 4u) & 0xffffu);
+                s.tm[h + 13u] = pay;
+                s.tm[h + 14u] = pay;
+                s.tm[h + BRX_HDR_INFO] = (info & 0xff00u) | 5u | 0xffff0000u;
+            }
+            continue;
+        }
+        if ((info & 3u) != 2u) continue; // (a one-symbol tree of a last-distance code keeps the plain code in its info word)
         const u32 nnz = info >> 16;
         for (u32 k = d.lane; k < nnz; k += 64u) s.tm[h + BRX_HDR_WORDS + k] = distance_payload(s.tm[h + BRX_HDR_WORDS + k], m.npostfix, m.ndirect);
     }
     for (u32 t = 0; t < n_iac; t++) {
         const u32 h = rfl(s.tm[m.hi + t]);
-        const u32 nnz = rfl(s.tm[h + BRX_HDR_INFO]) >> 16;
+        const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
+        if ((info & 3u) == 1u) {
+            // A ONE-symbol insert&copy code (a meta-block whose commands are all alike -- e.g. one insert of 30 000 literals: low-entropy
+            // data without repeats at quality 10 / 11 -- zero bits per symbol, Q5).  Round 5: it becomes a table the assembly loop's
+            // ordinary lookup reads -- header[0] = "always matches" (limit all ones; lane 0 is the lowest lane: length 0, no bits) with
+            // base -8, which puts its two candidate entries into header word 13 (unused: a one-symbol code has no lengths), both
+            // = the symbol's record offset; the info word carries the same form for the C++ loop.  Before, such a meta-block ran in
+            // the C++ loop alone: 2 700 cycles per literal (profiles/r05_fixture_rates.txt: e072_lowent 33 ms).
+            const u32 x = ((info >> 16) << 4) & 0xffffu;
+            if (d.lane == 0u) {
+                s.tm[h] = 0xffff0000u | (0u - 8u & 0xffffu);
+                s.tm[h + 13u] = x | (x << 16);
+                s.tm[h + BRX_HDR_INFO] = (info & 0xffffu) | (x << 16);
+            }
+            continue;
+        }
+        const u32 nnz = info >> 16;
         u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
         for (u32 k = d.lane; k < nnz; k += 64u) sy[k] = (u16)(sy[k] << 4);
     }
@@ -1695,7 +1724,8 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             else {
                 const u32 kind_ = rfl(s.tm[h_ + BRX_HDR_INFO]) & 3u; // literal / distance trees may be one-symbol codes
                 const bool iac_ = i >= m.ntl && i < m.ntl + I.nbl;
-                if (kind_ != 2u && (iac_ || kind_ != 1u)) { ok = 0u; why |= 4u; }
+                if (kind_ != 2u && kind_ != 1u) { ok = 0u; why |= 4u; } // (general or one-symbol codes: prepare_fast_tables)
+                (void)iac_;
                 // a general code must be complete (the assembly lookup has no "no such codeword" exit, Q15):
                 // the left-aligned upper bound of its longest codes is then exactly 2^15 (the high half of the header word)
                 const u32 hvw_ = s.tm[h_ + (d.lane & 15u)];
@@ -1703,6 +1733,8 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
                 if (kind_ == 2u && !full_) { ok = 0u; why |= 8u; }
             }
         }
+        if ((rfl(s.st[ST_SPEC]) & 2u) != 0u) { ok = 0u; why |= 64u; } // (option command_loop = 6: as if no meta-block qualified -- the suite's way
+                                                                       // to the path of meta-blocks the assembly loop cannot take)
         if (ok) { // one context mode for every literal block type (what encoders emit today): literal entries carry the info
             bool uniform = true;
             for (u32 i = 1; i < L.nbl; i++)
@@ -1710,7 +1742,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             if (!prepare_fast_tables(d, s, m, I.nbl, tm_u8(d, s, m.cmode_w * 4u), uniform)) { ok = 0u; why |= 128u; }
             else ok = uniform ? 1u : 3u; // bit 1: mixed context modes
         }
-        s.mbw[MBW_ASM] = ok ? (ok | (rfl(s.st[ST_SPEC]) << 2)) : 0u; // bit 2: where the loop is poisoned (brx_hot.S, .Lwsafe_spec)
+        s.mbw[MBW_ASM] = ok ? (ok | ((rfl(s.st[ST_SPEC]) & 1u) << 2)) : 0u; // bit 2: where the loop is poisoned (brx_hot.S, .Lwsafe_spec)
         if (!ok) s.pad[8] |= why;
     }
     const bool fast_tables = rfl(s.mbw[MBW_ASM]) != 0u; // symbol entries are in the assembly loop's forms
@@ -1784,7 +1816,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             // ---- decode_distance :1412-1481
             if (fast_tables && (dcode & BRX_DIST_UNFIT) == BRX_DIST_UNFIT) dcode &= 0xffffu; // plain code: the arithmetic below
             else if (fast_tables && !implicit_zero && dcode >= 16u && (dcode & 0x80000000u) == 0u) {
-                // payload form of a code >= 16: nbits | base << 5 (one-symbol trees keep the plain code, always < 16 here)
+                // payload form of a code >= 16: nbits | base << 5 (one-symbol trees: the plain code < 16, or the payload via decode_sym_as)
                 u32 e;
                 if (!in_bits(d, dcode & 31u, e)) return ST_EOF;
                 distance = (dcode >> 5) + (e << m.npostfix);
@@ -2288,7 +2320,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 s.st[ST_IACTAB] = (u32)(uintptr_t)a.t.iac; s.st[ST_IACTAB + 1] = (u32)((u64)(uintptr_t)a.t.iac >> 32);
                 s.st[ST_PAUSE_AT] = 0xffffffffu; s.st[ST_PAUSE_AT + 1] = 0xffffffffu;
                 s.st[ST_IN_LOW] = 0xffffffffu; s.st[ST_IN_LOW + 1] = 0xffffffffu;
-                s.st[ST_SPEC] = (a.resume == nullptr && a.debug_stop == 0u) ? 1u : 0u;
+                s.st[ST_SPEC] = ((a.resume == nullptr && a.debug_stop == 0u) ? 1u : 0u) | (a.debug_stop == 6u ? 2u : 0u);
             }
             if (lane < 32u) s.pad[lane] = 0u;
         }
@@ -2556,7 +2588,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // The meta-block is taken back -- everything out to HBM, Lds::st as it stood at the header (the flush cursor set to
                 // the position, a slab claimed meanwhile stays claimed), the ring reloaded from the stream's own output as for a late
                 // resume -- and decoded again by the C++ loop with the reference's exact end-of-input rules.
-                if (use_asm && rfl(s.st[ST_SPEC]) != 0u && get64(s, 3) > get64(s, 5)) {
+                if (use_asm && (rfl(s.st[ST_SPEC]) & 1u) != 0u && get64(s, 3) > get64(s, 5)) {
                     if (lane == 0u) (void)atomicAdd(a.work_counter + 18, 1u);
                     seg_finish();
                     __threadfence();

@@ -121,7 +121,8 @@ void brx_ctx_destroy(brx_ctx *ctx);
  * instances behind / next to the regular one, the lean instance for short streams). */
 enum {
     BRX_OPTION_COMMAND_LOOP = 1,  /* 0 = assembly loop with the C++ loop as its safety net (default); 8 = the C++ loop alone, whole
-                                     meta-blocks; 7 = the C++ loop alone, re-entered after every command */
+                                     meta-blocks; 7 = the C++ loop alone, re-entered after every command; 6 = the default loop with every
+                                     meta-block treated as one the assembly loop cannot take (also honoured by bounded readers made after it) */
     BRX_OPTION_LOOP_BUILD = 2,    /* -1 = by occupancy (default); 0 = bit window in VGPRs (full chip); 1 = in SGPRs (sparse launch) */
     BRX_OPTION_QUEUE_ORDER = 3,   /* 1 = longest compressed stream first on the host path (default); 0 = index order */
     BRX_OPTION_HAND_UP = 4,       /* 1 = streams whose tables spill a kernel's LDS go to the wider instance that holds them (default);

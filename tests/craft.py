@@ -271,11 +271,12 @@ class MetaBlock:
     a near-uniform insert&copy code over the symbols the commands use and a uniform distance code over the 64 symbols
     of NPOSTFIX = NDIRECT = 0.  Commands: (literal bytes, copy_len, distance) -- distance None = no copy (last command)."""
 
-    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0, lit_lengths=None, single_iac=False):
+    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0, lit_lengths=None, single_iac=False, single_dist=False):
         self.commands, self.mlen, self.npostfix, self.ndirect = commands, mlen, npostfix, ndirect
+        self.single_dist = single_dist  # a ONE-symbol distance code (every copy has the same distance code; zero bits per symbol; the
+                                        # copies may still differ in the code's extra bits)
         self.lit_lengths = lit_lengths  # code lengths of the 256 literals (default: 8 bits each)
-        self.single_iac = single_iac    # keep a ONE-symbol insert&copy code (zero bits per symbol; such a meta-block runs in the
-                                        # HIP decoder's C++ command loop, never in the assembly loop)
+        self.single_iac = single_iac    # keep a ONE-symbol insert&copy code (zero bits per symbol)
 
     def emit(self, b, is_last, out_len_hint):
         mlen = self.mlen if self.mlen is not None else out_len_hint
@@ -303,7 +304,13 @@ class MetaBlock:
         else:
             iac = complex_code(b, uniform_lengths(704, syms), zero_run_17=True)
         dalpha = 16 + self.ndirect + (48 << self.npostfix)
-        dist = complex_code(b, uniform_lengths(dalpha), zero_run_17=False)
+        if self.single_dist:
+            codes = sorted({distance_code(d, self.npostfix, self.ndirect)[0] for l, c, d in self.commands if d is not None})
+            assert len(codes) == 1
+            simple_code(b, codes, max(1, (dalpha - 1).bit_length()))
+            dist = {codes[0]: (0, 0)}
+        else:
+            dist = complex_code(b, uniform_lengths(dalpha), zero_run_17=False)
         for lits, cl, d in self.commands:
             sym, ie, ce = iac_symbol(len(lits), cl if cl else 2)
             put_sym(b, iac, sym)
@@ -678,7 +685,7 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18, first
     return b.bytes(), bytes(out)
 
 
-def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac=False):
+def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac=False, single_dist=False):
     """A stream of ANY length in constant memory: (prefix, unit, final, unit_output).  stream = prefix + unit * K + final decodes
     to unit_output * K.  The prefix is the stream header and an empty metadata block (which pads to a byte boundary); a unit is
     one compressed meta-block -- `commands` x (`literals` random bytes at 8 bits each, then a copy of 4 from inside the unit,
@@ -714,7 +721,7 @@ def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac
         lens[14] = lens[15] = 15
         data = bytes(rng.choice((14, 15)) for _ in range(literals))
         b = Bits()
-        MetaBlock([(data, 4, 8)], mlen=len(data) + 4, lit_lengths=lens, single_iac=single_iac).emit(b, False, len(data) + 4)
+        MetaBlock([(data, 4, 8)], mlen=len(data) + 4, lit_lengths=lens, single_iac=single_iac, single_dist=single_dist).emit(b, False, len(data) + 4)
         empty_metadata(b)
         return prefix, b.bytes(), b"\x03", data + data[-8:-4]
     if raw:  # (raw=True: the unit is one UNCOMPRESSED meta-block of 64 KiB -- more compressed bytes than output bytes)

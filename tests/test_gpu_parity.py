@@ -474,14 +474,23 @@ def test_pulled_reader_on_input_heavy_streams():
         d = brx.Decompressor(_periodic_source(parts, 60), c2, streaming=True)
         assert _read_periodic(d, parts[3]) == 60 * len(parts[3])  # 35 MiB: the framing segment pauses in FRONT of a block that does not fit
         d.close()
-        # (d) the commands of (b) in meta-blocks that do NOT qualify for the assembly loop (a one-symbol insert&copy code): the C++
-        # loop takes a whole command per call, 375 KiB of input with a margin of 64 KiB to the end of a 2 MiB window
-        parts = craft.periodic_stream_parts(16, raw=True, literals=200 << 10, single_iac=True)
+        # (d) the commands of (b) in the C++ command loop (option command_loop = 6: no meta-block qualifies; until round 5 a one-symbol
+        # insert&copy or distance code put a meta-block there -- both run in the assembly loop now and are covered here as well): a
+        # whole command per call, 375 KiB of input with a margin of 64 KiB to the end of a 2 MiB window
+        for seed, kw in ((17, dict(single_iac=True)), (18, dict(single_dist=True))):
+            parts = craft.periodic_stream_parts(seed, raw=True, literals=200 << 10, **kw)
+            assert oracle.decode(parts[0] + parts[1] * 2 + parts[2], 0, cap=1 << 20)[1] == parts[3] * 2
+            d = brx.Decompressor(_periodic_source(parts, 30), c2, streaming=True)
+            assert _read_periodic(d, parts[3]) == 30 * len(parts[3])
+            d.close()
+        parts = craft.periodic_stream_parts(16, raw=True, literals=200 << 10)
         assert oracle.decode(parts[0] + parts[1] * 2 + parts[2], 0, cap=1 << 20)[1] == parts[3] * 2
         before = c2.stream_short_slices()
+        c2.set_option("command_loop", 6)
         d = brx.Decompressor(_periodic_source(parts, 60), c2, streaming=True)
         assert _read_periodic(d, parts[3]) == 60 * len(parts[3])  # 12 MiB out of 22 MiB
         d.close()
+        c2.set_option("command_loop", 0)
         assert c2.stream_short_slices() > before, (before, c2.stream_short_slices())
         # (e) text in meta-blocks of 2 MiB (the adaptive generator) under a 1 MiB window: the assembly loop runs up to the end of the
         # resident input and hands the straddling command back; the slice pauses in front of it
@@ -921,10 +930,11 @@ def test_bitflip_fuzz_of_the_long_streams(ctx):
     assert sum(1 for w in want if w[0] == 0) > 0 and sum(1 for w in want if w[0] != 0) > 20
 
 
-@pytest.mark.parametrize("stop", ["7", "8"])
+@pytest.mark.parametrize("stop", ["6", "7", "8"])
 def test_cpp_only_command_loops(stop):
     """BRX_DEBUG_STOP=8: the C++ command loop alone, whole meta-blocks; =7: re-entered after every single command (the
-    resume points the assembly loop uses).  Same parity subset as the mixed path, in a fresh process."""
+    resume points the assembly loop uses); =6: the default loop with every meta-block treated as one the assembly loop cannot
+    take (what a meta-block with more than 64 trees gets).  Same parity subset as the mixed path, in a fresh process."""
     import subprocess
     import sys
     env = dict(os.environ, BRX_DEBUG_STOP=stop)
@@ -1222,6 +1232,91 @@ def test_tree_cache_of_many_tree_meta_blocks(build, mode):
             assert w[0] == 0 and w[1] == out_
         streams = [f[0] for f in fx] * 40 + [_read("mapsdatazrh.compressed")] * 8
         want = [f[1] for f in fx] * 40 + [_read("mapsdatazrh")] * 8
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
+            bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+            assert not bad, bad[:8]
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("build", [0, 1])
+def test_one_symbol_insert_copy_and_distance_codes_in_the_assembly_loop(build):
+    """Round 5: a meta-block whose commands all carry the SAME insert&copy symbol has a one-symbol code (zero bits per symbol, Q5) --
+    one insert of 30 000 literals (low-entropy data without repeats at quality 10 / 11), or a regular record structure; likewise a
+    one-symbol DISTANCE code naming an explicit distance (every copy in one distance bucket).  Both used to run in the C++ loop alone
+    (2 700 cycles per literal); prepare_fast_tables now makes them tables the assembly loop's lookup reads.
+    Hand-assembled: 1 .. 2000 equal commands, literals of 8 bits and of a skewed code, explicit distances in and behind the ring,
+    one-symbol insert&copy code / one-symbol distance code (with and without extra bits, NPOSTFIX / NDIRECT) / both; and the two
+    libbrotlienc fixtures of those shapes.  Both builds of the loop, against the oracle."""
+    import craft
+    import random
+    rng = random.Random(21)
+    c2 = brx_knobs.context(0, loop_build=build)
+    try:
+        streams, want = [], []
+        for ncmd, nlit, clen, skew in ((1, 30000, 4, True), (400, 5, 6, False), (37, 130, 9, True), (3, 7, 2, False), (2000, 1, 3, False)):
+            lens = None
+            if skew:
+                lens = [0] * 256
+                for k in range(14):
+                    lens[k] = k + 1
+                lens[14] = lens[15] = 15
+            out, cmds = bytearray(), []
+            for k in range(ncmd):
+                lits = bytes(rng.choice((0, 1, 2, 14, 15)) if skew else rng.randrange(256) for _ in range(nlit))
+                out += lits
+                dist = rng.choice([1, 2, 3, len(out), min(len(out), 2047), min(len(out), 2049), min(len(out), 5000)])
+                cmds.append((lits, clen, dist))
+                for _ in range(clen):
+                    out.append(out[-dist])
+            b = craft.Bits()
+            craft.stream_header(b, 18)
+            craft.MetaBlock(cmds, mlen=len(out), lit_lengths=lens, single_iac=True).emit(b, True, len(out))
+            st_ = b.bytes()
+            w = oracle.decode(st_, 0, cap=len(out) + 64)
+            assert w[0] == 0 and w[1] == bytes(out), (ncmd, nlit)
+            streams += [st_] * 16
+            want += [bytes(out)] * 16
+        # one-symbol distance codes: every copy's distance in ONE code's bucket (lo .. hi share the code; the extra bits differ)
+        for ncmd, nlit, clen, lo, hi, npostfix, ndirect, one_iac in ((300, 40, 5, 8, 8, 0, 0, False), (300, 9, 4, 17, 20, 0, 0, False),
+                                                                      (200, 70, 7, 2100, 2500, 0, 0, True), (500, 3, 3, 1, 1, 0, 0, False),
+                                                                      (150, 33, 6, 300, 330, 2, 5, False), (90, 600, 40, 40000, 50000, 1, 0, True),
+                                                                      (64, 11, 4, 19, 19, 0, 12, False)):
+            code = craft.distance_code(lo, npostfix, ndirect)[0]
+            bucket = [x for x in range(lo, hi + 1) if craft.distance_code(x, npostfix, ndirect)[0] == code]
+            out = bytearray(rng.randrange(256) for _ in range(hi))
+            cmds = [(bytes(out), clen, rng.choice(bucket))]
+            for _ in range(clen):
+                out.append(out[-cmds[0][2]])
+            for k in range(ncmd - 1):
+                lits = bytes(rng.randrange(256) for _ in range(nlit if one_iac else rng.randrange(1, nlit + 1)))
+                out += lits
+                dist = rng.choice(bucket)
+                cmds.append((lits, clen, dist))
+                for _ in range(clen):
+                    out.append(out[-dist])
+            if one_iac:
+                cmds[0] = (cmds[0][0][hi - nlit:], clen, cmds[0][2])
+            head = bytes(out[:hi - nlit]) if one_iac else b""  # (the first command's surplus literals go into an uncompressed meta-block in front)
+            b = craft.Bits()
+            craft.stream_header(b, 18)
+            if one_iac and hi > nlit:
+                craft.raw_block(b, head)
+                craft.MetaBlock(cmds, mlen=len(out) - len(head), npostfix=npostfix, ndirect=ndirect, single_iac=True, single_dist=True).emit(b, True, len(out) - len(head))
+            else:
+                craft.MetaBlock(cmds, mlen=len(out), npostfix=npostfix, ndirect=ndirect, single_iac=one_iac, single_dist=True).emit(b, True, len(out))
+            st_ = b.bytes()
+            w = oracle.decode(st_, 0, cap=len(out) + 64)
+            assert w[0] == 0 and w[1] == bytes(out), (ncmd, nlit, lo, w[0])
+            streams += [st_] * 16
+            want += [bytes(out)] * 16
+        for name in ("e072_lowent", "e094_lowent"):
+            st_ = open(os.path.join(GOLDEN, "enc", name + ".compressed"), "rb").read()
+            w = oracle.decode(st_, 0, cap=1 << 16)
+            assert w[0] == 0
+            streams += [st_] * 16
+            want += [w[1]] * 16
         for rep in range(2):
             outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
             bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
