@@ -1321,6 +1321,21 @@ def test_one_symbol_insert_copy_and_distance_codes_in_the_assembly_loop(build):
             outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
             bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
             assert not bad, bad[:8]
+        # the same streams cut short (the speculative end: a meta-block that read past the end is taken back and decoded exactly) and
+        # with too little room: status and bytes as the oracle's
+        cuts, caps = [], []
+        for st_, w in list(zip(streams, want))[::16]:
+            for cut in sorted({len(st_) - 1, len(st_) - 2, len(st_) - 5, len(st_) // 2, len(st_) // 3, 40, 12} | {rng.randrange(8, len(st_)) for _ in range(24)}):
+                cuts.append(st_[:cut])
+                caps.append(len(w) + 8)
+            for room in (len(w) - 1, len(w) - 3, len(w) // 2, 1):
+                cuts.append(st_)
+                caps.append(room)
+        exp = [oracle.decode(c_, 0, cap=r_) for c_, r_ in zip(cuts, caps)]
+        outs, status, out_len = c2.decode_batch(cuts, caps)
+        bad = [(i, e[0], int(t)) for i, (e, o, t) in enumerate(zip(exp, outs, status)) if e[0] != t or (t == 0 and o != e[1])]
+        assert not bad, bad[:8]
+        assert sum(1 for e in exp if e[0] != 0) > 100
     finally:
         c2.close()
 
