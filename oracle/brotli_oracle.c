@@ -815,6 +815,7 @@ static int compressed_meta_block(Dec *d, size_t mlen) {
     if (!cmap_l) { rc = -1; goto out; }
     if (ntrees_l >= 2 && (rc = parse_context_map(d, ntrees_l, cmap_l, 64 * (size_t)L.nbl))) goto out;
     if ((rc = parse_n_bltypes(d, &ntrees_d))) goto out; /* parse_n_trees_d :582 */
+    if (g_trace) fprintf(stderr, "NTD %u %u %u\n", ntrees_d, D.nbl, I.nbl); /* analysis aid: distance trees, distance / insert&copy block types */
     cmap_d = (uint8_t *)calloc(4 * (size_t)D.nbl, 1);
     if (!cmap_d) { rc = -1; goto out; }
     if (ntrees_d >= 2 && (rc = parse_context_map(d, ntrees_d, cmap_d, 4 * (size_t)D.nbl))) goto out;
