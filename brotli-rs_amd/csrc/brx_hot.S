@@ -504,6 +504,29 @@
 .endm
 #endif
 
+// Descriptors (LDS byte address of the header, or 0x80000000 | x for a one-symbol tree) of the trees whose INDICES sit in the lanes of
+// \vidx -> \vd (may be the same register), gathered from table memory: tm[list + index] = h, the header's info word.  \mbwoff = where
+// the meta-block words hold the list's word address (20: literal trees, 28: distance trees).  What the lanes of VLHOFF / VDHOFF give
+// for the first 64 trees; a meta-block with more trees of a kind (one piece of > 1 MiB from libbrotlienc: up to 256 literal trees,
+// profiles/r05_big_trees.txt) takes this on entry and at block switches.  EXEC = the lanes wanted; clobbers \vta, \vtb, \mask.
+.macro DESC_GATHER vd, vidx, mbwoff, kmask, vta, vtb, mask
+    ds_read_b32 \vta, VZERO offset:LDS_MBW+\mbwoff
+    s_waitcnt lgkmcnt(0)
+    v_add_u32 \vd, \vidx, \vta
+    v_lshlrev_b32 \vd, 2, \vd
+    ds_read_b32 \vd, \vd offset:LDS_TM                  // h
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 \vd, 2, \vd
+    ds_read_b32 \vta, \vd offset:LDS_TM+INFOOFF         // kind | max_len << 8 | x << 16
+    v_add_u32 \vd, LDS_TM, \vd
+    s_waitcnt lgkmcnt(0)
+    v_and_b32 \vtb, \kmask, \vta
+    v_lshrrev_b32 \vta, 16, \vta
+    v_or_b32 \vta, 0x80000000, \vta
+    v_cmp_eq_u32 \mask, 1, \vtb
+    s_nop 1                                             // (a VALU-written SGPR pair as the next VALU's mask)
+    v_cndmask_b32 \vd, \vd, \vta, \mask
+.endm
 // ======================================================================================================== entry
     .p2align 8
     s_getreg_b32 PRIOW, hwreg(HW_REG_HW_ID, 0, 4)       // this wave's slot in its SIMD (phase of the priority rotation, .Lspecial)
@@ -698,15 +721,20 @@
     v_readfirstlane_b32 T0, VT3                         // context mode
     // CMH[c] = descriptor of the literal tree of context id c; VDH4 lane 2k = descriptor of the distance tree of
     // distance context k (both for the current block types; a block switch leaves the loop and re-enters here)
-    v_lshlrev_b32 VT4, 2, VT4
-    v_mov_b32 VCMIDX, VT4
-    ds_bpermute_b32 VT4, VT4, VLHOFF
+    v_lshlrev_b32 VCMIDX, 2, VT4
+    s_cmp_gt_u32 s13, 63
+    s_cbranch_scc1 .Lent_cmh_far                        // more than 64 literal trees: FLAGS bit 7, DESC_GATHER
+    ds_bpermute_b32 VT4, VCMIDX, VLHOFF
+.Lent_cmh_have:
     v_lshrrev_b32 VT3, 1, VLANE                         // lane 2k (and 2k + 1) = context k
     v_lshlrev_b32 VT3, 3, VT3
     v_lshrrev_b32 VT3, VT3, CMDW
     v_and_b32 VT3, 0xff, VT3
+    s_cmp_gt_u32 s14, 63
+    s_cbranch_scc1 .Lent_vdh_far                        // more than 64 distance trees: FLAGS bit 8
     v_lshlrev_b32 VT3, 2, VT3
     ds_bpermute_b32 VDH4, VT3, VDHOFF
+.Lent_vdh_have:
     v_lshlrev_b32 VT3, 2, VLANE
     s_waitcnt lgkmcnt(0)
     ds_write_b32 VT3, VT4 offset:LDS_CMH
@@ -1892,7 +1920,10 @@
     s_andn2_b32 SLOTT, SLOTT, T0
     s_lshl_b32 T0, T6, CLEN
     s_or_b32 SLOTT, SLOTT, T0
+    s_bitcmp1_b32 FLAGS, 7
+    s_cbranch_scc1 .Lslot_fill_far                      // more than 64 literal trees: the descriptor from table memory
     v_readlane_b32 T0, VLHOFF, T6                       // the tree's descriptor
+.Lslot_fill_have:
     s_bfm_b64 exec, 16, T1                              // the slot's lanes
     s_cmp_lt_i32 T0, 0
     s_cbranch_scc1 .Lslot_fill_single
@@ -1920,6 +1951,25 @@
     s_waitcnt lgkmcnt(0)
     s_mov_b64 exec, -1
     s_setpc_b64 LINKB
+.Lslot_fill_far:                                        // (DESC_GATHER for one tree, the decisions on the scalar side)
+    ds_read_b32 VT0, VZERO offset:LDS_MBW+20
+    s_waitcnt lgkmcnt(0)
+    v_add_u32 VT0, T6, VT0
+    v_lshlrev_b32 VT0, 2, VT0
+    ds_read_b32 VT0, VT0 offset:LDS_TM                  // h
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 VT0, 2, VT0
+    ds_read_b32 VT1, VT0 offset:LDS_TM+INFOOFF
+    s_waitcnt lgkmcnt(0)
+    v_readfirstlane_b32 T0, VT0
+    v_readfirstlane_b32 CLEN, VT1
+    s_add_u32 T0, T0, LDS_TM
+    s_and_b32 vcc_lo, CLEN, 3
+    s_cmp_eq_u32 vcc_lo, 1
+    s_cbranch_scc0 .Lslot_fill_have
+    s_lshr_b32 T0, CLEN, 16                             // a one-symbol tree
+    s_bitset1_b32 T0, 31
+    s_branch .Lslot_fill_have
 // The context map row changed (a literal block switch): VT4 = tree index per context id -> VCMAP, VSLOT.  EXEC = all lanes.
 .macro SLOT_REMAP
     v_lshlrev_b32 VCMAP, 1, VT4
@@ -1933,6 +1983,14 @@
     .endr
 .endm
 #endif
+.Lent_cmh_far:
+    s_bitset1_b32 FLAGS, 7
+    DESC_GATHER VT4, VT4, 20, 3, VT0, VT1, vcc
+    s_branch .Lent_cmh_have
+.Lent_vdh_far:
+    s_bitset1_b32 FLAGS, 8
+    DESC_GATHER VDH4, VT3, 28, 7, VT0, VT1, vcc
+    s_branch .Lent_vdh_have
 .Lland:
     s_cmp_eq_u32 PFREE, 0
     s_cbranch_scc1 .Lland_chk
@@ -2484,13 +2542,19 @@
     s_bitcmp1_b32 FLAGS, 6
     s_cbranch_scc0 .Lsw_L_resident
     SLOT_REMAP
-    v_lshlrev_b32 VT4, 2, VT4                           // ... and the descriptor table of the per-literal loop (SL_RUN_END)
+    s_bitcmp1_b32 FLAGS, 7                              // ... and the descriptor table of the per-literal loop (SL_RUN_END)
+    s_cbranch_scc1 .Lsw_L_far
+    v_lshlrev_b32 VT4, 2, VT4
     ds_bpermute_b32 VT4, VT4, VLHOFF
+.Lsw_L_have:
     v_lshlrev_b32 VT3, 2, VLANE
     s_waitcnt lgkmcnt(0)
     ds_write_b32 VT3, VT4 offset:LDS_CMH
     s_mov_b64 exec, XLOOP
     s_setpc_b64 LINKB
+.Lsw_L_far:
+    DESC_GATHER VT4, VT4, 20, 3, VT0, VT1, vcc
+    s_branch .Lsw_L_have
 .Lsw_L_resident:
 #endif
     v_lshlrev_b32 VCMAP, 1, VT4
@@ -2523,14 +2587,20 @@
     SLOT_REMAP
 .Lx_lsu_noslots:
 #endif
+    s_bitcmp1_b32 FLAGS, 7
+    s_cbranch_scc1 .Lx_lsu_far
     v_lshlrev_b32 VT4, 2, VT4
     ds_bpermute_b32 VT4, VT4, VLHOFF
+.Lx_lsu_have:
     v_lshlrev_b32 VT3, 2, VLANE
     s_waitcnt lgkmcnt(0)
     ds_write_b32 VT3, VT4 offset:LDS_CMH
     s_mov_b64 exec, XLOOP
     ds_read_b32 VH, VC offset:LDS_CMH
     s_branch .Llit_ticked_u
+.Lx_lsu_far:
+    DESC_GATHER VT4, VT4, 20, 3, VT0, VT1, vcc
+    s_branch .Lx_lsu_have
 .Lx_lit_switch_m:                                       // (block types of different context modes: the C++ side switches)
 .Lx_lit_switch:                                         // literal block count exhausted (or poisoned), mid-run
     s_mov_b32 LBLEN, 0
@@ -2557,8 +2627,11 @@
     v_lshlrev_b32 VT3, 3, VT3
     v_lshrrev_b32 VT3, VT3, CMDW
     v_and_b32 VT3, 0xff, VT3
+    s_bitcmp1_b32 FLAGS, 8
+    s_cbranch_scc1 .Lx_ds_far
     v_lshlrev_b32 VT3, 2, VT3
     ds_bpermute_b32 VDH4, VT3, VDHOFF
+.Lx_ds_have:
     s_waitcnt lgkmcnt(0)
     s_mov_b64 exec, XLOOP
     s_mov_b32 T2, 0xc0000000
@@ -2577,6 +2650,9 @@
     s_cbranch_scc0 .Ldist_ticked
     s_and_b32 DCODE, DTREE, 0xffff                      // a one-symbol tree (always a last-distance code here)
     s_branch .Ldist_ring_s
+.Lx_ds_far:
+    DESC_GATHER VDH4, VT3, 28, 7, VT0, VT1, s[86:87]    // (T2 / T3 as the mask: vcc may hold the early insert&copy compare)
+    s_branch .Lx_ds_have
 .Lx_dist_bail:
     s_mov_b32 DBLEN, 0
     s_mov_b32 INS, 0

@@ -685,6 +685,120 @@ def growing_tables_stream(seed, trees_per_mb, mode=0, n_cmds=40, wbits=18, first
     return b.bytes(), bytes(out)
 
 
+def many_trees_stream(seed, ntl, ntd, nbl_l, nbl_d, n_cmds=400, wbits=18):
+    """One compressed meta-block with up to 256 literal and 256 distance trees behind context maps, nbl_l literal and nbl_d distance
+    block types that SWITCH (block type symbols 0 = the one before, 1 = the next one; counts 1 .. 4 or 17 .. 24), what one piece of
+    more than a megabyte looks like out of libbrotlienc (profiles/r05_big_trees.txt) at a size a test decodes in no time.  Every
+    literal tree has two symbols (one bit per literal under ANY tree: the bytes that come out tell the trees apart), every distance
+    tree two symbols -- one of the four last-distance codes and one explicit code of 1 or 2 extra bits; commands: 6 / 7 literals,
+    then a copy of 2 .. 5 (all four distance contexts).  The caller takes the expected output from the oracle (the stream is
+    valid by construction: a model of the distance ring keeps every distance inside the output)."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    raw_block(b, bytes(rng.randrange(256) for _ in range(40)))  # (so that every distance of the ring and of the explicit codes is inside the output)
+    cmds = [(6 + rng.randrange(2), 2 + rng.randrange(4)) for _ in range(n_cmds)]
+    mlen = sum(i + c for i, c in cmds) - cmds[-1][1]  # (the last command's copy is cut off by MLEN)
+    _mb_header(b, mlen, True)
+    BLEN = {0: (1, 2), 4: (17, 3)}  # block count code -> (base, extra bits)
+
+    def category(n):
+        """NBLTYPES, the two codes, the first count; returns the state of the category"""
+        _nbltypes(b, n)
+        st = {"n": n, "cur": 0, "prev": 1, "left": 1 << 30}
+        if n >= 2:
+            simple_code(b, [0, 1], (n + 1).bit_length())
+            simple_code(b, [0, 4], 5)
+            st["left"] = count(st)
+        return st
+
+    def count(st):
+        code = rng.choice((0, 0, 4))
+        base, nb = BLEN[code]
+        x = rng.randrange(1 << nb)
+        b.put(*code_bits([0, 4], code))
+        b.put(x, nb)
+        return base + x
+
+    def tick(st):
+        """one symbol of the category is about to be read: the block switch in front of it, if its count is used up"""
+        if st["left"] == 0:
+            sym = rng.randrange(2)
+            b.put(*code_bits([0, 1], sym))
+            new = st["prev"] if sym == 0 else (st["cur"] + 1) % st["n"]
+            st["prev"], st["cur"] = st["cur"], new
+            st["left"] = count(st)
+        st["left"] -= 1
+
+    L = category(nbl_l)
+    category(1)
+    D = category(nbl_d)
+    b.put(0, 2)  # NPOSTFIX
+    b.put(0, 4)  # NDIRECT
+    mode = rng.randrange(4)
+    for _ in range(nbl_l):
+        b.put(mode, 2)  # (one context mode: the meta-block stays in the assembly loop across literal block switches)
+
+    def context_map(ntrees, size):
+        _nbltypes(b, ntrees)
+        if ntrees < 2:
+            return [0] * size
+        cmap = [rng.randrange(ntrees) for _ in range(size)]
+        b.put(0, 1)  # RLEMAX = 0
+        if ntrees <= 4:
+            simple_code(b, list(range(ntrees)), max(1, (ntrees - 1).bit_length()))
+            for c in cmap:
+                b.put(*code_bits(list(range(ntrees)), c))
+        else:
+            codes = complex_code(b, uniform_lengths(ntrees))
+            for c in cmap:
+                put_sym(b, codes, c)
+        b.put(0, 1)  # no inverse move-to-front
+        return cmap
+
+    context_map(ntl, 64 * nbl_l)
+    cmap_d = context_map(ntd, 4 * nbl_d)
+    for _ in range(ntl):
+        simple_code(b, sorted(rng.sample(range(256), 2)), 8)
+    iac = [176, 177, 178, 179]  # cell 2 (explicit distance): insert code 6, copy codes 0 .. 3 = copy lengths 2 .. 5
+    simple_code(b, iac, 10)
+    dtrees = []
+    for _ in range(ntd):
+        t = (rng.randrange(4), 16 + rng.randrange(4))  # a last-distance code, an explicit code (hcode 0 .. 3: distances 1 .. 12)
+        simple_code(b, list(t), 6)
+        dtrees.append(t)
+    ring = [4, 11, 15, 16]  # last, second-last, ...
+    pos = 40
+    for k, (ins, cpy) in enumerate(cmds):
+        b.put(*code_bits(iac, 176 + cpy - 2))
+        b.put(ins - 6, 1)
+        for _ in range(ins):
+            tick(L)
+            b.put(rng.randrange(2), 1)
+        pos += ins
+        if k == n_cmds - 1:
+            break
+        tick(D)
+        t = dtrees[cmap_d[4 * D["cur"] + min(cpy - 2, 3)]]
+        hcode = t[1] - 16
+        nbits = 1 + (hcode >> 1)
+        base = ((2 + (hcode & 1)) << nbits) - 4 + 1
+        if ring[t[0]] <= pos and (rng.randrange(2) or base + (1 << nbits) - 1 > pos):
+            b.put(*code_bits(list(t), t[0]))
+            dist = ring[t[0]]
+            if t[0] != 0:
+                ring = [dist] + ring[:3]
+        else:
+            assert base + (1 << nbits) - 1 <= pos, (k, pos, t)
+            x = rng.randrange(1 << nbits)
+            b.put(*code_bits(list(t), t[1]))
+            b.put(x, nbits)
+            dist = base + x
+            ring = [dist] + ring[:3]
+        pos += cpy
+    return b.bytes()
+
+
 def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac=False, single_dist=False):
     """A stream of ANY length in constant memory: (prefix, unit, final, unit_output).  stream = prefix + unit * K + final decodes
     to unit_output * K.  The prefix is the stream header and an empty metadata block (which pads to a byte boundary); a unit is

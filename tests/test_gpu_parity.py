@@ -6,6 +6,7 @@ import io
 import json
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -1336,6 +1337,57 @@ def test_one_symbol_insert_copy_and_distance_codes_in_the_assembly_loop(build):
         bad = [(i, e[0], int(t)) for i, (e, o, t) in enumerate(zip(exp, outs, status)) if e[0] != t or (t == 0 and o != e[1])]
         assert not bad, bad[:8]
         assert sum(1 for e in exp if e[0] != 0) > 100
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("levels", [0, 2])
+@pytest.mark.parametrize("build", [0, 1])
+def test_more_than_64_trees_of_a_kind(build, levels):
+    """Round 5: one piece of more than a megabyte out of libbrotlienc (any quality from 5 up) is ONE meta-block with 80 .. 250 literal
+    trees and dozens of block types (profiles/r05_big_trees.txt); until now more than 64 trees of a kind kept a meta-block out of the
+    assembly loop (descriptors in the 64 lanes of one register) -- 1.3 s for a 4 MiB stream.  The loop gathers the descriptors from
+    table memory now (DESC_GATHER: entry, literal / distance block switches, the tree cache's miss path).  Hand-assembled streams with
+    up to 256 literal and 256 distance trees and switching block types, sized for every kernel instance (regular .. level 3 and the
+    slab); both builds of the loop, both launch plans, cut short and with too little room; and -- where the image has libbrotlienc --
+    1 MiB and 2 MiB of text at quality 5 / 9 (78 .. 104 literal trees).  Against the oracle."""
+    import craft
+    c2 = brx_knobs.context(0, loop_build=build, levels=levels)
+    try:
+        streams, want = [], []
+        shapes = [(200, 80, 5, 25), (65, 65, 2, 17), (256, 256, 4, 64), (100, 3, 3, 1), (3, 100, 1, 30), (70, 1, 6, 1), (66, 1, 1, 1),
+                  (1, 65, 1, 20), (130, 130, 9, 40), (90, 20, 2, 5)]
+        for seed, (ntl, ntd, nl, nd) in enumerate(shapes):
+            for rep in range(2):
+                st_ = craft.many_trees_stream(100 * rep + seed, ntl, ntd, nl, nd, n_cmds=400 if rep == 0 else 1500)
+                w = oracle.decode(st_, 0, cap=1 << 16)
+                assert w[0] == 0 and len(w[1]) > 3000
+                streams += [st_] * 6
+                want += [w[1]] * 6
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
+            bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+            assert not bad, bad[:8]
+        rng = random.Random(5)
+        cuts, caps = [], []
+        for st_, w in list(zip(streams, want))[::6]:
+            for cut in sorted({len(st_) - 1, len(st_) - 3, len(st_) // 2} | {rng.randrange(60, len(st_)) for _ in range(10)}):
+                cuts.append(st_[:cut])
+                caps.append(len(w) + 8)
+            cuts.append(st_)
+            caps.append(len(w) - 1 - rng.randrange(200))
+        exp = [oracle.decode(c_, 0, cap=r_) for c_, r_ in zip(cuts, caps)]
+        outs, status, out_len = c2.decode_batch(cuts, caps)
+        bad = [(i, e[0], int(t)) for i, (e, o, t) in enumerate(zip(exp, outs, status)) if e[0] != t or (t == 0 and o != e[1])]
+        assert not bad, bad[:8]
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import brotli_enc
+        if brotli_enc.available():
+            text = (_read("lcet10.txt") + _read("plrabn12.txt") + _read("alice29.txt") + _read("asyoulik.txt")) * 2
+            big = [brotli_enc.compress(text[:size], quality=q, lgwin=22) for size, q in ((1 << 20, 5), (2 << 20, 9))]
+            outs, status, out_len = c2.decode_batch(big * 3, [(2 << 20) + 64] * 6)
+            for i, (o, t) in enumerate(zip(outs, status)):
+                assert t == 0 and o == text[:(1 << 20, 2 << 20)[i % 2]], (i, int(t))
     finally:
         c2.close()
 

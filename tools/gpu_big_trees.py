@@ -41,15 +41,23 @@ def run(streams, olen, what):
     return out
 
 
-for q in (5, 9, 10, 11):
-    st = brotli_enc.compress(src, quality=q, lgwin=24)
-    r = oracle_py.decode(st, 0, cap=len(src) + 64, want_stats=True)
-    assert r[0] == 0 and r[1] == src
-    t0 = time.time(); oracle_py.decode(st, 0, cap=len(src) + 64); cpu = time.time() - t0
-    print("quality %d: %d -> %d bytes, oracle on one host core %.1f ms; stats %s" % (q, len(src), len(st), cpu * 1e3,
-          {k: r[2][k] for k in ("meta_blocks", "commands", "literals", "block_switches") if k in r[2]}), flush=True)
-    out = run([st], len(src), "  one 4 MiB stream")
-    assert bytes(out[:len(src)].cpu().numpy().tobytes()) == src
-    run([st] * copies, len(src), "  %d copies" % copies)
-    parts = [brotli_enc.compress(src[i:i + 65536], quality=q, lgwin=24) for i in range(0, len(src), 65536)]
-    run(parts * copies, 65536, "  the same bytes as %d x 64 streams of 64 KiB" % copies)
+text = b"".join(open(os.path.join(G, t), "rb").read() for t in ("lcet10.txt", "plrabn12.txt", "alice29.txt", "asyoulik.txt")) * 3
+for name, data, sizes in (("text", text, (1 << 20, 2 << 20)), ("texts + ELF images", src, (4 << 20,))):
+    for size in sizes:
+        for q in (5, 9, 11):
+            piece = data[:size]
+            st = brotli_enc.compress(piece, quality=q, lgwin=24)
+            r = oracle_py.decode(st, 0, cap=size + 64, want_stats=True)
+            assert r[0] == 0 and r[1] == piece
+            t0 = time.time(); oracle_py.decode(st, 0, cap=size + 64); cpu = time.time() - t0
+            print("%s, %d KiB, quality %d: %d compressed bytes, oracle on one host core %.1f ms; %s" % (name, size >> 10, q, len(st), cpu * 1e3,
+                  {k: r[2][k] for k in ("meta_blocks", "commands", "literals", "block_switches") if k in r[2]}), flush=True)
+            out = run([st], size, "  one stream")
+            assert bytes(out[:size].cpu().numpy().tobytes()) == piece
+            run([st] * copies, size, "  %d copies" % copies)
+            ctx.set_option("command_loop", 6)  # every meta-block as one the assembly loop cannot take: what > 64 trees of a kind meant until round 5
+            run([st] * copies, size, "  %d copies, C++ loop (command_loop = 6)" % copies)
+            ctx.set_option("command_loop", 0)
+    if name != "text":
+        parts = [brotli_enc.compress(src[i:i + 65536], quality=9, lgwin=24) for i in range(0, len(src), 65536)]
+        run(parts * copies, 65536, "  the same bytes as %d x 64 streams of 64 KiB, quality 9" % copies)

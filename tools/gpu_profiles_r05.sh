@@ -7,7 +7,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$GRAFT_REPO_ROOT; TAG=${TAG:-r05}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-WLS="alice29x4096 text40k_lowqx4096 text64k_q11x4096 config5_1MiBx1024 gen_c5x1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192 compressed_repeatedx4096 lcet10x4096 plrabn12x4096 mapsdatazrhx4096 mixed_textx4096 mixed_allx4096 monkeyx16384 ukkonooax16384 quickfoxx16384"
+WLS="alice29x4096 text40k_lowqx4096 text64k_q11x4096 raw_256KiBx4096 config5_1MiBx1024 gen_c5x1024 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192 compressed_repeatedx4096 lcet10x4096 plrabn12x4096 mapsdatazrhx4096 mixed_textx4096 mixed_allx4096 monkeyx16384 ukkonooax16384 quickfoxx16384"
 for wl in $WLS; do
   timeout 600 python bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --no-copy-path 2>/dev/null | tail -1 > $O/bench_${TAG}_${wl}.json
 done
