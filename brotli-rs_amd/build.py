@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
+SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_l4.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
 DEPS = SOURCES + ["brx_device.h", "brx_plan.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
@@ -56,6 +56,8 @@ def _build_locked(verbose):
     for level, grow in ((1, 2560), (2, 10240), (3, 30720)):
         variants += [("brx_hot_asm_l%d.h" % level, ["-DLDS_GROW=%d" % grow], None),
                      ("brx_hot_asm_sw_l%d.h" % level, ["-DLDS_GROW=%d" % grow, "-DBRX_WIN_SGPR"], ".LS_")]
+    # level 4 (150 KiB of LDS, one workgroup per CU): the table memory last, nothing else moves with its size
+    variants += [("brx_hot_asm_l4.h", ["-DLDS_TM_LAST"], None), ("brx_hot_asm_sw_l4.h", ["-DLDS_TM_LAST", "-DBRX_WIN_SGPR"], ".LS_")]
     for name, defs, prefix in variants:
         hot = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp"] + prof + defs + [os.path.join(CSRC, "brx_hot.S")]).decode()
         assert ")BRXASM" not in hot and "%" not in hot and "{" not in hot and "$" not in hot
@@ -69,7 +71,7 @@ def _build_locked(verbose):
     # the code-length symbol loop of the header path (brx_lens.S): one asm statement WITH operands -- `@n@` in the source is
     # operand n, local labels get the statement's unique suffix
     # (LDS_LENS = offset of Lds::lens: behind the ring and the table memory; "s" = the lean instance, brx_small.h)
-    for level, lens_at in ((0, 8960), (1, 8960 + 2560), (2, 8960 + 10240), (3, 8960 + 30720), ("s", 2048 + 2048)):
+    for level, lens_at in ((0, 8960), (1, 8960 + 2560), (2, 8960 + 10240), (3, 8960 + 30720), (4, 2048), ("s", 2048 + 2048)):
         txt = subprocess.check_output(["cpp", "-P", "-x", "assembler-with-cpp", "-DLDS_LENS=%d" % lens_at,
                                        os.path.join(CSRC, "brx_lens.S")]).decode()
         assert ")BRXASM" not in txt and "%" not in txt and "{" not in txt and "$" not in txt

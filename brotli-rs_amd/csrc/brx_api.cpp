@@ -108,6 +108,7 @@ struct brx_ctx {
     hipStream_t s_wide[3] = {};                   // plan B: the wider kernels' own streams (levels 1..3)
     hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING][3] = {};
     uint32_t *d_handup = nullptr;                 // state records of the late lists: BRX_COUNTER_RING x BRX_LATE_CAP x 16 words
+    uint32_t *d_handup2 = nullptr;                // ... of the second late lists (level 3 -> level 4): BRX_COUNTER_RING x BRX_LATE2_CAP x 16 words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
     hipEvent_t ev_in[BRX_MAX_CHUNKS] = {}, ev_k[BRX_MAX_CHUNKS] = {};
@@ -185,6 +186,7 @@ static void ctx_release(brx_ctx *c) {
     if (c->h_handed) (void)hipHostFree(c->h_handed);
     (void)hipFree(c->d_defer);
     (void)hipFree(c->d_handup);
+    (void)hipFree(c->d_handup2);
     (void)hipFree(c->d_trace);
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_pool);
@@ -430,7 +432,7 @@ static int ensure_pool(brx_ctx *c, unsigned grid) {
 
 // Room for the lists of n stream indices each of every launch in flight (grown rarely: nobody may be using the old lists).
 static int ensure_defer(brx_ctx *c, uint32_t n) {
-    if (c->d_defer && c->d_handup && c->defer_cap >= n) return BRX_SUCCESS;
+    if (c->d_defer && c->d_handup && c->d_handup2 && c->defer_cap >= n) return BRX_SUCCESS;
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(c->d_defer);
     c->d_defer = nullptr;
@@ -441,6 +443,10 @@ static int ensure_defer(brx_ctx *c, uint32_t n) {
     if (!c->d_handup) { // (first: a launch must never see lists without the state records that go with them)
         e = hipMalloc(&c->d_handup, (size_t)BRX_COUNTER_RING * BRX_LATE_CAP * 16u * 4u);
         if (e != hipSuccess) { c->d_handup = nullptr; return fail(BRX_ERR_OUT_OF_MEMORY, "state-record allocation failed", e); }
+    }
+    if (!c->d_handup2) {
+        e = hipMalloc(&c->d_handup2, (size_t)BRX_COUNTER_RING * BRX_LATE2_CAP * 16u * 4u);
+        if (e != hipSuccess) { c->d_handup2 = nullptr; return fail(BRX_ERR_OUT_OF_MEMORY, "state-record allocation failed", e); }
     }
     e = hipMalloc(&c->d_defer, cap * 4u * BRX_LIST_REGIONS * BRX_COUNTER_RING); // (brx_device.h: lists 0..2, late, lean, class bytes)
     if (e != hipSuccess) { c->d_defer = nullptr; return fail(BRX_ERR_OUT_OF_MEMORY, "deferred-stream list allocation failed", e); }
@@ -499,6 +505,8 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     a.defer_cap = 0;
     a.handup = nullptr;
     a.late_cap = 0;
+    a.handup2 = nullptr;
+    a.late2_cap = 0;
     a.cls = nullptr;
     a.prepass = 0u;
     a.list_mask = 0u;
@@ -518,6 +526,8 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         a.defer_cap = (uint32_t)c->defer_cap;
         a.handup = c->d_handup + ring_slot * (size_t)BRX_LATE_CAP * 16u;
         a.late_cap = (uint32_t)std::min<size_t>(c->defer_cap, BRX_LATE_CAP);
+        a.handup2 = c->d_handup2 + ring_slot * (size_t)BRX_LATE2_CAP * 16u;
+        a.late2_cap = BRX_LATE2_CAP;
     }
     // The lean instance in front (brx_small.h; 32 waves per CU): it decodes the streams of at most BRX_SMALL_STREAM_BYTES
     // compressed bytes and lists the rest -- and what it gives up on -- for the regular kernel (BrxKernelArgs::s_list).  With a
@@ -682,6 +692,17 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         unsigned gc = std::min(n, per_cu * 4u);
         if (c->grid_cap != 0u) gc = std::min(gc, c->grid_cap);
         brx_launch_decode_l3(ac, gc, st);
+        HIP_TRY(hipGetLastError());
+        // ... and behind it level 4 (150 KiB of LDS: one workgroup per CU) for what level-3 kernels handed on -- meta-blocks whose tables
+        // spill even level 3 (one heterogeneous piece of > 1 MiB from libbrotlienc: 10 .. 35 k words).  Its workgroups leave at once
+        // when the second late list is empty.
+        BrxKernelArgs a4 = a;
+        a4.cls = nullptr;
+        a4.list_mask = 8u;
+        a4.counter_idx = 20u;
+        unsigned g4 = std::min(n, per_cu);
+        if (c->grid_cap != 0u) g4 = std::min(g4, c->grid_cap);
+        brx_launch_decode_l4(a4, g4, st);
         HIP_TRY(hipGetLastError());
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -893,7 +914,7 @@ extern "C" double brx_last_timing(brx_ctx *c, int which) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: pauses in front of one item that needed more room behind the window
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
-    if ((which >= 2 && which <= 7) || which == 10) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
+    if ((which >= 2 && which <= 7) || which == 10 || which == 11) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
                                     // (2: every stream that left the regular kernel); 5 = streams the lean instance left to the
                                     // regular kernel (large ones + given up); 6 = streams of the late list (handed up with their
                                     // state at a later meta-block); 7 = bytes decoded twice (0: every one of those was resumed)
@@ -903,6 +924,7 @@ extern "C" double brx_last_timing(brx_ctx *c, int which) {
         if (hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
         if (hipMemcpy(w, c->last_counter, 128, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
         if (which == 10) return (double)w[18]; // meta-blocks taken back after a speculative end (the stream read on past its input)
+        if (which == 11) return (double)std::min<uint32_t>(w[19], BRX_LATE2_CAP); // streams level 3 handed on to level 4
         const uint32_t late = std::min<uint32_t>(w[8], BRX_LATE_CAP);
         switch (which) {
         case 2: return (double)w[5] + w[6] + w[7] + late;

@@ -19,17 +19,25 @@
 #ifndef BRX_LEVEL
 #define BRX_LEVEL 0
 #endif
-#define BRX_LEVELS 4
+#define BRX_LEVELS 5
 #define BRX_LIST_REGIONS 6  // regions of one launch in brx_ctx::d_defer: lists 0..2, the late list, the lean kernel's list, the class bytes
 #define BRX_LATE_CAP 16384u // entries of the late list (with state records); a stream that finds it full keeps its slab
+#define BRX_LATE2_CAP 4096u // entries of the second late list (level 3 -> level 4)
 #if BRX_LEVEL == 0
 #define BRX_LDS_GROW 0u
 #elif BRX_LEVEL == 1
 #define BRX_LDS_GROW 2560u
 #elif BRX_LEVEL == 2
 #define BRX_LDS_GROW 10240u
-#else
+#elif BRX_LEVEL == 3
 #define BRX_LDS_GROW 30720u
+#else
+// Level 4 (round 5): ONE workgroup per CU, 150 KiB of LDS (gfx950 lets a workgroup declare all 160 KiB of the CU's): 37 568 words of
+// table memory for the meta-blocks libbrotlienc makes of one heterogeneous piece of more than a megabyte (80 .. 250 literal trees, dozens
+// of block types: 10 .. 35 k words of tables; profiles/r05_big_trees.txt).  Launched behind the level-3 catch-all; its only input is the
+// SECOND late list (BrxKernelArgs::handup2), which level-3 kernels fill.  Its Lds has the table memory LAST (brx_kernels.hip), so that
+// everything else keeps an offset a DS instruction's 16-bit immediate can hold.
+#define BRX_LDS_GROW 143360u
 #endif
 // A fifth, LEAN instance (brx_kernels_s.hip, BRX_SMALL): 5 120 B of LDS per wave and <= 64 VGPRs = 32 waves per CU, for
 // streams of at most BRX_SMALL_STREAM_BYTES compressed bytes (a batch of short messages, the RLE-like fills of BASELINE
@@ -143,6 +151,9 @@ struct BrxKernelArgs {
     uint32_t defer_cap;
     uint32_t *handup;       // state records of the late list, 16 words per entry, late_cap entries
     uint32_t late_cap;
+    uint32_t *handup2;      // the SECOND late list, level 3 -> level 4: state records only (the stream index is a record's word 12),
+    uint32_t late2_cap;     // count in word 19 of the counter line; word 20 = tickets of the level-4 launch.  nullptr / 0: level 3 keeps
+                            // a meta-block whose tables spill even there (slab + C++ loop, as before round 5)
     uint8_t *cls;           // plan B: per-stream class written by the pre-pass (0 = the regular kernel's), else nullptr
     uint32_t prepass;       // regular kernel only: 1 = classify (first meta-block header) and write cls / lists 0..2, decode nothing
     uint32_t list_mask;     // wider kernels: the lists this launch decodes (bit j = list j)
@@ -193,4 +204,5 @@ void brx_launch_decode(const BrxKernelArgs &args, unsigned grid, void *hip_strea
 void brx_launch_decode_l1(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // the wider instances (args.defer set)
 void brx_launch_decode_l2(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
 void brx_launch_decode_l3(const BrxKernelArgs &args, unsigned grid, void *hip_stream);
+void brx_launch_decode_l4(const BrxKernelArgs &args, unsigned grid, void *hip_stream); // (reads args.handup2 only)
 void brx_launch_decode_s(const BrxKernelArgs &args, unsigned grid, void *hip_stream);  // the lean instance (args.s_list set)

@@ -42,15 +42,27 @@
 #ifndef LDS_GROW
 #define LDS_GROW 0
 #endif
+#define RMASK 2047
+#define RING 2048
+#ifdef LDS_TM_LAST
+// level 4 (150 KiB of LDS): the table memory LAST -- the fixed areas stay within a DS instruction's 16-bit offset
+#define LDS_ITAB 2048
+#define LDS_SPARE 2304
+#define LDS_CMH 2560
+#define LDS_ST 2816
+#define LDS_MBW 3008
+#define LDS_PAD0 3200
+#define LDS_TM 3328
+#else
 #define LDS_TM 2048
 #define LDS_ST (9728+LDS_GROW)
 #define LDS_MBW (9920+LDS_GROW)
-#define RMASK 2047
-#define RING 2048
 // the code-length scratch area (Lds::lens, 768 B) is free during the command loop
 #define LDS_ITAB (8960+LDS_GROW)   // byte -> context info (filled by prepare_fast_tables)
 #define LDS_SPARE (9216+LDS_GROW)  // 12 x 4 B: the two-entry symbol lists of resident one-symbol literal trees
 #define LDS_CMH (9472+LDS_GROW)    // context id * 4 -> tree descriptor of the current literal block type (filled at entry)
+#define LDS_PAD0 (10112+LDS_GROW)
+#endif
 #define SYMOFF 68       // symbol list of a tree: after its 17 header words (brx_kernels.hip, "Table layout in table memory")
 #define INFOOFF 64      // the header's info word: kind | max_len << 8 | x << 16
 // EXEC inside the loop: lanes 0..16 only (the 16 comparator lanes of a lookup, + 1).  Everything uniform needs one lane; copies,
@@ -258,7 +270,7 @@
 // distance symbol (<= 15); every literal, every extra-bit field > 0 and the distance symbol are followed by a check.
 // (bring-up, -DBRX_PROF: cycles spent waiting for copies in flight, and how often, go to Lds::pad[10..13])
 #ifdef BRX_PROF
-#define LDS_PAD (10112+LDS_GROW)
+#define LDS_PAD LDS_PAD0
 .macro PROF_WAIT_VM
     s_waitcnt lgkmcnt(0)
     s_memtime s[16:17]

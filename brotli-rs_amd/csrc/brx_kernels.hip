@@ -61,6 +61,16 @@ struct __attribute__((aligned(16))) Lds { // the lean instance (brx_device.h): r
     u8 trash[64];                    // per-lane dump for predicated-off LDS byte stores (see ring_put)
     u32 pad[48];
 };
+#elif BRX_LEVEL >= 4
+struct __attribute__((aligned(16))) Lds { // (level 4: the table memory last -- brx_device.h; brx_hot.S, LDS_TM_LAST)
+    u8 ring[BRX_RING_BYTES];
+    u8 lens[BRX_LENS_BYTES - 512u];
+    u32 st[48];
+    u32 mbw[48];
+    u32 pad[16];
+    u8 trash[64];
+    u32 tm[BRX_TM_WORDS];
+};
 #else
 struct __attribute__((aligned(16))) Lds {
     u8 ring[BRX_RING_BYTES];
@@ -748,8 +758,10 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
 #include "_gen/brx_lens_asm_l1.h"
 #elif BRX_LEVEL == 2
 #include "_gen/brx_lens_asm_l2.h"
-#else
+#elif BRX_LEVEL == 3
 #include "_gen/brx_lens_asm_l3.h"
+#else
+#include "_gen/brx_lens_asm_l4.h"
 #endif
             : "=s"(stat), "=s"(nz_a), "=s"(i_a), "=s"(dirty_a), "+s"(win), "+s"(nav), "+s"(ww), "+s"(cbase), "+v"(cha), "+v"(chb),
               "=&v"(cur_a), "=&v"(vt0), "=&v"(vt1)
@@ -1561,8 +1573,10 @@ __device__ __noinline__ u32 asm_commands() {
 #include "_gen/brx_hot_asm_l1.h"
 #elif BRX_LEVEL == 2
 #include "_gen/brx_hot_asm_l2.h"
-#else
+#elif BRX_LEVEL == 3
 #include "_gen/brx_hot_asm_l3.h"
+#else
+#include "_gen/brx_hot_asm_l4.h"
 #endif
         :
         :
@@ -1577,8 +1591,10 @@ __device__ __noinline__ u32 asm_commands_sw() {
 #include "_gen/brx_hot_asm_sw_l1.h"
 #elif BRX_LEVEL == 2
 #include "_gen/brx_hot_asm_sw_l2.h"
-#else
+#elif BRX_LEVEL == 3
 #include "_gen/brx_hot_asm_sw_l3.h"
+#else
+#include "_gen/brx_hot_asm_sw_l4.h"
 #endif
         :
         :
@@ -2118,10 +2134,30 @@ __device__ __noinline__ void seg_finish() {
 #define BRX_KERNEL_NAME brx_decode_kernel_l2
 #define BRX_LAUNCH_NAME brx_launch_decode_l2
 #define BRX_WAVES_PER_SIMD 4
-#else
+#elif BRX_LEVEL == 3
 #define BRX_KERNEL_NAME brx_decode_kernel_l3
 #define BRX_LAUNCH_NAME brx_launch_decode_l3
 #define BRX_WAVES_PER_SIMD 4
+#else
+#define BRX_KERNEL_NAME brx_decode_kernel_l4
+#define BRX_LAUNCH_NAME brx_launch_decode_l4
+#define BRX_WAVES_PER_SIMD 4
+#endif
+// The late list a level appends to / reads: levels 0 .. 2 append to the first one (count in word 8, stream indices in region 3 of
+// `defer`), which the level-3 catch-all reads; level 3 appends to the second one (word 19, the index inside the record), level 4's input.
+#if BRX_LEVEL == 3
+#define LATE_OUT_RECS a.handup2
+#define LATE_OUT_CAP a.late2_cap
+#define LATE_OUT_CNT 19
+#else
+#define LATE_OUT_RECS a.handup
+#define LATE_OUT_CAP a.late_cap
+#define LATE_OUT_CNT 8
+#endif
+#if BRX_LEVEL == 4
+#define LATE_IN_RECS a.handup2
+#else
+#define LATE_IN_RECS a.handup
 #endif
 // ---- hand-up of a stream to a wider level (BrxKernelArgs::defer) -------------------------------------------------------
 // Table memory of the four levels in words (brx_device.h): the level a meta-block needing `need` words belongs to.
@@ -2185,6 +2221,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
     if (a.list_mask & 8u) cnt3 = rfl(__builtin_nontemporal_load(&a.work_counter[8]));
     cnt0 = cnt0 < a.defer_cap ? cnt0 : a.defer_cap; cnt1 = cnt1 < a.defer_cap ? cnt1 : a.defer_cap;
     cnt2 = cnt2 < a.defer_cap ? cnt2 : a.defer_cap; cnt3 = cnt3 < a.late_cap ? cnt3 : a.late_cap;
+#if BRX_LEVEL == 4
+    cnt0 = cnt1 = cnt2 = 0u; // (level 4 reads the second late list and nothing else)
+    cnt3 = a.handup2 != nullptr ? rfl(__builtin_nontemporal_load(&a.work_counter[19])) : 0u;
+    cnt3 = cnt3 < a.late2_cap ? cnt3 : a.late2_cap;
+#endif
     const u32 n_streams = cnt0 + cnt1 + cnt2 + cnt3;
     if (n_streams == 0u) return;
     // few streams per CU: the sparse-launch build of the loop (levels 2 / 3 never have more than 8 / 4 per CU -- and their
@@ -2270,7 +2311,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         else if (sid < cnt0 + cnt1 + cnt2) sid = rfl(a.defer[2u * (size_t)a.defer_cap + (sid - cnt0 - cnt1)]);
         else {
             late_slot = sid - cnt0 - cnt1 - cnt2;
+#if BRX_LEVEL == 4
+            sid = rfl(__builtin_nontemporal_load(&a.handup2[(size_t)late_slot * HU_WORDS + HU_SID]));
+#else
             sid = rfl(a.defer[3u * (size_t)a.defer_cap + late_slot]);
+#endif
         }
 #else
         if (sid >= a.n) sid = rfl(a.s_list[sid - a.n]);        // listed by the lean kernel
@@ -2494,7 +2539,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             // ---- resume with state (the late list): the stream was under way in a narrower kernel when the header that comes
             // next outgrew it.  Its record goes over the fresh state, the ring comes back from HBM, and the loop below starts at
             // that header.
-            const u32 *rec = a.handup + (size_t)late_slot * HU_WORDS;
+            const u32 *rec = LATE_IN_RECS + (size_t)late_slot * HU_WORDS;
             const u32 rpos = rfl(rec[HU_POS]);
             if (lane == 0u) {
                 s.st[3] = rec[HU_BITPOS]; s.st[4] = rec[HU_BITPOS + 1];
@@ -2529,8 +2574,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 if (BRX_LEVEL == 0 && a.late_only == 0u && rfl(s.st[10]) == 0u) {
                     hand = 1u;
                 } else {
-                    late_at = rdl(atomicAdd(a.work_counter + 8, lane == 0u ? 1u : 0u), 0);
-                    if (late_at < a.late_cap) hand = 2u;
+                    if (LATE_OUT_RECS != nullptr) {
+                        late_at = rdl(atomicAdd(a.work_counter + LATE_OUT_CNT, lane == 0u ? 1u : 0u), 0);
+                        if (late_at < LATE_OUT_CAP) hand = 2u;
+                    }
                 }
                 if (hand != 0u) break;
             }
@@ -2619,13 +2666,15 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 const u32 slot = rdl(atomicAdd(a.work_counter + 4 + hand_level, lane == 0u ? 1u : 0u), 0);
                 if (lane == 0u) a.defer[(size_t)(hand_level - 1u) * a.defer_cap + slot] = sid;
             } else if (lane == 0u) { // (everything decoded so far is in HBM: seg_finish above)
-                u32 *rec = a.handup + (size_t)late_at * HU_WORDS;
+                u32 *rec = LATE_OUT_RECS + (size_t)late_at * HU_WORDS;
                 rec[HU_BITPOS] = (u32)hdr_bitpos; rec[HU_BITPOS + 1] = (u32)(hdr_bitpos >> 32);
                 rec[HU_POS] = s.st[10]; rec[HU_WINDOW] = s.st[13];
                 rec[HU_DIST] = s.st[14]; rec[HU_DIST + 1] = s.st[15]; rec[HU_DIST + 2] = s.st[16]; rec[HU_DIST + 3] = s.st[17];
                 rec[HU_WD] = s.st[29]; rec[HU_WD + 1] = s.st[30];
                 rec[HU_ISLAST] = s.st[ST_ISLAST]; rec[HU_MLEN] = s.st[ST_MLEN]; rec[HU_SID] = sid;
+#if BRX_LEVEL < 3
                 a.defer[3u * (size_t)a.defer_cap + late_at] = sid;
+#endif
                 (void)atomicAdd(a.work_counter + 11, s.st[10]); // taken back by the resume: what stays was decoded twice
             }
             if (lane == 0u && a.handed_seq != nullptr) *a.handed_seq = a.launch_seq; // (pinned host word: "this context meets such streams")
