@@ -267,6 +267,10 @@ class Context:
         """Meta-blocks of the most recent launch taken back after a speculative end (the fast loop read on past the stream's input)."""
         return int(self._lib.brx_last_timing(self._h, 10))
 
+    def last_level4(self):
+        """Streams of the most recent launch that level-3 kernels handed on to the level-4 instance (tables beyond 37.6 KiB)."""
+        return int(self._lib.brx_last_timing(self._h, 11))
+
     def stream_regrown(self):
         """Slices of bounded / pulled streams of this context run again with a larger output buffer (one command beyond the slack)."""
         return int(self._lib.brx_last_timing(self._h, 9))

@@ -694,7 +694,7 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         brx_launch_decode_l3(ac, gc, st);
         HIP_TRY(hipGetLastError());
         // ... and behind it level 4 (150 KiB of LDS: one workgroup per CU) for what level-3 kernels handed on -- meta-blocks whose tables
-        // spill even level 3 (one heterogeneous piece of > 1 MiB from libbrotlienc: 10 .. 35 k words).  Its workgroups leave at once
+        // spill even level 3 (one heterogeneous piece of > 1 MiB from the reference encoder: 10 .. 35 k words).  Its workgroups leave at once
         // when the second late list is empty.
         BrxKernelArgs a4 = a;
         a4.cls = nullptr;

@@ -33,7 +33,7 @@
 #define BRX_LDS_GROW 30720u
 #else
 // Level 4 (round 5): ONE workgroup per CU, 150 KiB of LDS (gfx950 lets a workgroup declare all 160 KiB of the CU's): 37 568 words of
-// table memory for the meta-blocks libbrotlienc makes of one heterogeneous piece of more than a megabyte (80 .. 250 literal trees, dozens
+// table memory for the meta-blocks the reference encoder makes of one heterogeneous piece of more than a megabyte (80 .. 250 literal trees, dozens
 // of block types: 10 .. 35 k words of tables; profiles/r05_big_trees.txt).  Launched behind the level-3 catch-all; its only input is the
 // SECOND late list (BrxKernelArgs::handup2), which level-3 kernels fill.  Its Lds has the table memory LAST (brx_kernels.hip), so that
 // everything else keeps an offset a DS instruction's 16-bit immediate can hold.

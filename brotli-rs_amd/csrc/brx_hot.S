@@ -2284,6 +2284,12 @@
     s_sub_u32 T4, T1, 1
     s_cmp_lt_u32 T4, 2
     s_cbranch_scc1 .Lxf_upper                           // UppercaseFirst / UppercaseAll: the word's bytes are needed HERE
+    // (ONE transformed byte with nothing pending -- OmitFirst3 of a four-letter word -- would leave a single pending lane, and a literal
+    // run takes its two context bytes from the LAST TWO pending lanes (LIT_CTX_ENTRY: "a copy is at least 2 bytes long"): that one is
+    // stored straight into the ring, as the Uppercase forms are.  Found by the soak, tools/wide_fuzz.py 2 43 late.)
+    s_add_u32 T4, PFREE, CLEN
+    s_cmp_eq_u32 T4, 1
+    s_cbranch_scc1 .Lxf_upper
     // ---- identity / OmitFirstN / OmitLastN (round 5: four transformed words in five of quality-5..11 text; libbrotlienc leans on
     // the dictionary, 40 % of the commands of a 4 KiB-window stream): prefix, the used part of the word and suffix JOIN THE PENDING
     // LANES -- prefix and suffix bytes from the transform's record (SGPRs), the word's bytes by a load that nothing waits for,

@@ -1734,7 +1734,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
                   m.cml + 64u * L.nbl <= TM_BYTES && m.cmd + 4u * D.nbl <= TM_BYTES && m.cmode_w * 4u + L.nbl <= TM_BYTES &&
                   (u64)d.pos + m.mlen <= (u64)d.cap && d.bitend < (1ull << 31)) ? 1u : 0u;
         u32 why = ok ? 0u : ((m.ntl > 256u || m.ntd > 256u) ? 16u : (m.hl + total > BRX_TM_WORDS) ? 1u : 32u); // (bring-up statistics)
-        // (up to 64 trees of a kind have their descriptors in the lanes of one register; beyond -- one piece of > 1 MiB from libbrotlienc
+        // (up to 64 trees of a kind have their descriptors in the lanes of one register; beyond -- one piece of > 1 MiB from the reference encoder
         // has up to 256 literal trees -- the assembly loop gathers them from table memory: DESC_GATHER, round 5)
         for (u32 i = 0; i < total; i++) {
             const u32 h_ = ok ? tm_u32(d, s, m.hl + i) : 0u;

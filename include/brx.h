@@ -183,6 +183,8 @@ const char *brx_last_error(void);
  *            grows to hold the item
  *   10       meta-blocks of the most recent launch that were taken back and decoded again with the exact end-of-input rules because
  *            the fast loop had read on past the end of the stream's input (truncated / corrupted streams only; 0 for valid ones)
+ *   11       streams of the most recent launch that the level-3 kernels handed on to the level-4 instance (150 KiB of LDS, one per
+ *            CU: meta-blocks with more than 37.6 KiB of prefix-code tables -- one piece of several MiB from an encoder)
  */
 double brx_last_timing(brx_ctx *ctx, int which);
 

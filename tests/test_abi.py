@@ -107,7 +107,7 @@ def test_assembly_loop_passes_the_wait_state_lint():
     import sys
     # both builds of the loop, then the build-time switches kept for A/B and bring-up (serial symbol fetch; in-loop timers):
     # they have their own copies of the lookups / the literal dispatch and must keep assembling
-    for defs in ("", "BRX_WIN_SGPR", "BRX_NO_SPEC", "BRX_NO_SPEC BRX_WIN_SGPR", "BRX_PROF"):
+    for defs in ("", "BRX_WIN_SGPR", "BRX_NO_SPEC", "BRX_NO_SPEC BRX_WIN_SGPR", "BRX_PROF", "LDS_TM_LAST BRX_WIN_SGPR"):  # (the last one: level 4's layout)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_lint.py")], capture_output=True, text=True,
                            env=dict(os.environ, ASM_DEFS=defs))
         assert r.returncode == 0, r.stdout + r.stderr

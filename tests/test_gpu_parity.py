@@ -1341,6 +1341,38 @@ def test_one_symbol_insert_copy_and_distance_codes_in_the_assembly_loop(build):
         c2.close()
 
 
+@pytest.mark.parametrize("build", [0, 1])
+def test_one_byte_transformed_word_in_front_of_context_modelled_literals(build):
+    """Round 5's own bug, found by the soak (tools/wide_fuzz.py 2 43 late) a few commits after it went in: transformed dictionary words
+    join the pending lanes since 4fac7e1, and OmitFirst3 / OmitFirst6 of a four-letter word is ONE byte -- with nothing else pending
+    that left a single pending lane, while a literal run takes its two context bytes from the LAST TWO pending lanes ("a copy is at
+    least 2 bytes long"): wrong context, wrong tree, a stream that went its own way from output byte 10 730 on (here a corrupted
+    stream that ends in error 9 after 22 702 bytes; the decoder said error 6 after 10 990).  The stream as the fuzzer made it."""
+    s_ = open(os.path.join(GOLDEN, "regress_xf1", "omitfirst_one_byte_a.compressed"), "rb").read()
+    want = oracle.decode(s_, 0, cap=1 << 21)
+    assert want[0] == 9 and len(want[1]) == 22702
+    c2 = brx_knobs.context(0, loop_build=build)
+    try:
+        import torch
+        dev = torch.device("cuda:0")
+        n, cap = 24, 1 << 16
+        blob = torch.frombuffer(bytearray(s_), dtype=torch.uint8).to(dev).repeat(n).contiguous()
+        in_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * len(s_)).contiguous()
+        out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * cap + torch.arange(n + 1, dtype=torch.int64, device=dev) % 16).contiguous()
+        out = torch.zeros(int(out_off[-1].item()) + 64, dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        c2.decode_batch_device(blob.data_ptr(), in_off.data_ptr(), n, out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), status.data_ptr())
+        c2.synchronize()
+        assert status.tolist() == [9] * n and out_len.tolist() == [22702] * n, (status.tolist(), out_len.tolist())
+        host = out.cpu().numpy()
+        for i in range(n):
+            o0 = int(out_off[i].item())
+            assert host[o0:o0 + 22702].tobytes() == want[1], i  # (the bytes decoded before the error are the reference's, too)
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("levels", [0, 2])
 @pytest.mark.parametrize("build", [0, 1])
 def test_more_than_64_trees_of_a_kind(build, levels):
@@ -1368,6 +1400,7 @@ def test_more_than_64_trees_of_a_kind(build, levels):
             outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
             bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
             assert not bad, bad[:8]
+            assert c2.last_level4() == 12, c2.last_level4()  # (the two streams with 256 + 256 trees, six copies each: ~9.7 k words of tables)
         rng = random.Random(5)
         cuts, caps = [], []
         for st_, w in list(zip(streams, want))[::6]:
@@ -1388,6 +1421,16 @@ def test_more_than_64_trees_of_a_kind(build, levels):
             outs, status, out_len = c2.decode_batch(big * 3, [(2 << 20) + 64] * 6)
             for i, (o, t) in enumerate(zip(outs, status)):
                 assert t == 0 and o == text[:(1 << 20, 2 << 20)[i % 2]], (i, int(t))
+            # 2 MiB of an ELF image: ~13 k words of tables -> listed for level 3, handed on to level 4 from its start
+            elf = open(sys.executable, "rb").read()[:2 << 20]
+            if len(elf) == 2 << 20:
+                big = [brotli_enc.compress(elf, quality=q, lgwin=22) for q in (5, 9)]
+                for b_ in big:
+                    assert oracle.decode(b_, 0, cap=len(elf) + 64)[1] == elf
+                outs, status, out_len = c2.decode_batch(big * 2, [len(elf) + 64] * 4)
+                for i, (o, t) in enumerate(zip(outs, status)):
+                    assert t == 0 and o == elf, (i, int(t))
+                assert c2.last_level4() == 4, c2.last_level4()
     finally:
         c2.close()
 
