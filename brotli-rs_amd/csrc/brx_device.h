@@ -5,7 +5,7 @@
 // Geometry of one decoder wave.  One workgroup = one 64-lane wavefront = one stream at a time.
 #define BRX_WAVE 64
 #define BRX_RING_BYTES 2048u     // LDS sliding-window ring: last 2 KiB of the stream's output
-// Four instances of the kernel, one source (brx_kernels.hip; brx_kernels_l1/l2/l3.hip set BRX_LEVEL): the regular one with
+// Four instances of the kernel (five with level 4, below), one source (brx_kernels.hip; brx_kernels_l1/l2/l3/l4.hip set BRX_LEVEL): the regular one with
 // 10 KiB of LDS per wave (16 streams per CU) and three wider ones for streams whose meta-block tables do not fit its table
 // memory (real text at high quality: lcet10.txt needs 2 208 words, 800 KB of text at quality 11 ~5 000):
 //   level   LDS per wave   table memory          streams per CU
@@ -13,9 +13,10 @@
 //     1       12 800 B      2 368 words            12
 //     2       20 480 B      4 288 words             8
 //     3       40 960 B      9 408 words             4
+//     4      153 600 B     37 568 words             1      (round 5; fed by level 3 only)
 // (sizes are multiples of 1 280 B so that the waves of a CU fill its 160 KiB whatever the allocation granule.)  A wave that
 // finds a stream spilling its level's table memory drops it and lists it for the level that holds its tables
-// (BrxKernelArgs::defer, no host round trip).  Beyond level 3: the spill slabs.
+// (BrxKernelArgs::defer, no host round trip).  Beyond level 4: the spill slabs.
 #ifndef BRX_LEVEL
 #define BRX_LEVEL 0
 #endif

@@ -2113,8 +2113,8 @@ __device__ __noinline__ void seg_finish() {
 // between the out-of-line segments.  Keeping it this small is what lets every segment have its own register
 // allocation (nothing but `a`, `sid` and &s is live across the calls).
 //
-// Four instances of this file (BRX_LEVEL, brx_device.h): the regular kernel (10 KiB of LDS per wave, 16 waves per CU) and
-// three wider ones (12.5 / 20 / 40 KiB: 12 / 8 / 4 waves per CU).  A stream whose meta-block tables spill the table memory
+// Five instances of this file (BRX_LEVEL, brx_device.h): the regular kernel (10 KiB of LDS per wave, 16 waves per CU),
+// three wider ones (12.5 / 20 / 40 KiB: 12 / 8 / 4 waves per CU) and, since round 5, level 4 (150 KiB, one per CU; fed by level 3 only).  A stream whose meta-block tables spill the table memory
 // would run that meta-block in the C++ loop against tables in HBM (lcet10.txt: 8 x slower than its neighbours); with a.defer
 // set a kernel instead drops such a stream at the first spill and lists it for the next level, whose kernel -- launched
 // right behind on the same HIP stream, no host round trip -- decodes the listed streams from their start.
@@ -2160,7 +2160,8 @@ __device__ __noinline__ void seg_finish() {
 #define LATE_IN_RECS a.handup
 #endif
 // ---- hand-up of a stream to a wider level (BrxKernelArgs::defer) -------------------------------------------------------
-// Table memory of the four levels in words (brx_device.h): the level a meta-block needing `need` words belongs to.
+// Table memory of levels 0 .. 3 in words (brx_device.h): the level a meta-block needing `need` words is LISTED for (level 4 is
+// reached from level 3 only, through the second late list).
 FI u32 level_for(u32 need) {
     return need <= 1728u + 2560u / 4u ? 1u : need <= 1728u + 10240u / 4u ? 2u : 3u;
 }

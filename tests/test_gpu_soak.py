@@ -28,6 +28,9 @@ SECTIONS += [({p: "1"}, "device_fuzz", ["3", "302"]) for p in PLANS]
 SECTIONS += [({"BRX_LOOP_BUILD": str(b)}, "wide_fuzz", ["1", "45"]) for b in (0, 1)]
 SECTIONS += [({"BRX_LOOP_BUILD": str(b)}, "gen_fuzz", ["2", "46"]) for b in (0, 1)]
 SECTIONS += [({"BRX_GRID_CAP": "64"}, "wide_fuzz", ["2", "47"])]  # a pool of 64 slabs under corrupted wide streams: a slab not given back stalls this
+# round 5: every tenth stream ONE piece of 1.2 .. 2.5 MiB of text + an ELF image -- more than 64 trees of a kind, tables for the level-4
+# instance -- and their corrupted / truncated variants, under both plans
+SECTIONS += [({p: "1"}, "wide_fuzz", ["1", "611", "big"]) for p in PLANS]
 SECTIONS += [({"BRX_DEBUG_STOP": "8"}, "big_fuzz", ["1", "48"])]  # the C++ command loops only (the safety net of the assembly loop)
 
 

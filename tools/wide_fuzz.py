@@ -22,6 +22,9 @@ G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 LATE = len(sys.argv) > 3 and sys.argv[3] == "late"
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # "big": every tenth stream ONE piece of 1.2 .. 2.5 MiB of text + an ELF image (80 .. 250
+                                                  # literal trees, 10 .. 25 k words of tables: the level-4 instance, DESC_GATHER)
+elf = open(sys.executable, "rb").read()
 texts = [open(os.path.join(G, f), "rb").read() for f in ("lcet10.txt", "plrabn12.txt", "alice29.txt", "asyoulik.txt", "mapsdatazrh")]
 corpus = b"".join(texts)
 assert brotli_enc.available()
@@ -34,6 +37,11 @@ for r in range(rounds):
             o = rng.randrange(len(corpus) - 20000)
             data = corpus[o:o + rng.randrange(1, 20000)]
             q = rng.randrange(0, 12)
+        elif BIG and it % 10 == 1:
+            a_, b_ = rng.randrange(200000, 900000), rng.randrange(900000, 1700000)
+            o1, o2 = rng.randrange(len(corpus) - a_), rng.randrange(max(1, len(elf) - b_))
+            data = corpus[o1:o1 + a_] + elf[o2:o2 + b_] if rng.random() < 0.7 else elf[o2:o2 + b_] + corpus[o1:o1 + a_]
+            q = rng.choice([5, 9, 10, 11])
         else:
             n = rng.randrange(150000, len(corpus) if it % 10 == 0 else 600000)
             o = rng.randrange(len(corpus) - n + 1)
@@ -48,7 +56,7 @@ for r in range(rounds):
         datas.append(data)
     caps = [len(x) + rng.randrange(0, 40) for x in datas]
     outs, status, out_len = ctx.decode_batch(streams, caps)
-    wide = [ctx.last_wide_streams(k) for k in (1, 2, 3)] + ["late %d" % ctx.last_late_streams()]
+    wide = [ctx.last_wide_streams(k) for k in (1, 2, 3)] + ["late %d" % ctx.last_late_streams(), "level 4: %d" % ctx.last_level4()]
     for i, (d, o, st) in enumerate(zip(datas, outs, status)):
         if st != 0 or o != d:
             bad += 1
@@ -62,8 +70,9 @@ for r in range(rounds):
         else:
             s = s[:rng.randrange(1, len(s) + 1)]
         cs.append(bytes(s))
-    exp = [oracle_py.decode(s, cap=1 << 21) for s in cs]
-    outs, status, out_len = ctx.decode_batch(cs, [1 << 21] * len(cs))
+    CAP = 1 << 22 if BIG else 1 << 21
+    exp = [oracle_py.decode(s, cap=CAP) for s in cs]
+    outs, status, out_len = ctx.decode_batch(cs, [CAP] * len(cs))
     wide2 = [ctx.last_wide_streams(k) for k in (1, 2, 3)]
     for i, (e, o, st) in enumerate(zip(exp, outs, status)):
         if int(st) != e[0] or (e[0] == 0 and o != e[1]):
