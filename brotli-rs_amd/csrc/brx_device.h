@@ -135,7 +135,9 @@ struct BrxKernelArgs {
                             // [12] / [13] pre-pass: sizes (units of 64 B) / number of the streams that stay with the regular kernel,
                             // [14] plan B: workgroups of the wider kernels that have started, [15] lean kernel: sizes of the streams
                             // it listed (units of 64 B), [16] / [17] the largest of those sizes / 0xfffff - the smallest (lean
-                            // kernel and pre-pass: which walks over an oversubscribed queue can have members at all)
+                            // kernel and pre-pass: which walks over an oversubscribed queue can have members at all), [18] meta-blocks
+                            // taken back after a speculative end, [19] entries of the second late list (level 3 -> 4), [20] tickets
+                            // of the level-4 launch
     // Streams whose meta-block tables spill a kernel's LDS table memory are not decoded there: they are LISTED for the level
     // whose table memory holds them (the need is known exactly once the header is parsed) and decoded by that level's kernel.
     //   lists 0..2 (region j of `defer`): streams of level j + 1 that have produced no output yet -- decoded from their start;
