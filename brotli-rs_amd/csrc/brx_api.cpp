@@ -108,6 +108,7 @@ struct brx_ctx {
     hipStream_t s_wide[3] = {};                   // plan B: the wider kernels' own streams (levels 1..3)
     hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING][3] = {};
     uint32_t *d_handup = nullptr;                 // state records of the late lists: BRX_COUNTER_RING x BRX_LATE_CAP x 16 words
+    bool level4 = true;                           // BRX_OPTION_LEVEL4: the level-4 launch behind every batch launch
     uint32_t *d_handup2 = nullptr;                // ... of the second late lists (level 3 -> level 4): BRX_COUNTER_RING x BRX_LATE2_CAP x 16 words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
@@ -362,6 +363,7 @@ extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
     case BRX_OPTION_GRID_CAP: c->grid_cap = (unsigned)std::max<int64_t>(value, 0); break;
     case BRX_OPTION_SMALL_BYTES: c->small_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), BRX_SMALL_MAX_BYTES); break;
     case BRX_OPTION_TRACE: c->trace_on = value != 0; break;
+    case BRX_OPTION_LEVEL4: c->level4 = value != 0; break;
     case BRX_OPTION_READER_WINDOW:
         if (value < (1 << 20) || value > (256 << 20)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: reader window is 1 MiB .. 256 MiB");
         c->reader_window = ((size_t)value + 65535u) & ~(size_t)65535;
@@ -526,8 +528,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         a.defer_cap = (uint32_t)c->defer_cap;
         a.handup = c->d_handup + ring_slot * (size_t)BRX_LATE_CAP * 16u;
         a.late_cap = (uint32_t)std::min<size_t>(c->defer_cap, BRX_LATE_CAP);
-        a.handup2 = c->d_handup2 + ring_slot * (size_t)BRX_LATE2_CAP * 16u;
-        a.late2_cap = BRX_LATE2_CAP;
+        if (c->level4) { // (without it level 3 keeps what spills it: BrxKernelArgs::handup2)
+            a.handup2 = c->d_handup2 + ring_slot * (size_t)BRX_LATE2_CAP * 16u;
+            a.late2_cap = BRX_LATE2_CAP;
+        }
     }
     // The lean instance in front (brx_small.h; 32 waves per CU): it decodes the streams of at most BRX_SMALL_STREAM_BYTES
     // compressed bytes and lists the rest -- and what it gives up on -- for the regular kernel (BrxKernelArgs::s_list).  With a
@@ -696,14 +700,16 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
         // ... and behind it level 4 (150 KiB of LDS: one workgroup per CU) for what level-3 kernels handed on -- meta-blocks whose tables
         // spill even level 3 (one heterogeneous piece of > 1 MiB from the reference encoder: 10 .. 35 k words).  Its workgroups leave at once
         // when the second late list is empty.
-        BrxKernelArgs a4 = a;
-        a4.cls = nullptr;
-        a4.list_mask = 8u;
-        a4.counter_idx = 20u;
-        unsigned g4 = std::min(n, per_cu);
-        if (c->grid_cap != 0u) g4 = std::min(g4, c->grid_cap);
-        brx_launch_decode_l4(a4, g4, st);
-        HIP_TRY(hipGetLastError());
+        if (c->level4) {
+            BrxKernelArgs a4 = a;
+            a4.cls = nullptr;
+            a4.list_mask = 8u;
+            a4.counter_idx = 20u;
+            unsigned g4 = std::min(n, per_cu);
+            if (c->grid_cap != 0u) g4 = std::min(g4, c->grid_cap);
+            brx_launch_decode_l4(a4, g4, st);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));

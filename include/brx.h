@@ -138,8 +138,13 @@ enum {
                                      500; 0 = no lean instance) */
     BRX_OPTION_SMALL_WAVES = 10,  /* waves per CU of the lean instance's grid (default 32) */
     BRX_OPTION_TRACE = 11,        /* 1 = every launch records when and where each stream was decoded (brx_last_trace); default 0 */
-    BRX_OPTION_READER_WINDOW = 12 /* compressed bytes a bounded / pulled stream keeps resident on the device (default 8 MiB; 1 .. 256
+    BRX_OPTION_READER_WINDOW = 12, /* compressed bytes a bounded / pulled stream keeps resident on the device (default 8 MiB; 1 .. 256
                                      MiB): streams started afterwards */
+    BRX_OPTION_LEVEL4 = 13        /* 1 = behind every batch launch one more (usually empty, 4 us) launch of the level-4 instance -- 150 KiB
+                                     of LDS, one per CU -- takes the streams whose prefix-code tables spill even level 3 (pieces of several
+                                     MiB compressed in one go) (default); 0 = no such launch: those meta-blocks run in the C++ loop from a
+                                     slab (~3 MB/s per stream).  For callers whose batches are tens of microseconds long and never hold
+                                     such streams */
 };
 int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
 

@@ -9,7 +9,7 @@ from brotli_rs_amd import brx
 ENV = {"BRX_DEBUG_STOP": ("command_loop", None), "BRX_LOOP_BUILD": ("loop_build", None), "BRX_NO_ORDER": ("queue_order", 0),
        "BRX_NO_DEFER": ("hand_up", 0), "BRX_PLAN_A": ("levels", 0), "BRX_PLAN_B": ("levels", 2),
        "BRX_TINY_BYTES": ("tiny_bytes", None), "BRX_NO_MIRROR": ("host_in_place", 0), "BRX_GRID_CAP": ("grid_cap", None),
-       "BRX_SMALL_BYTES": ("small_bytes", None), "BRX_SMALL_WAVES": ("small_waves", None)}
+       "BRX_SMALL_BYTES": ("small_bytes", None), "BRX_SMALL_WAVES": ("small_waves", None), "BRX_NO_LEVEL4": ("level4", 0)}
 
 
 def options_from_env():

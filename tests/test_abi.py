@@ -24,8 +24,8 @@ def test_library_builds_for_gfx950():
     blob = open(path, "rb").read()
     assert b"gfx950" in blob  # the code object targets MI355X
     assert b"brx_decode_kernel" in blob
-    # the three wider-LDS instances of the kernel (brx_device.h, BRX_LEVEL) travel in the same library
-    for k in (1, 2, 3):
+    # the wider-LDS instances of the kernel (brx_device.h, BRX_LEVEL) travel in the same library
+    for k in (1, 2, 3, 4):
         assert b"brx_decode_kernel_l%d" % k in blob
     assert b"brx_decode_kernel_s" in blob  # ... and the lean instance for short streams (brx_small.h)
 
@@ -122,5 +122,5 @@ def test_python_option_numbers_are_the_header_s():
     """brx.OPTIONS (ctypes side) names exactly the BRX_OPTION_* values of include/brx.h."""
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "brx.h")).read()
-    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"^\s+BRX_OPTION_([A-Z_]+)\s*=\s*(\d+),?\s", hdr, flags=re.M)}
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"^\s+BRX_OPTION_([A-Z0-9_]+)\s*=\s*(\d+),?\s", hdr, flags=re.M)}
     assert enum == brx.OPTIONS, (enum, brx.OPTIONS)

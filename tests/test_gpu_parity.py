@@ -1401,6 +1401,11 @@ def test_more_than_64_trees_of_a_kind(build, levels):
             bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
             assert not bad, bad[:8]
             assert c2.last_level4() == 12, c2.last_level4()  # (the two streams with 256 + 256 trees, six copies each: ~9.7 k words of tables)
+        c2.set_option("level4", 0)  # (BRX_OPTION_LEVEL4 = 0: no level-4 launch -- level 3 keeps them: slab + C++ loop, the same bytes)
+        outs, status, out_len = c2.decode_batch(streams, [len(w) + 1 + i % 16 for i, w in enumerate(want)])
+        bad = [(i, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+        assert not bad and c2.last_level4() == 0, (bad[:8], c2.last_level4())
+        c2.set_option("level4", 1)
         rng = random.Random(5)
         cuts, caps = [], []
         for st_, w in list(zip(streams, want))[::6]:
