@@ -15,6 +15,10 @@ for SEED in ${1:-101 102}; do
       env $env timeout 900 python tools/$1.py $2 $3 ${4:-} 2>&1 | grep -i "mismatch" | tail -3 >> $O
     done
   done
+  for env in BRX_PLAN_A=1 BRX_PLAN_B=1; do  # pieces of 1.2 .. 2.5 MiB (more than 64 trees of a kind, the level-4 instance)
+    echo "== $env wide_fuzz 1 $SEED big" >> $O
+    env $env timeout 900 python tools/wide_fuzz.py 1 $SEED big 2>&1 | grep -i "mismatch" | tail -3 >> $O
+  done
   echo "== BRX_GRID_CAP=64 wide_fuzz 2 $SEED" >> $O
   BRX_GRID_CAP=64 timeout 900 python tools/wide_fuzz.py 2 $SEED 2>&1 | grep -i "mismatch" | tail -3 >> $O
 done
