@@ -164,3 +164,14 @@ def test_crafted_context_mode_streams(mode):
             for flags in (0, oracle.FLAG_TREE_WALK):
                 st, out = oracle.decode(stream, flags=flags)[:2]
                 assert st == 0 and out == expect, (mode, seed, n, flags)
+
+
+def test_regression_stream_of_round_5_on_the_oracle():
+    """tests/golden/regress_xf1 (a corrupted libbrotlienc stream the round-5 soak made): one-byte results of OmitFirst3 / OmitFirst6 on
+    four-letter dictionary words in front of context-modelled literals, then error 9 (invalid transform id) after 22 702 bytes -- the
+    expectation the GPU regression test holds the HIP path to, pinned here in both lookup modes."""
+    import hashlib
+    s = open(os.path.join(GOLDEN, "regress_xf1", "omitfirst_one_byte_a.compressed"), "rb").read()
+    for flags in (0, oracle.FLAG_TREE_WALK):
+        st, out = oracle.decode(s, flags=flags, cap=1 << 21)[:2]
+        assert st == 9 and len(out) == 22702 and hashlib.sha256(out).hexdigest().startswith("9d1a9b7d92948510")
