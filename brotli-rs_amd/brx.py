@@ -32,6 +32,11 @@ class _Opts(ctypes.Structure):
     _fields_ = [("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("hip_stream", ctypes.c_void_p)]
 
 
+class _NodeOpts(ctypes.Structure):  # brx_node_opts
+    _fields_ = [("flags", ctypes.c_uint32), ("deal", ctypes.c_uint32), ("use_gpus", ctypes.c_int32), ("root", ctypes.c_int32),
+                ("hip_stream", ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -90,6 +95,23 @@ def load_library():
     L.brx_host_alloc.argtypes = [ctypes.c_size_t]
     L.brx_host_free.restype = None
     L.brx_host_free.argtypes = [ctypes.c_void_p]
+    L.brx_node_create.restype = ctypes.c_int
+    L.brx_node_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    L.brx_node_destroy.restype = None
+    L.brx_node_destroy.argtypes = [ctypes.c_void_p]
+    L.brx_node_size.restype = ctypes.c_int
+    L.brx_node_size.argtypes = [ctypes.c_void_p]
+    L.brx_node_ctx.restype = ctypes.c_void_p
+    L.brx_node_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.brx_node_set_option.restype = ctypes.c_int
+    L.brx_node_set_option.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64]
+    L.brx_node_decode_batch.restype = ctypes.c_int
+    L.brx_node_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(_NodeOpts)]
+    L.brx_node_deal.restype = ctypes.c_int
+    L.brx_node_deal.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    L.brx_node_last_timing.restype = ctypes.c_double
+    L.brx_node_last_timing.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     _lib = L
     return L
 
@@ -99,7 +121,8 @@ READ_FN = ctypes.CFUNCTYPE(ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctyp
 EXPORTED_SYMBOLS = ["brx_ctx_create", "brx_ctx_destroy", "brx_decode_batch", "brx_status_str", "brx_last_error",
                     "brx_last_timing", "brx_synchronize", "brx_stream_new", "brx_stream_read", "brx_stream_free",
                     "brx_host_alloc", "brx_host_free", "brx_stream_new_bounded", "brx_generate_batch", "brx_compact_batch",
-                    "brx_ctx_set_option", "brx_last_trace", "brx_stream_new_reader"]
+                    "brx_ctx_set_option", "brx_last_trace", "brx_stream_new_reader", "brx_node_create", "brx_node_destroy",
+                    "brx_node_size", "brx_node_ctx", "brx_node_set_option", "brx_node_decode_batch", "brx_node_last_timing", "brx_node_deal"]
 
 
 def status_str(code: int) -> str:
@@ -271,6 +294,14 @@ class Context:
         """Streams of the most recent launch that level-3 kernels handed on to the level-4 instance (tables beyond 37.6 KiB)."""
         return int(self._lib.brx_last_timing(self._h, 11))
 
+    def slab_waits(self):
+        """Waves that ever had to wait for a spill slab on this context (0 by construction since round 6: brx_last_timing 12)."""
+        return int(self._lib.brx_last_timing(self._h, 12))
+
+    def pool_slabs(self):
+        """Slabs of the context's spill pool right now (brx_last_timing 13)."""
+        return int(self._lib.brx_last_timing(self._h, 13))
+
     def stream_regrown(self):
         """Slices of bounded / pulled streams of this context run again with a larger output buffer (one command beyond the slack)."""
         return int(self._lib.brx_last_timing(self._h, 9))
@@ -294,6 +325,115 @@ class Context:
                 cap = max(cap * 4, int(ln[0]))
                 continue
             return int(st[0]), outs[0]
+
+
+DEALS = {"ranges": 0, "bytes": 1, "snake": 2}
+NODE_OPTIONS = {"transport": 100, "min_streams": 101, "exchange_root": 102}
+
+
+def node_deal(sizes, gpus, deal="ranges"):
+    """brx_node_deal: (order np.uint32[n], cut np.uint32[gpus + 1]) for streams of the given compressed sizes.  No GPU needed."""
+    L = load_library()
+    n = len(sizes)
+    in_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(sizes, dtype=np.uint64), out=in_off[1:])
+    order = np.zeros(max(n, 1), dtype=np.uint32)
+    cut = np.zeros(gpus + 1, dtype=np.uint32)
+    rc = L.brx_node_deal(in_off.ctypes.data, n, gpus, DEALS[deal], order.ctypes.data, cut.ctypes.data)
+    if rc != 0:
+        raise BrxError("brx_node_deal failed (%d): %s" % (rc, L.brx_last_error().decode()))
+    return order[:n], cut
+
+
+class Node:
+    """brx_node: the GPUs of one machine behind one call (one process, one context and one host thread per GPU).  `devices`: HIP
+    device index per rank (None = every visible GPU); a device may appear more than once -- "virtual ranks", the same code on one GPU."""
+
+    def __init__(self, devices=None, options=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices) if devices else None
+        rc = self._lib.brx_node_create(ctypes.byref(self._h), arr, len(devices) if devices else 0)
+        if rc != 0:
+            raise BrxError("brx_node_create failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    @property
+    def size(self):
+        return int(self._lib.brx_node_size(self._h))
+
+    def set_option(self, name, value):
+        opt = NODE_OPTIONS[name] if name in NODE_OPTIONS else OPTIONS[name]
+        rc = self._lib.brx_node_set_option(self._h, opt, int(value))
+        if rc != 0:
+            raise BrxError("brx_node_set_option(%s) failed (%d): %s" % (name, rc, self._lib.brx_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.brx_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _opts(self, flags, deal, use_gpus, root, hip_stream, timing):
+        return _NodeOpts(flags | (OPT_TIMING if timing else 0), DEALS[deal], int(use_gpus), int(root), hip_stream)
+
+    def decode_batch(self, streams, capacities, deal="ranges", use_gpus=0, timing=False, raw=False):
+        """As Context.decode_batch, over the node (host pointers: every GPU reads / writes the caller's buffers itself).  raw=True:
+        outputs are the slots' bytes up to min(out_len, capacity) whatever the status (the bytes in front of an error)."""
+        n = len(streams)
+        if isinstance(capacities, int):
+            capacities = [capacities] * n
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in streams], out=in_off[1:])
+        np.cumsum(capacities, out=out_off[1:])
+        blob = np.frombuffer(b"".join(streams), dtype=np.uint8) if in_off[-1] else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(max(int(out_off[-1]), 1), dtype=np.uint8)
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.full(max(n, 1), -1, dtype=np.int32)
+        opts = self._opts(MEM_HOST, deal, use_gpus, 0, None, timing)
+        rc = self._lib.brx_node_decode_batch(self._h, blob.ctypes.data, in_off.ctypes.data, n, out.ctypes.data, out_off.ctypes.data,
+                                             out_len.ctypes.data, status.ctypes.data, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_node_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        outs = []
+        for i in range(n):
+            ln = min(int(out_len[i]), int(capacities[i])) if (raw or status[i] == OK) else 0
+            outs.append(out[int(out_off[i]):int(out_off[i]) + ln].tobytes())
+        return outs, status[:n], out_len[:n]
+
+    def decode_batch_host_raw(self, in_ptr, in_off, n, out_ptr, out_off, deal="ranges", use_gpus=0, timing=False):
+        """Host pointers as they are (e.g. pinned buffers from host_alloc(): used in place by every GPU).  Returns (status, out_len)."""
+        out_len = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.full(max(n, 1), -1, dtype=np.int32)
+        opts = self._opts(MEM_HOST, deal, use_gpus, 0, None, timing)
+        rc = self._lib.brx_node_decode_batch(self._h, in_ptr, in_off.ctypes.data, n, out_ptr, out_off.ctypes.data,
+                                             out_len.ctypes.data, status.ctypes.data, ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_node_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+        return status[:n], out_len[:n]
+
+    def decode_batch_device(self, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr, deal="ranges", use_gpus=0,
+                            root=0, hip_stream=None, timing=False):
+        """Every pointer is memory of the root rank's GPU: scatter over xGMI, decode everywhere, ragged gather.  Returns when done."""
+        opts = self._opts(MEM_DEVICE, deal, use_gpus, root, hip_stream, timing)
+        rc = self._lib.brx_node_decode_batch(self._h, in_ptr, in_off_ptr, n, out_ptr, out_off_ptr, out_len_ptr, status_ptr,
+                                             ctypes.byref(opts))
+        if rc != 0:
+            raise BrxError("brx_node_decode_batch failed (%d): %s" % (rc, self._lib.brx_last_error().decode()))
+
+    def last(self):
+        """Of the most recent batch: {gpus, streams[], in_bytes[], kernel_ms[], wall_ms, scatter_ms, rccl}."""
+        t = lambda which, rank=0: float(self._lib.brx_node_last_timing(self._h, which, rank))  # noqa: E731
+        g = int(t(0))
+        return {"gpus": g, "streams": [int(t(1, r)) for r in range(g)], "in_bytes": [int(t(2, r)) for r in range(g)],
+                "kernel_ms": [t(3, r) for r in range(g)], "wall_ms": t(4), "scatter_ms": t(5), "rccl": bool(t(6))}
 
 
 def host_alloc(nbytes):

@@ -9,8 +9,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_PATH = os.path.join(PKG, "libbrx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_l4.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp"]
-DEPS = SOURCES + ["brx_device.h", "brx_plan.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
+SOURCES = ["brx_kernels.hip", "brx_kernels_l1.hip", "brx_kernels_l2.hip", "brx_kernels_l3.hip", "brx_kernels_l4.hip", "brx_kernels_s.hip", "brx_gen.hip", "brx_util.hip", "brx_api.cpp", "brx_node.cpp"]
+DEPS = SOURCES + ["brx_device.h", "brx_internal.h", "brx_plan.h", "brx_small.h", "brx_hot.S", "brx_lens.S", os.path.join("..", "host", "brx_walk.cpp"), os.path.join("..", "..", "include", "brx.h"),
                   os.path.join("..", "tables", "dictionary.bin"), os.path.join("..", "tables", "context_lut.bin"),
                   os.path.join("..", "tables", "transforms.bin"), os.path.join("..", "tables", "gen_header.bin"), os.path.join("..", "build.py")]
 
@@ -84,7 +84,7 @@ def _build_locked(verbose):
         cmd.append("-DBRX_BRINGUP")  # bring-up: BRX_DEBUG_STATS / BRX_DEBUG_STOP=9 + BRX_DEBUG_DUMP (tools/gpu_dumps.sh, tools/span_stats.py)
     cmd += extra + [os.path.join(CSRC, s) for s in SOURCES]
     tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
-    cmd += ["-o", tmp]
+    cmd += ["-ldl", "-lpthread", "-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -25,6 +25,7 @@
 #include "../../include/brx.h"
 #include "_gen/brx_tables_gen.h" // BRX_DICT, BRX_CONTEXT_LUT, BRX_TRANSFORMS  (tools/bin2h.py from tables/*.bin)
 #include "brx_device.h"
+#include "brx_internal.h"
 #include "brx_plan.h"
 
 static thread_local std::string g_err;
@@ -93,7 +94,8 @@ struct brx_ctx {
     uint32_t small_waves_per_cu = 32;              // grid of the lean instance (A/B)
     // spill-slab pool: slabs are claimed by waves (atomic bitmap), sized lazily by the largest grid seen
     BrxSlabPool *d_pool = nullptr; // device copy of `pool`
-    BrxSlabPool pool = {nullptr, nullptr, 0, nullptr};
+    BrxSlabPool pool = {nullptr, nullptr, 0, nullptr, nullptr};
+    uint64_t slab_waits = 0; // of pools this context had before (brx_last_timing 12 adds the current pool's word)
     unsigned max_grid = 0;
     unsigned grid_cap = 0;
     bool force_plan_b = false;                    // BRX_OPTION_LEVELS 2: plan B (classification pre-pass, all levels next to each other) on every launch (A/B)
@@ -112,6 +114,11 @@ struct brx_ctx {
     uint32_t *d_handup2 = nullptr;                // ... of the second late lists (level 3 -> level 4): BRX_COUNTER_RING x BRX_LATE2_CAP x 16 words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
+    // Slab accounting (round 6): the pool always has at least as many slabs as the launches IN FLIGHT on this context have waves
+    // that can claim one, so a wave never waits for a slab (brx.h, BRX_INTERNAL_WATCHDOG).  ev_done[k] is recorded behind the launch
+    // that used ring slot k, inflight_waves[k] is that launch's waves until the event has been seen complete.
+    hipEvent_t ev_done[BRX_COUNTER_RING] = {};
+    unsigned inflight_waves[BRX_COUNTER_RING] = {};
     hipEvent_t ev_in[BRX_MAX_CHUNKS] = {}, ev_k[BRX_MAX_CHUNKS] = {};
     bool have_timing = false;
     bool any_launch = false;
@@ -134,6 +141,11 @@ struct brx_ctx {
 };
 
 extern "C" const char *brx_last_error(void) { return g_err.c_str(); }
+
+// (brx_internal.h: for brx_node.cpp)
+int brx_fail(int code, const char *what) { return fail(code, what); }
+int brx_ctx_device(const brx_ctx *c) { return c->device; }
+unsigned brx_ctx_max_grid(const brx_ctx *c) { return c->max_grid; }
 
 extern "C" const char *brx_status_str(int32_t s) {
     // 1..24: description strings of the reference, src/lib.rs:331-354 (typos are the reference's)
@@ -205,6 +217,8 @@ static void ctx_release(brx_ctx *c) {
     for (auto &ev : c->ev_k)
         if (ev) (void)hipEventDestroy(ev);
     if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+    for (auto &ev : c->ev_done)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_fork)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &evs : c->ev_join)
@@ -307,6 +321,7 @@ static int ctx_init(brx_ctx *c, int device) {
     for (auto &ev : c->ev_in) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto &ev : c->ev_k) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming));
+    for (auto &ev : c->ev_done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto &ev : c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto &evs : c->ev_join)
         for (auto &ev : evs) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -403,28 +418,60 @@ static int grow(uint8_t **p, size_t *cap, size_t need) {
 
 // The spill-slab pool serves tables that do not fit the LDS table memory (worst case 256 trees per category,
 // SURVEY 2.2): 896 KiB per slab, claimed by a wave the first time it spills and released at the end of its
-// stream.  One slab per resident wave of the largest grid launched so far means no wave ever waits for one;
+// stream.  One slab per wave of the launches in flight (pool_need) means no wave ever waits for one;
 // nothing is allocated before the first launch and small batches stay small.
 static int ensure_pool(brx_ctx *c, unsigned grid) {
     unsigned want = 64;
     while (want < grid) want <<= 1;
-    if (want > c->max_grid) want = ((c->max_grid + 31u) / 32u) * 32u;
+    if (want > c->max_grid) want = ((c->max_grid + 31u) / 32u) * 32u + 32u; // (what the chip holds at a time, and a word to spare)
     if (c->pool.slabs && c->pool.count >= want) return BRX_SUCCESS;
     HIP_TRY(hipDeviceSynchronize()); // (rare) nobody may hold a slab of the old pool: launches on any stream included
+    for (auto &w : c->inflight_waves) w = 0u; // (nothing is in flight any more)
+    if (c->pool.waits) {
+        uint32_t w = 0;
+        if (hipMemcpy(&w, c->pool.waits, 4, hipMemcpyDeviceToHost) == hipSuccess) c->slab_waits += w;
+    }
     (void)hipFree(c->pool.bitmap);
     (void)hipFree(c->pool.slabs);
     c->pool.bitmap = nullptr;
     c->pool.slabs = nullptr;
+    c->pool.waits = nullptr;
     c->pool.count = 0;
     hipError_t e = hipMalloc(&c->pool.slabs, ((size_t)want + 1u) * BRX_SCRATCH_WORDS * 4u); // (+ 1: BrxSlabPool::sink)
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab pool allocation failed", e);
-    e = hipMalloc(&c->pool.bitmap, (size_t)(want / 32u) * 4u);
+    e = hipMalloc(&c->pool.bitmap, (size_t)(want / 32u + 1u) * 4u); // (+ 1: BrxSlabPool::waits)
     if (e != hipSuccess) return fail(BRX_ERR_OUT_OF_MEMORY, "spill-slab bitmap allocation failed", e);
-    HIP_TRY(hipMemset(c->pool.bitmap, 0, (size_t)(want / 32u) * 4u));
+    HIP_TRY(hipMemset(c->pool.bitmap, 0, (size_t)(want / 32u + 1u) * 4u));
     c->pool.count = want;
+    c->pool.waits = c->pool.bitmap + want / 32u;
     c->pool.sink = c->pool.slabs + (size_t)want * BRX_SCRATCH_WORDS;
     HIP_TRY(hipMemcpy(c->d_pool, &c->pool, sizeof(BrxSlabPool), hipMemcpyHostToDevice));
     return BRX_SUCCESS;
+}
+
+// How many slabs the pool must have for a launch whose kernels run `waves` slab-claiming waves at a time: those, plus the waves
+// of every earlier launch of this context that may still be running (device-pointer calls on other HIP streams overlap).  A slab is
+// held by a RESIDENT wave only -- claimed at a header, released before the wave takes its next stream -- and the chip holds at most
+// max_grid of them (16 per CU: 10 KiB of LDS, 128 VGPRs), whatever is queued: that many slabs can never run out.  Until round 6 the
+// pool followed the largest single grid, a wave of a second overlapping launch could find every slab taken, and after 4 s it gave up:
+// a VALID stream came back with BRX_INTERNAL_WATCHDOG.  Events are only polled when the bound without polling
+// (every launch of the last 64 counted as running) exceeds the pool: synchronous callers never poll, back-to-back asynchronous ones
+// about once per launch.
+static unsigned pool_need(brx_ctx *c, unsigned waves) {
+    const unsigned cap = ((c->max_grid + 31u) / 32u) * 32u + 32u;
+    if (c->pool.slabs && c->pool.count >= cap) return cap;
+    unsigned busy = 0;
+    for (auto w : c->inflight_waves) busy += w;
+    if (busy + waves > c->pool.count && busy != 0u) {
+        busy = 0;
+        for (unsigned k = 0; k < BRX_COUNTER_RING; k++) {
+            if (c->inflight_waves[k] == 0u) continue;
+            if (hipEventQuery(c->ev_done[k]) == hipSuccess) c->inflight_waves[k] = 0u;
+            else busy += c->inflight_waves[k];
+        }
+        (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure of this call)
+    }
+    return std::min(cap, busy + waves + 32u); // (+ a word to spare: the last claimer does not have to hunt for the one free slab)
 }
 
 // Streams per CU up to which a launch counts as sparse (profiles/r02_loop_build_sweep.txt).
@@ -489,8 +536,12 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     unsigned grid = n < c->max_grid ? n : c->max_grid;
     if (c->grid_cap != 0u && grid > c->grid_cap) grid = c->grid_cap; // (A/B knob BRX_GRID_CAP: fewer resident waves, more rounds)
     a.pool = d_own_pool;
+    // (what this launch runs at a time: its regular grid; under plan B the wider grids next to it -- together never more than its
+    // streams, nor than the chip holds; the grid-cap knob caps each of the four grids)
+    const bool can_plan_b = may_plan_b && !c->no_defer && !c->no_plan_b && d_resume == nullptr && c->debug_stop == 0u && n <= BRX_DEFER_MAX_STREAMS;
+    const unsigned slab_waves = d_own_pool ? 0u : (c->grid_cap != 0u && can_plan_b) ? std::min(n, 4u * c->grid_cap) : grid;
     if (!d_own_pool) {
-        int rc = ensure_pool(c, grid);
+        int rc = ensure_pool(c, pool_need(c, slab_waves));
         if (rc) return rc;
         a.pool = c->d_pool;
     }
@@ -713,6 +764,10 @@ static int launch(brx_ctx *c, hipStream_t st, bool timing, const uint8_t *d_in, 
     }
     if (timing) HIP_TRY(hipEventRecord(c->ev[3], st));
     HIP_TRY(hipEventRecord(c->ev_last, st));
+    if (slab_waves != 0u) {
+        HIP_TRY(hipEventRecord(c->ev_done[ring_slot], st));
+        c->inflight_waves[ring_slot] = slab_waves;
+    }
     c->last_counter = (a.defer != nullptr || lean) ? a.work_counter : nullptr;
     c->any_launch = true;
 #ifdef BRX_BRINGUP
@@ -807,7 +862,7 @@ static int decode_host(brx_ctx *c, const uint8_t *in, const uint64_t *in_off, ui
                 return in_off[gx + 1] - in_off[gx] > in_off[gy + 1] - in_off[gy];
             });
     }
-    if ((rc = ensure_pool(c, n < c->max_grid ? n : c->max_grid))) return rc; // once, for all the chunks' launches together
+    if ((rc = ensure_pool(c, pool_need(c, n < c->max_grid ? n : c->max_grid)))) return rc; // once, for all the chunks' launches together
     // Output buffer in pinned, mapped host memory (brx_host_alloc, hipHostMalloc, hipHostRegister) at the 16-byte phase of
     // the staging slots: the kernel stores every output byte to it as well (BrxKernelArgs::out_mirror) and there is no
     // device-to-host copy of the data afterwards -- it rode on the decode.  The HBM copy stays: it is the window.
@@ -918,6 +973,16 @@ extern "C" int brx_decode_batch(brx_ctx *c, const uint8_t *in, const uint64_t *i
 extern "C" double brx_last_timing(brx_ctx *c, int which) {
     if (!c) return -1.0;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (which == 12 || which == 13) { // 12: waves that ever had to wait for a spill slab (0 by construction: pool_need); 13: slabs of the pool
+        if (which == 13) return (double)c->pool.count;
+        uint32_t w = 0;
+        if (c->pool.waits) {
+            if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+            if (c->any_launch && hipEventSynchronize(c->ev_last) != hipSuccess) return -1.0;
+            if (hipMemcpy(&w, c->pool.waits, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+        }
+        return (double)(c->slab_waits + w);
+    }
     if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: pauses in front of one item that needed more room behind the window
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
     if ((which >= 2 && which <= 7) || which == 10 || which == 11) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
@@ -1175,7 +1240,8 @@ static int bounded_init(brx_stream *s) {
     HIP_TRY(hipMemset(s->d_rec, 0, 32));
     const uint32_t only_slab_0 = 0xfffffffeu; // a private pool of ONE slab that survives between the slices
     HIP_TRY(hipMemcpy(s->d_bitmap, &only_slab_0, 4, hipMemcpyHostToDevice));
-    BrxSlabPool p = {s->d_bitmap, s->d_slab, 32, s->d_slab}; // (sink = the one slab: only this stream's one wave ever asks)
+    HIP_TRY(hipMemset(s->d_bitmap + 1, 0, 4));
+    BrxSlabPool p = {s->d_bitmap, s->d_slab, 32, s->d_slab, s->d_bitmap + 1}; // (sink = the one slab: only this stream's one wave ever asks)
     HIP_TRY(hipMemcpy(s->d_pool, &p, sizeof p, hipMemcpyHostToDevice));
     s->stage.resize(BRX_IN_STAGE);
     return BRX_SUCCESS;
@@ -1195,6 +1261,12 @@ static size_t stream_pull(brx_stream *s, uint8_t *buf, size_t cap, std::unique_l
             throw;
         }
         lk.lock();
+        // (the callback may have been a reader on a context of another device, and another thread may have destroyed this stream's
+        // context meanwhile -- against the contract, but cheap to notice: ADVICE r5)
+        if (s->ctx == nullptr || s->d_inwin == nullptr || hipSetDevice(s->ctx->device) != hipSuccess) {
+            s->pull_broken = true;
+            return 0;
+        }
         if (got > cap) {
             s->pull_broken = true;
             return 0;
@@ -1315,6 +1387,10 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
             // than the window holds -- a bigger window (only when that fails does the slice run as if this were all there is)
             rc = bounded_grow_in(s);
             if (rc == BRX_SUCCESS) rc = bounded_refill(s, lk);
+            else if (rc == BRX_ERR_OUT_OF_MEMORY) { // (the window is at its limit, or the allocation failed: this slice is told that what is
+                s->stalled = true;                   // resident is all there is and reports the status it finds -- the reference's
+                rc = BRX_SUCCESS;                    // UnexpectedEOF, not a library error: ADVICE r5)
+            }
             if (rc) return rc;
         }
     }
@@ -1329,9 +1405,10 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
         // command or meta-block boundary, or in the middle of a literal run -- and a segment that still runs into that end (a
         // header, an uncompressed block, one whole command of the C++ loop) is taken back by the kernel itself: the slice
         // pauses in FRONT of it (brx_kernels.hip, resumable mode).  So UnexpectedEOF comes out of a slice only when it was told
-        // that the resident input is all there is: the source is dry -- or `stalled`: the last slice paused where it had started
-        // although the window could not be moved or filled any further (one item that needs more input than the window holds, or
-        // a real UnexpectedEOF of the format); this slice reports what it finds.
+        // that the resident input is all there is: the source is dry -- or `stalled`: the last slice paused where it had started, the
+        // window could not be moved or filled any further and could not grow either (one item that needs more than 256 MiB of input
+        // resident); this slice reports what it finds.  (UnexpectedEOF that the reference raises for a FORMAT error -- a bad
+        // MSKIPLEN, Q10 -- is not taken back by the kernel: ST_EOF_FORMAT in brx_kernels.hip.)
         const size_t margin = s->in_window / BRX_IN_MARGIN_DIV;
         const uint64_t in_low = s->src_eof || s->in_fill <= margin || s->stalled ? ~0ull : 8ull * (s->in_fill - margin);
         const uint64_t pz[3] = {pause_at, s->in_slide_pending, in_low};

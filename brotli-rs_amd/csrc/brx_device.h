@@ -71,8 +71,10 @@ struct BrxSlabPool {
     uint32_t *bitmap; // count / 32 words, bit set = slab in use
     uint32_t *slabs;  // count * BRX_SCRATCH_WORDS
     uint32_t count;   // multiple of 32
-    uint32_t *sink;   // one slab outside the bitmap: where the tables of a wave go that could not claim one within 0.5 s (a pool
+    uint32_t *sink;   // one slab outside the bitmap: where the tables of a wave go that could not claim one within 4 s (a pool
                       // that stays exhausted is a bug); its stream ends with the watchdog status, the device does not hang
+    uint32_t *waits;  // one word: waves that did not get a slab at their first try (brx_last_timing 12).  Stays 0: the host sizes the
+                      // pool for every wave of the launches in flight (brx_api.cpp, pool_need)
 };
 
 // One static-dictionary word transform (spec Appendix B): prefix + elementary op + suffix.

@@ -88,7 +88,7 @@
 #define WENDM1 s44
 #define WSAFE s45
 // The loop has no end-of-input test: it is poisoned when the refill pulls in dword WSAFE - 1 = (bitend >> 5) - END_MARGIN - 1
-// (resumable decode; batches: (bitend >> 5) + 3, see .Lwsafe_spec),
+// (resumable decode; batches: (bitend >> 5) + 3 -- mbw[MBW_WSAFE], set by the dispatcher),
 // the cursor then at most at bitend - 32 * END_MARGIN - 32, and leaves at the next insert&copy symbol or literal run.  Until
 // then it takes at most 24 + 24 (insert / copy extra bits) + 15 + 15 + 24 (a distance block switch: type, count, its extra
 // bits) + 15 + 24 (distance symbol, extra bits) = 141 bits: four dwords would do, five are kept (eight until round 4: a
@@ -594,7 +594,6 @@
     s_mov_b32 s19, 0x00020000
 #endif
     s_sub_u32 WENDM1, T0, 1
-    s_lshr_b32 WSAFE, T2, 5                             // (the margin follows once MBW_ASM has been read: .Lwsafe)
     s_lshr_b32 CBASE, T1, 5                             // first staged dword = the one holding the cursor
     s_and_b32 T3, T1, 31                                // bit offset inside it
     // stage 2 x 64 input dwords (clamped to the stream's last dword)
@@ -630,22 +629,17 @@
     ds_read_b128 v[24:27], VZERO offset:LDS_MBW+16      // cmd, hl, hi, hd
     ds_read_b64 v[32:33], VZERO offset:LDS_MBW+32       // ntl, ntd
     ds_read_b32 v36, VZERO offset:LDS_MBW+124           // MBW_ASM: 1 | mixed context modes << 1
+    ds_read_b32 v37, VZERO offset:LDS_MBW+156           // MBW_WSAFE
     s_waitcnt lgkmcnt(0)
     v_readfirstlane_b32 FLAGS, v36
-    // Where the loop gets poisoned (.Lspecial).  Bit 2 of MBW_ASM clear -- the resumable decode of the bounded reader, which cannot
-    // take a meta-block back: END_MARGIN dwords in front of the end of the input, every bit consumed here is a real bit.  Set
-    // (batches, round 5): only four dwords BEHIND the end -- a valid stream's last meta-block ends before that (the staged input
-    // repeats the stream's last dword beyond its end: memory-safe), so its last bytes no longer go through the C++ loop; a
-    // truncated stream runs on into those repeated bits, is poisoned and leaves with its cursor beyond the end, and the kernel then
-    // takes the whole meta-block back and decodes it again with the exact rules (brx_kernels.hip, "speculative end").
-    s_bitcmp1_b32 FLAGS, 2
-    s_cbranch_scc1 .Lwsafe_spec
-    s_sub_u32 WSAFE, WSAFE, END_MARGIN
-    s_cselect_b32 WSAFE, 0, WSAFE                       // borrow -> 0
-    s_branch .Lwsafe
-.Lwsafe_spec:
-    s_add_u32 WSAFE, WSAFE, 4
-.Lwsafe:
+    // Where the loop gets poisoned (.Lspecial): the dispatcher says (mbw[MBW_WSAFE], round 6).  The resumable decode of the bounded
+    // reader, which cannot take anything back: END_MARGIN dwords in front of the end of the input, every bit consumed here is a real
+    // bit.  Batches: four dwords BEHIND the end -- a valid stream's last meta-block ends before that (the staged input repeats the
+    // stream's last dword beyond its end: memory-safe), so its last bytes do not go through the C++ loop; a truncated stream runs on
+    // into those repeated bits, is poisoned and leaves with its cursor beyond the end, and the kernel then goes back to a checkpoint
+    // of the parked state that it took a few dozen dwords in front of the end -- which is where the loop is poisoned FIRST in a long
+    // stream -- and decodes the rest with the exact rules (brx_kernels.hip, "speculative end").
+    v_readfirstlane_b32 WSAFE, v37
     v_readfirstlane_b32 NPOST, v20
 #ifndef BRX_WIN_SGPR
     s_lshl_b32 NPOST, 1, NPOST                          // (this build multiplies: TAKE_EXTRA)

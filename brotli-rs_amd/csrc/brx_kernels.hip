@@ -47,8 +47,15 @@ enum {
     ST_NON_ZERO_RESERVED_BIT = 14, ST_NON_ZERO_TRAILER_BIT = 15, ST_NON_ZERO_TRAILER_NIBBLE = 16,
     ST_PARSE_CONTEXT_MAP = 17, ST_PARSE_COMPLEX_LENGTHS = 18, ST_PARSE_DISTANCE_CODE = 19,
     ST_PARSE_IAC = 20, ST_PARSE_LITERALS = 21, ST_RUN_LENGTH_EXCEEDED = 23, ST_EOF = 24,
-    ST_OUTPUT_TOO_SMALL = 25, ST_REF_PANIC = 26, ST_WATCHDOG = 27
+    ST_OUTPUT_TOO_SMALL = 25, ST_REF_PANIC = 26, ST_WATCHDOG = 27,
+    // kernel-internal, never stored: UnexpectedEOF that does NOT come from running out of bits -- the reference maps a few format
+    // errors to it (Q10: a bad MSKIPLEN, src/lib.rs:460-466; the WBITS pattern without an entry; an unassigned codeword where a block
+    // count is read, :977).  The resumable decode takes an item back when it meets the end of the RESIDENT input (ST_EOF) and asks for
+    // more; these stay errors however much input there is (the host doubled its window up to 256 MiB for them).  Stored
+    // as ST_EOF (final_status).
+    ST_EOF_FORMAT = 29
 };
+__device__ __attribute__((always_inline)) inline unsigned final_status(unsigned st) { return st == ST_EOF_FORMAT ? (unsigned)ST_EOF : st; }
 
 enum { LK_OK = 0, LK_NONE = 1, LK_EOF = 2 };
 
@@ -238,24 +245,31 @@ FI void tm_zero_bytes(const Dec &d, Lds &s, u32 ba, u32 n) {
 FI u32 *scratch_claim(const BrxSlabPool *pool) {
     const u32 nwords = pool->count >> 5;
     u32 w = (blockIdx.x * 7u) % nwords;
+    const u32 nwords0 = w == 0u ? nwords : w; // the word that ends the first pass: the one in front of the start
+    bool waited = false;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        // (a launch never has more waves than the pool has slabs -- brx_api.cpp sizes the pool by the largest grid -- so a wave only
-        // ever waits for slabs held by ANOTHER launch of the same context running next to it on another HIP stream, and for as
-        // long as that one's slab-class streams take: seconds for very large ones.  A pool that stays exhausted for 4 s -- 100 MHz
-        // counter -- is taken for a bug: the stream gets the watchdog status instead of the device a hang.  0.5 s until round 5.)
+        // (the pool has a slab for every wave of every launch in flight on the context -- brx_api.cpp, pool_need; until round 6 it
+        // followed the largest single grid, and a wave of a second, overlapping launch could wait for as long as the other one's
+        // slab-class streams took -- so nobody waits here.  A pool that stays exhausted for 4 s -- 100 MHz counter -- is a bug: the
+        // stream gets the watchdog status instead of the device a hang.)
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) return nullptr;
         u32 got = 0xffffffffu;
         if (threadIdx.x == 0u) {
-            const u32 cur = __hip_atomic_load(&pool->bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur != 0xffffffffu) {
+            u32 cur = __hip_atomic_load(&pool->bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (cur != 0xffffffffu) { // (a bit lost to another wave is set in what the atomic returns: at most 32 turns)
                 const u32 bit = (u32)__builtin_ctz(~cur);
                 const u32 old = atomicOr(&pool->bitmap[w], 1u << bit);
-                if (((old >> bit) & 1u) == 0u) got = w * 32u + bit;
+                if (((old >> bit) & 1u) == 0u) { got = w * 32u + bit; break; }
+                cur = old;
             }
         }
         got = rfl(got);
         if (got != 0xffffffffu) return pool->slabs + (size_t)got * BRX_SCRATCH_WORDS;
+        if (!waited && w + 1u == nwords0) { // (one pass over the bitmap found nothing)
+            waited = true;
+            if (threadIdx.x == 0u) (void)atomicAdd(pool->waits, 1u);
+        }
         w = w + 1u == nwords ? 0u : w + 1u;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -391,6 +405,10 @@ FI u32 in_byte_tail(Dec &d) {
 #define MBW_DIST 36
 #define MBW_DISTBAD 37
 #define MBW_EXIT 38
+#define BRX_END_MARGIN 5u          // = END_MARGIN of brx_hot.S: what the loop may consume between a poisoned refill and its next exit test
+#define BRX_SPEC_CK_DWORDS 64u     // speculative end: a long stream's loop is first poisoned this far in front of the end of the input (the checkpoint)
+#define BRX_SPEC_CK_MIN_DWORDS 1024u // ... if it is entered with more input than this left; shorter ones take their checkpoint at the first entry
+#define MBW_WSAFE 39 // the dword at which the assembly loop is poisoned (brx_hot.S, .Lspecial): set by the dispatcher before every call
 
 #ifndef BRX_SMALL
 // ---- parking the decoder state in LDS ------------------------------------------------------------------
@@ -1265,7 +1283,7 @@ FI u32 hd_decode(Dec &d, const Lds &s, u32 h, u32 hv, u32 &sym) {
 // of the 26 block count codes in closed form (spec section 6)
 FI u32 hd_block_count(Dec &d, const Lds &s, u32 h, u32 &blen) {
     u32 sym;
-    if (hd_decode(d, s, h, hd_tree(d, s, h), sym) != LK_OK) return ST_EOF;
+    if (hd_decode(d, s, h, hd_tree(d, s, h), sym) != LK_OK) return ST_EOF_FORMAT; // (no such codeword; cold_header turns a crossed end into ST_EOF)
     if (sym > 25u) return ST_INVALID_BLOCK_COUNT_CODE;
     u32 nb, base;
     if (sym < 16u) { const u32 g = sym >> 2; nb = 2u + g; base = 1u + 16u * ((1u << g) - 1u) + ((sym & 3u) << nb); }
@@ -1277,7 +1295,8 @@ FI u32 hd_block_count(Dec &d, const Lds &s, u32 h, u32 &blen) {
 // parse_block_count, src/lib.rs:957-987 (Ok(None) -> UnexpectedEOF, :977)
 FI u32 read_block_count(Dec &d, const Lds &s, u32 h, u32 &blen) {
     u32 sym, e;
-    if (decode_sym(d, s, h, sym) != LK_OK) return ST_EOF;
+    const u32 lk = decode_sym(d, s, h, sym);
+    if (lk != LK_OK) return lk == LK_EOF ? ST_EOF : ST_EOF_FORMAT;
     if (sym > 25u) return ST_INVALID_BLOCK_COUNT_CODE;
     u32 pk = rfl(K_BLEN[sym]);
     if (!in_bits(d, pk & 31u, e)) return ST_EOF;
@@ -1760,7 +1779,7 @@ FI u32 generic_body(Dec &d, Lds &s, const u32 mode_in) {
             if (!prepare_fast_tables(d, s, m, I.nbl, tm_u8(d, s, m.cmode_w * 4u), uniform)) { ok = 0u; why |= 128u; }
             else ok = uniform ? 1u : 3u; // bit 1: mixed context modes
         }
-        s.mbw[MBW_ASM] = ok ? (ok | ((rfl(s.st[ST_SPEC]) & 1u) << 2)) : 0u; // bit 2: where the loop is poisoned (brx_hot.S, .Lwsafe_spec)
+        s.mbw[MBW_ASM] = ok; // (where the loop is poisoned: Lds::mbw[MBW_WSAFE], set by the dispatcher before every call)
         if (!ok) s.pad[8] |= why;
     }
     const bool fast_tables = rfl(s.mbw[MBW_ASM]) != 0u; // symbol entries are in the assembly loop's forms
@@ -1965,7 +1984,7 @@ __device__ __noinline__ u32 seg_frame() {
                 wbits = 17u + v;
             } else {
                 if (!in_bits(d, 3, v)) return ST_EOF;
-                if (v == 1u) return ST_EOF;
+                if (v == 1u) return ST_EOF_FORMAT;
                 wbits = v == 0u ? 17u : 8u + v;
             }
         }
@@ -2007,7 +2026,8 @@ __device__ __noinline__ u32 seg_frame() {
                     if (!in_bits(d, 8, last)) { bad = true; break; }
                     skip |= last << i;
                 }
-                if (bad || (mskipbytes > 1u && last == 0u)) { rc = ST_EOF; break; }
+                if (bad) { rc = ST_EOF; break; }
+                if (mskipbytes > 1u && last == 0u) { rc = ST_EOF_FORMAT; break; } // (Q10: whatever follows)
                 skip += 1u;
                 if (in_byte_tail(d)) { rc = ST_NON_ZERO_FILL_BIT; break; }
                 if (in_remaining(d) < 8ull * skip) { rc = ST_EOF; break; }
@@ -2428,6 +2448,13 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // register) goes back, bar the flush cursor: what the failed call has flushed are good bytes, and they stay flushed.
 #define BRX_ST_BACKUP() const u32 st_bak = s.st[lane < 48u ? lane : 0u]
 #define BRX_ST_RESTORE() do { if (lane < 48u && lane != 12u && lane != 20u && lane != 21u) s.st[lane] = st_bak; } while (0) /* (a slab claimed meanwhile stays claimed) */
+                // ... and the RING: a command of the C++ loop inserts its literals before its copy finds no room (or its next field no
+                // input), and an insert of RING - 2 bytes or more has overwritten the slots of the bytes in front of the command -- the two
+                // context bytes the re-run's first literals choose their tree by (a wrong tree with two or more literal
+                // trees, silently).  What the failed call produced is flushed, so the last 2 KiB in front of the restored position come
+                // back from the stream's own output, as for a late resume.  (The flush cursor st[12] stays where the failed call left
+                // it: those are good bytes, and the re-run puts them into the ring again before anything reads them.)
+#define BRX_RING_BACK() do { seg_finish(); __threadfence(); seg_resume(); } while (0)
                 if (phase == PH_HEADER) {
                     BRX_ST_BACKUP();
                     st = cold_header();
@@ -2446,10 +2473,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                         if (rfl(s.mbw[MBW_ASM]) == 0u) {
                             BRX_ST_BACKUP();
                             st = generic_commands(HC_RESUME_R1); // one command per call: a pause point after each
-                            if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; paused = true; break; }
-                            if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); st = HC_CONTINUE; paused = true; break; }
+                            if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); BRX_RING_BACK(); st = HC_CONTINUE; paused = true; break; }
+                            if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); BRX_RING_BACK(); st = HC_CONTINUE; paused = true; break; }
                             continue;
                         }
+                        if (lane == 0u) { const u32 we = (u32)(get64(s, 5) >> 5); s.mbw[MBW_WSAFE] = we > BRX_END_MARGIN ? we - BRX_END_MARGIN : 0u; }
                         r = sw_loop ? asm_commands_sw() : asm_commands();
                         // (the assembly loop knows no pause: it runs until something unusual comes up -- at the latest the last dwords
                         // of the RESIDENT input, and the command it hands back there may well straddle that end.  While the source
@@ -2459,14 +2487,15 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     {
                         BRX_ST_BACKUP();
                         st = generic_commands(HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u)));
-                        if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
+                        if (st == ST_EOF && in_low != ~0ull) { BRX_ST_RESTORE(); BRX_RING_BACK(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
                         // (one command -- a long copy, a long insert -- that runs past the window's capacity: taken back like the one that
                         // ran out of input; the host makes room for it, BrxResume::need_room)
-                        if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
+                        if (st == ST_OUTPUT_TOO_SMALL) { need_room = rfl(s.st[22]); BRX_ST_RESTORE(); BRX_RING_BACK(); st = HC_CONTINUE; phase = PH_ASMEXIT; paused = true; break; }
                     }
                 }
 #undef BRX_ST_BACKUP
 #undef BRX_ST_RESTORE
+#undef BRX_RING_BACK
                 if (paused || st) break;
                 phase = PH_FRAME;
             }
@@ -2482,7 +2511,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 if (lane == 0u) rec->state = 2u;
             }
             if (lane == 0u) {
-                a.status[sid] = (int)st;
+                a.status[sid] = (int)final_status(st);
                 a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)rfl(s.st[22]) : (u64)rfl(s.st[10]);
             }
             continue;
@@ -2557,10 +2586,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
 #endif
         st = seg_frame();
         PT_ADD(0, pd);
-        bool exact = false; // this meta-block is decoded again after a speculative end: the C++ loop alone
         while (st == SEG_NEED_HEADER) {
             hdr_bitpos = get64(s, 3);
-            const u32 st_bak = s.st[lane < 48u ? lane : 0u]; // Lds::st at the meta-block's header, one word per lane ("speculative end" below)
             st = cold_header();
             PT_ADD(1, pd);
             if (st) break;
@@ -2583,7 +2610,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 if (hand != 0u) break;
             }
 #endif
-            if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u) || exact) {
+            if (a.debug_stop == 8u || (tiny && a.debug_stop == 0u)) {
                 // the C++ loop alone, whole meta-block per call: a bring-up mode, and the way of streams of a few dozen
                 // bytes (a handful of commands, e.g. the RLE-like fills of BASELINE configs 3 / 4): preparing the
                 // assembly loop's tables and handing over at every long copy costs more than it saves there
@@ -2621,36 +2648,64 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 const bool use_asm = rfl(s.mbw[MBW_ASM]) != 0u;
                 if (prof_on && lane == 0u) s.pad[use_asm ? 2 : 0]++;
                 if (st == HC_CONTINUE && !use_asm) st = generic_commands(HC_RESUME_R1_WHOLE);
-                while (st == HC_CONTINUE) {
-                    PT_ADD(3, pd);
-                    const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
-                    PT_ADD(4, pd);
-                    if (prof_on && lane == 0u) {
-                        s.pad[4 + (r & 3u)]++;
+                // ---- speculative end (round 5; checkpointed in round 6).  In a batch the assembly loop is poisoned only BEHIND the end of
+                // the input (brx_hot.S, mbw[MBW_WSAFE]): a valid stream never gets there -- its last meta-block ends first, and its last
+                // bytes do not pass through the C++ loop at 2 - 4 k cycles a symbol (a third of a 400-byte stream's time).  A stream that
+                // DID consume bits beyond its end (truncated, or corrupted so that it reads on) has decoded garbage from some point on:
+                // whatever status came of it is void.  Round 5 took the WHOLE meta-block back and ran it through the C++ loop -- a cut
+                // 1 MiB single-meta-block stream cost 0.35 s next to neighbours that take 45 ms.  Now the loop of a
+                // long stream is poisoned TWICE: first BRX_SPEC_CK_DWORDS in front of the end -- where everything consumed was real --
+                // and the dispatcher keeps the parked state of that moment (Lds::st and Lds::mbw, one word per lane of two registers:
+                // the checkpoint), then behind the end as before.  A stream that ran on goes back to the checkpoint -- everything out
+                // to HBM, st / mbw as they stood, the ring reloaded from the stream's own output as for a late resume -- and finishes
+                // with the margin IN FRONT of the end and the C++ loop's exact rules for the tail: what is decoded twice is those few
+                // dozen dwords.  Streams of a few KiB keep one stage (the checkpoint is the first entry of the loop): an extra
+                // hand-over per stream would cost them what the speculation saves.
+                const u32 w_end = (u32)(get64(s, 5) >> 5);
+                bool spec = use_asm && (rfl(s.st[ST_SPEC]) & 1u) != 0u;
+                bool have_ck = false;
+                u32 ck_st = 0u, ck_mbw = 0u;
+                for (;;) {
+                    while (st == HC_CONTINUE) {
+                        PT_ADD(3, pd);
+                        u32 wsafe = w_end > BRX_END_MARGIN ? w_end - BRX_END_MARGIN : 0u; // (no speculation: every bit consumed in the loop is a real one)
+                        bool stage1 = false;
+                        if (spec) {
+                            const u32 cw = (u32)(get64(s, 3) >> 5);
+                            if (!have_ck && cw + BRX_SPEC_CK_MIN_DWORDS < w_end) {
+                                stage1 = true;
+                                wsafe = w_end - BRX_SPEC_CK_DWORDS;
+                            } else {
+                                if (!have_ck) {
+                                    ck_st = s.st[lane < 48u ? lane : 0u];
+                                    ck_mbw = s.mbw[lane < 48u ? lane : 0u];
+                                    have_ck = true;
+                                }
+                                wsafe = w_end + 4u;
+                            }
+                        }
+                        if (lane == 0u) s.mbw[MBW_WSAFE] = wsafe;
+                        const u32 r = sw_loop ? asm_commands_sw() : asm_commands();
+                        PT_ADD(4, pd);
+                        if (prof_on && lane == 0u) {
+                            s.pad[4 + (r & 3u)]++;
+                        }
+                        // (bit 4 of the exit word: "the cursor is at the poison point, the loop would only hand straight back" -- true of the
+                        // last one; behind the first one the loop goes on, with the checkpoint taken)
+                        st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | (((r & 16u) && !stage1) ? HC_TO_END : 0u));
                     }
-                    st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | ((r & 16u) ? HC_TO_END : 0u));
-                }
-                PT_ADD(3, pd);
-                // ---- speculative end (round 5).  In a batch the assembly loop is poisoned only BEHIND the end of the input (brx_hot.S,
-                // .Lwsafe_spec): a valid stream never gets there -- its last meta-block ends first, and its last bytes no longer pass
-                // through the C++ loop at 2 - 4 k cycles a symbol (a third of a 400-byte stream's time).  A stream that DID consume bits
-                // beyond its end (truncated, or corrupted so that it reads on) has decoded garbage: whatever status came of it is void.
-                // The meta-block is taken back -- everything out to HBM, Lds::st as it stood at the header (the flush cursor set to
-                // the position, a slab claimed meanwhile stays claimed), the ring reloaded from the stream's own output as for a late
-                // resume -- and decoded again by the C++ loop with the reference's exact end-of-input rules.
-                if (use_asm && (rfl(s.st[ST_SPEC]) & 1u) != 0u && get64(s, 3) > get64(s, 5)) {
+                    PT_ADD(3, pd);
+                    if (!(spec && have_ck && get64(s, 3) > get64(s, 5))) break;
                     if (lane == 0u) (void)atomicAdd(a.work_counter + 18, 1u);
                     seg_finish();
                     __threadfence();
-                    if (lane < 48u && lane != 12u && lane != 20u && lane != 21u) s.st[lane] = st_bak;
-                    if (lane == 0u) s.st[12] = s.st[10] + s.st[11];
+                    if (lane < 48u && lane != 20u && lane != 21u) s.st[lane] = ck_st; // (a slab claimed meanwhile stays claimed)
+                    if (lane < 48u) s.mbw[lane] = ck_mbw;
                     seg_resume();
-                    exact = true;
-                    st = SEG_NEED_HEADER;
-                    continue;
+                    spec = false;
+                    st = HC_CONTINUE;
                 }
             }
-            exact = false;
             if (st) break;
             st = seg_frame();
             PT_ADD(0, pd);
@@ -2692,7 +2747,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
         if (prof_on && lane < 32u) a.debug[(size_t)a.n_total * 10u + (size_t)sid * 32u + lane] = g_prof[lane];
 #endif
         if (lane == 0u) {
-            a.status[sid] = (int)st;
+            a.status[sid] = (int)final_status(st);
             a.out_len[sid] = st == ST_OUTPUT_TOO_SMALL ? (u64)needed : (u64)pos;
         }
         if (a.trace != nullptr && lane == 0u) {

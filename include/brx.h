@@ -56,7 +56,13 @@ enum {
     BRX_OUTPUT_TOO_SMALL = 25, /* capacity out_off[i+1]-out_off[i] exhausted; out_len[i] = bytes needed so far */
     BRX_REF_PANIC = 26,        /* the reference would panic here: UppercaseFirst on a dictionary word that
                                   starts with 0x00 (src/transformation/mod.rs:52-82) */
-    BRX_INTERNAL_WATCHDOG = 27 /* bug guard inside the kernel (a decode loop made no progress); never expected */
+    BRX_INTERNAL_WATCHDOG = 27 /* bug guard inside the kernel.  Unreachable from any stream the reference terminates on, by construction:
+                                  (1) the loop guard counts commands and meta-blocks against  8 * input bytes + capacity + 65536 --
+                                  every command consumes a bit or emits a byte (one that does neither -- one-symbol codes throughout and a
+                                  transform that leaves nothing of its word -- repeats for ever in the reference too, src/lib.rs:2003-2141);
+                                  (2) the wait for a spill slab: since round 6 the pool holds one slab per wave of ALL launches in flight
+                                  on the context (at most the 16 waves per CU the chip can hold at a time), so no wave ever waits --
+                                  until then a second overlapping launch could starve a wave for 4 s and end a VALID stream with 27 */
 };
 
 /* ---- library-level return codes (not per-stream) ---------------------------------------------------- */
@@ -186,10 +192,14 @@ const char *brx_last_error(void);
  *   9        (since the context was made) pauses of bounded / pulled streams in front of ONE item (a long copy or insert, an uncompressed
  *            meta-block) that did not fit the room behind the output window: the window slides, and if that is not enough the buffer
  *            grows to hold the item
- *   10       meta-blocks of the most recent launch that were taken back and decoded again with the exact end-of-input rules because
- *            the fast loop had read on past the end of the stream's input (truncated / corrupted streams only; 0 for valid ones)
+ *   10       streams of the most recent launch whose fast loop had read on past the end of the input (truncated / corrupted streams
+ *            only; 0 for valid ones): they went back to a checkpoint a few dozen dwords in front of the end and were finished with
+ *            the exact end-of-input rules (round 5 took the whole meta-block back: a cut 1 MiB stream stalled its batch)
  *   11       streams of the most recent launch that the level-3 kernels handed on to the level-4 instance (150 KiB of LDS, one per
  *            CU: meta-blocks with more than 37.6 KiB of prefix-code tables -- one piece of several MiB from an encoder)
+ *   12       (since the context was made) waves that did not get a spill slab at their first pass over the pool.  0 by construction
+ *            since round 6: the pool has a slab for every wave of every launch in flight on the context (BRX_INTERNAL_WATCHDOG)
+ *   13       slabs of the context's spill pool (896 KiB each; it grows with the launches in flight, to at most what the chip runs at a time)
  */
 double brx_last_timing(brx_ctx *ctx, int which);
 
@@ -282,6 +292,76 @@ typedef size_t (*brx_read_fn)(void *user, uint8_t *buf, size_t cap);
 brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, void *user);
 int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len);
 void brx_stream_free(brx_stream *s);
+
+/* ---- The node: the GPUs of one machine behind ONE call (round 6) ---------------------------------------------
+ * Streams are independent -- a reference Decompressor owns all of its state (src/lib.rs:378-394) -- so a batch shards trivially: a
+ * brx_node owns one brx_ctx per GPU (one process, one host thread per GPU), deals the streams of a batch over them, decodes the
+ * shards at the same time and leaves every result where the caller said, exactly as brx_decode_batch would have.  This is how a
+ * host that is not Python (the Rust `Decompressor` pool of INTEGRATION.md) reaches GPUs 1 .. 7.
+ *   BRX_MEM_HOST    every GPU reads its streams from, and writes its results to, the caller's buffers: no exchange between GPUs at
+ *                   all (pinned buffers -- brx_host_alloc -- are used in place by every GPU's kernel; pageable ones are staged per GPU).
+ *   BRX_MEM_DEVICE  every pointer is memory of the ROOT rank's GPU.  The other ranks get exactly their shard of the compressed bytes
+ *                   over xGMI (scatter), decode, compact their results and send them back (ragged gather); the root expands them
+ *                   into the caller's slots.  One grouped exchange each way: RCCL (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd,
+ *                   one communicator per GPU in this process; librccl is loaded the first time it is needed) or plain peer copies
+ *                   (hipMemcpyPeerAsync) -- BRX_NODE_OPTION_TRANSPORT.  No collective ever runs inside the decode.
+ * Dealing (brx_node_opts::deal):
+ *   BRX_NODE_DEAL_RANGES  rank r of G takes the contiguous index range [r * n / G, (r + 1) * n / G)            (default)
+ *   BRX_NODE_DEAL_BYTES   contiguous ranges cut at equal shares of the COMPRESSED bytes (a batch that is sorted or drifts in size)
+ *   BRX_NODE_DEAL_SNAKE   the streams sorted by compressed size, largest first, and dealt 0 .. G-1, G-1 .. 0, ... with every rank
+ *                         keeping the stream count of its index range: a ragged batch within a few percent of equal bytes AND equal
+ *                         counts per GPU.  Not contiguous, so every rank's shard is packed and its results are unpacked (one more
+ *                         pass over the data: host memcpy under BRX_MEM_HOST, an HBM-rate gather kernel under BRX_MEM_DEVICE).
+ * How many GPUs a batch is dealt over (brx_node_opts::use_gpus = 0): one per BRX_NODE_OPTION_MIN_STREAMS streams (default: what one
+ * GPU decodes at a time, 16 per CU = 4096 on MI355X) -- a stream is a serial job of one wavefront, and 512 of them take a GPU about as
+ * long as 4096; give use_gpus (or lower the option) to trade GPUs for latency.
+ * The devices of a node need not differ: several ranks on one GPU ("virtual ranks") run the same code -- contexts, threads,
+ * dealing, scatter, gather -- which is how the path is tested on a one-GPU box.
+ * Results, status codes and error behaviour per stream are those of brx_decode_batch.  The call returns when everything is done. */
+typedef struct brx_node brx_node;
+
+#define BRX_NODE_DEAL_RANGES 0u
+#define BRX_NODE_DEAL_BYTES 1u
+#define BRX_NODE_DEAL_SNAKE 2u
+
+typedef struct brx_node_opts {
+    uint32_t flags;   /* BRX_MEM_HOST | BRX_MEM_DEVICE | BRX_OPT_TIMING */
+    uint32_t deal;    /* BRX_NODE_DEAL_* */
+    int32_t use_gpus; /* 0 = the library picks (see above); else the batch is dealt over ranks 0 .. use_gpus - 1 (root included) */
+    int32_t root;     /* BRX_MEM_DEVICE: the rank whose GPU holds the buffers (0 <= root < use_gpus) */
+    void *hip_stream; /* BRX_MEM_DEVICE: a stream of the root's GPU the call's work is ordered behind (NULL: none) */
+} brx_node_opts;
+
+enum {
+    BRX_NODE_OPTION_TRANSPORT = 100,    /* 0 = RCCL where every rank has a GPU of its own, peer copies otherwise (default); 1 = peer
+                                           copies (hipMemcpyPeerAsync); 2 = RCCL (fails with BRX_ERR_INVALID_ARGUMENT for virtual ranks,
+                                           BRX_ERR_HIP if librccl cannot be loaded) */
+    BRX_NODE_OPTION_MIN_STREAMS = 101,  /* streams per GPU below which use_gpus = 0 does not add a GPU (0 = the default, see above) */
+    BRX_NODE_OPTION_EXCHANGE_ROOT = 102 /* 1 = under BRX_MEM_DEVICE the root's own shard travels through the transport as well (to
+                                           itself) instead of being decoded in place: exercises the send / receive pair on one GPU */
+};
+
+/* devices: n_devices HIP device indices, rank r on devices[r]; NULL / 0 = every visible GPU, one rank each.  Fails like
+ * brx_ctx_create (BRX_ERR_NO_DEVICE without a GPU: there is no CPU fallback). */
+int brx_node_create(brx_node **out, const int *devices, int n_devices);
+void brx_node_destroy(brx_node *node);
+int brx_node_size(const brx_node *node);
+/* The context of a rank (owned by the node): for brx_ctx_set_option / brx_last_timing on one GPU.  Do not destroy it. */
+brx_ctx *brx_node_ctx(brx_node *node, int rank);
+/* BRX_OPTION_* : applied to every rank's context.  BRX_NODE_OPTION_* : the node's own. */
+int brx_node_set_option(brx_node *node, uint32_t option, int64_t value);
+/* brx_decode_batch over the node.  Arguments as there; see the block comment above for where the pointers live. */
+int brx_node_decode_batch(brx_node *node, const uint8_t *in, const uint64_t *in_off, uint32_t n, uint8_t *out,
+                          const uint64_t *out_off, uint64_t *out_len, int32_t *status, const brx_node_opts *opts);
+/* The dealing of brx_node_decode_batch on its own (host arithmetic, no GPU is touched): order[k] = the caller's index of the k-th
+ * stream in dealt order (the identity for the two contiguous deals), rank r takes order[cut[r] .. cut[r + 1]).  in_off: n + 1
+ * offsets in host memory; order: n entries; cut: gpus + 1 entries.  For callers that place their data themselves, and for tests. */
+int brx_node_deal(const uint64_t *in_off, uint32_t n, int gpus, uint32_t deal, uint32_t *order, uint32_t *cut);
+/* Of the most recent brx_node_decode_batch.  which: 0 = ranks the batch was dealt over; 1 = streams of `rank`; 2 = compressed
+ * bytes of `rank`; 3 = decode-kernel milliseconds of `rank` (BRX_OPT_TIMING, else -1); 4 = wall milliseconds of the whole call;
+ * 5 = wall milliseconds until every shard was on its GPU (BRX_MEM_DEVICE: the scatter; else 0); 6 = 1 if the exchange went through
+ * RCCL, 0 for peer copies / no exchange.  Returns < 0 if unavailable. */
+double brx_node_last_timing(brx_node *node, int which, int rank);
 
 #ifdef __cplusplus
 }

@@ -857,3 +857,69 @@ def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac
     empty_metadata(b)
     assert b.n % 8 == 0
     return prefix, b.bytes(), b"\x03", bytes(out)
+
+
+def takeback_stream(seed, units, commands, mode=2, wbits=22):
+    """Round 6: streams for the bounded reader's take-back paths.  `units` compressed meta-blocks, each with TWO literal
+    trees over disjoint symbol pairs behind a context map (so every output byte tells which context the decoder computed: a literal
+    decoded under the wrong tree is a wrong byte) and the same `commands`: (number of literals, copy length, distance) with explicit
+    distances only (at most four different distance codes).  An insert of several KiB overwrites the decoder's whole LDS ring before
+    the command's copy finds no room behind the output window (a copy of several MiB) or its literals run out of resident input (an
+    insert of several hundred thousand literals: one bit each, longer than the reader's margin) -- the command is taken back and run
+    again, and its first literals take their tree from the two bytes in FRONT of the command.  Returns (stream, expected output);
+    the output comes from an independent model of the context rules."""
+    rng = random.Random(seed)
+    b = Bits()
+    stream_header(b, wbits)
+    out = bytearray()
+    iacs = sorted({iac_symbol(n, c)[0] for n, c, d in commands})
+    assert 1 < len(iacs) <= 4
+    dists = sorted({_explicit_distance(d)[0] for n, c, d in commands})
+    assert len(dists) <= 4
+    mlen = sum(n + c for n, c, d in commands)
+    nib = 4 if mlen <= 1 << 16 else 5 if mlen <= 1 << 20 else 6
+    for u in range(units):
+        trees = [sorted(rng.sample(range(256), 2)), None]
+        trees[1] = sorted(rng.sample([x for x in range(256) if x not in trees[0]], 2))
+        cmap = [rng.randrange(2) for _ in range(64)]
+        b.put(0, 1)            # ISLAST = 0
+        b.put(nib - 4, 2)
+        b.put(mlen - 1, 4 * nib)
+        b.put(0, 1)            # ISUNCOMPRESSED = 0
+        b.put(0, 1); b.put(0, 1); b.put(0, 1)  # NBLTYPESL/I/D = 1
+        b.put(0, 2); b.put(0, 4)               # NPOSTFIX, NDIRECT
+        b.put(mode, 2)
+        _nbltypes(b, 2)        # NTREESL = 2
+        b.put(0, 1)            # RLEMAX = 0
+        simple_code(b, [0, 1], 1)
+        for c in cmap:
+            b.put(c, 1)
+        b.put(0, 1)            # no inverse move-to-front
+        b.put(0, 1)            # NTREESD = 1
+        for t in trees:
+            simple_code(b, t, 8)
+        simple_code(b, iacs, 10)
+        simple_code(b, dists, 6)
+        for n, c, d in commands:
+            sym, ie, ce = iac_symbol(n, c)
+            b.put(*code_bits(iacs, sym))
+            b.put(*ie)
+            b.put(*ce)
+            for _ in range(n):
+                p1 = out[-1] if len(out) >= 1 else 0
+                p2 = out[-2] if len(out) >= 2 else 0
+                t = trees[cmap[context_id(mode, p1, p2)]]
+                s = rng.choice(t)
+                b.put(*code_bits(t, s))
+                out.append(s)
+            dcode, dn, dx = _explicit_distance(d)
+            b.put(*code_bits(dists, dcode))
+            b.put(dx, dn)
+            assert d <= len(out)
+            if d >= c:
+                out += out[len(out) - d:len(out) - d + c]
+            else:
+                period = bytes(out[-d:])
+                out += (period * (c // d + 1))[:c]
+    b.put(1, 1); b.put(1, 1)   # ISLAST, ISLASTEMPTY
+    return b.bytes(), bytes(out)
