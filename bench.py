@@ -191,7 +191,7 @@ def measured_traffic(workload, streams):
         try:
             cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--no-chain-floor", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
+                   "--no-cpu-baseline", "--no-copy-path", "--no-traffic", "--no-chain-floor", "--no-configs", "--verify", "0"] + (["--streams", str(streams)] if streams else [])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k, None)
@@ -298,7 +298,7 @@ class Batch:
     def __init__(self, torch, np, dev, fx, n):
         self.fx, self.n, self.K = fx, n, len(fx)
         K = self.K
-        self.cap = (max(len(e) for _, e in fx) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
+        self.cap = (max(len(f[1]) for f in fx) + 15) & ~15  # 16-B aligned slots: every stream's flushes are full 16-B stores
         self.lens = np.array([len(fx[i % K][0]) for i in range(n)], dtype=np.int64)
         in_off_h = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(self.lens, out=in_off_h[1:])
@@ -306,19 +306,20 @@ class Batch:
             one = torch.frombuffer(bytearray(fx[0][0]), dtype=torch.uint8).to(dev)
             self.blob = one.repeat(n).contiguous()
         else:
-            parts = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev) for c, _ in fx]
+            parts = [torch.frombuffer(bytearray(f[0]), dtype=torch.uint8).to(dev) for f in fx]
             self.blob = torch.cat([parts[i % K] for i in range(n)]).contiguous()
         self.in_off = torch.from_numpy(in_off_h).to(dev)
         self.out_off = (torch.arange(n + 1, dtype=torch.int64, device=dev) * self.cap).contiguous()
         self.out = torch.empty(n * self.cap, dtype=torch.uint8, device=dev)
         self.out_len = torch.zeros(n, dtype=torch.int64, device=dev)
         self.status = torch.full((n,), -1, dtype=torch.int32, device=dev)
-        self.out_bytes = sum(len(fx[i % K][1]) for i in range(n))
+        self.out_bytes = sum(len(fx[i % K][1]) for i in range(n) if len(fx[i % K]) < 3 or fx[i % K][2] == 0)
 
     def step(self, ctx, timing=False):
         if STUB:  # (launcher test only) stand-in for the decode: the expected bytes into every slot
             import torch
-            for k, (_, e) in enumerate(self.fx):
+            for k, f in enumerate(self.fx):
+                e = f[1]
                 want = torch.frombuffer(bytearray(e), dtype=torch.uint8)
                 self.out.view(self.n, self.cap)[k::self.K, :len(e)] = want
                 self.out_len[k::self.K] = len(e)
@@ -338,12 +339,20 @@ class Batch:
 
     def verify(self, torch):
         """status, lengths, and every stream's bytes (checksum of checksums by equality)"""
-        ok = bool((self.status == 0).all().item())
-        for k, (_, e) in enumerate(self.fx):
-            want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(self.out.device)
-            ok = ok and bool((self.out_len[k::self.K] == len(e)).all().item())
-            got = self.out.view(self.n, self.cap)[k::self.K, :len(e)]
-            ok = ok and bool((got == want.unsqueeze(0)).all().item())
+        ok = True
+        for k, f in enumerate(self.fx):
+            e, want_st = f[1], (f[2] if len(f) > 2 else 0)
+            ok = ok and bool((self.status[k::self.K] == want_st).all().item())
+            if want_st == 0:
+                want = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(self.out.device)
+                ok = ok and bool((self.out_len[k::self.K] == len(e)).all().item())
+                got = self.out.view(self.n, self.cap)[k::self.K, :len(e)]
+                ok = ok and bool((got == want.unsqueeze(0)).all().item())
+            else:  # a stream that fails (cut short): the reference's error kind, and the bytes in front of the error are the oracle's
+                m = min(int(self.out_len[k::self.K].min().item()), len(e), self.cap)
+                if m > 0:
+                    want = torch.frombuffer(bytearray(e[:m]), dtype=torch.uint8).to(self.out.device)
+                    ok = ok and bool((self.out.view(self.n, self.cap)[k::self.K, :m] == want.unsqueeze(0)).all().item())
         return ok
 
     def byte_model(self, which):
@@ -351,7 +360,8 @@ class Batch:
         in + out + every copied byte read from HBM) or 'w' (physical: in + out; the fill's source period stays in LDS)"""
         import oracle_py
         per = []
-        for c, e in self.fx:
+        for f in self.fx:
+            c, e = f[0], f[1]
             st = oracle_py.decode(c, want_stats=True)[2]
             per.append(len(c) + len(e) + {"alg": st["copy_bytes"] + st["dict_bytes"], "rw": st["copy_bytes"], "w": 0}[which])
         return sum(per[i % self.K] for i in range(self.n))
@@ -401,6 +411,158 @@ def copy_path(torch, np, dev, ctx, barrier, steps=5):
     return res
 
 
+def other_configs(torch, np, dev, ctx, barrier, with_traffic, steps=5):
+    """The other BASELINE configs' per-GPU shares in the driver-run line (VERDICT r5 missing #6): config 5 (1024 x 1 MiB multi-meta-block
+    streams with block switches: kernel ms, one stream alone, roofline fraction, counter traffic, bit-exact), and the same batch
+    with every 64th stream CUT at a random byte -- one bad stream must not stall its batch (a cut
+    1 MiB stream used to be decoded again by the C++ loop, ~8 x the batch)."""
+    import random
+    import oracle_py
+    res = {}
+    fixtures, n = WORKLOADS["config5_1MiBx1024"]
+    fx = [load_fixture(f) for f in fixtures]
+    b = Batch(torch, np, dev, fx, n)
+    dt, kms = timed_pass(ctx, b, steps, 1, barrier)
+    ok = b.verify(torch)
+    kavg = sum(kms) / len(kms)
+    alg = b.byte_model("alg")
+
+    def local_sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+    floor_ms, _ = chain_floor(torch, np, dev, ctx, fx, local_sync, steps=2, most=4)
+    r = {"workload": "%d x %s per GPU (BASELINE configs[4], per-GPU share of 8192 over 8)" % (n, "|".join(fixtures)), "kernel_ms_avg": round(kavg, 3),
+         "steps": steps, "decompressed_MB_per_s": round(b.out_bytes * steps / dt / 1e6, 1), "algorithmic_bytes_per_launch": alg,
+         "achieved": round(alg / (kavg * 1e-3) / 1e9, 1), "frac": round(alg / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "chain_floor_ms": round(floor_ms, 3), "frac_of_chain_floor": round(floor_ms / kavg, 4), "bit_exact": ok, "traffic": None}
+    if with_traffic:
+        try:
+            t, detail = measured_traffic("config5_1MiBx1024", 0)
+            r["traffic"] = t
+            if t:
+                r["traffic_over_algorithmic"] = round(t / alg, 2)
+            else:
+                r["traffic_error"] = detail
+        except Exception as e:
+            r["traffic_error"] = repr(e)[:200]
+    res["config5_1MiBx1024"] = r
+    # every 64th stream cut at a random byte (seeded); expected status and bytes from the oracle
+    rng = random.Random(64)
+    cut_fx = []
+    for i in range(n):
+        comp, exp = fx[i % len(fx)]
+        if i % 64 == 63:
+            c = comp[:rng.randrange(len(comp) // 20, len(comp) - 1)]
+            st, out = oracle_py.decode(c, 0, cap=len(exp) + 64)[:2]
+            cut_fx.append((c, out, st))
+        else:
+            cut_fx.append((comp, exp, 0))
+    bc = Batch(torch, np, dev, cut_fx, n)
+    dtc, kmsc = timed_pass(ctx, bc, steps, 1, barrier)
+    okc = bc.verify(torch)
+    kc = sum(kmsc) / len(kmsc)
+    res["config5_cut_1MiBx1024"] = {"workload": "the same batch, every 64th stream cut at a random byte (16 streams: status and bytes in front of the error "
+                                                "against the oracle)", "kernel_ms_avg": round(kc, 3), "over_all_valid": round(kc / kavg, 3),
+                                    "rollbacks_last_launch": ctx.last_spec_rollbacks(), "cut_statuses": sorted({f[2] for f in cut_fx if f[2]}),
+                                    "bit_exact": okc}
+    del b, bc
+    torch.cuda.empty_cache()
+    return res
+
+
+def node_abi(torch, np, dev, local_rank, fx, n, ctx_ms, steps=5):
+    """The node entry of the C ABI (brx_node_decode_batch, round 6) on the GPU this run has: the headline batch through a node of ONE
+    rank (the root decodes in place: what the extra layer costs), and over TWO virtual ranks on this GPU (half the batch travels by
+    peer copy, is decoded into slots of its own, compacted, copied back and expanded: the whole exchange on one GPU -- function, not
+    speed).  Real multi-GPU numbers: `bench.py --gpus N --node device|host` on a machine that has the GPUs."""
+    from brotli_rs_amd import brx
+    res = {}
+    for tag, devices, ranks in (("one_rank", [local_rank], 1), ("two_virtual_ranks", [local_rank, local_rank], 2)):
+        node = brx.Node(devices)
+        try:
+            b = Batch(torch, np, dev, fx, n)
+            best = 1e9
+            for k in range(steps + 1):
+                if k == steps:
+                    b.poison(torch)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                node.decode_batch_device(b.blob.data_ptr(), b.in_off.data_ptr(), n, b.out.data_ptr(), b.out_off.data_ptr(), b.out_len.data_ptr(),
+                                         b.status.data_ptr(), use_gpus=ranks, timing=True)
+                if k:
+                    best = min(best, time.perf_counter() - t0)
+            last = node.last()
+            res[tag] = {"wall_ms_best": round(best * 1e3, 3), "kernel_ms_per_rank": [round(v, 3) for v in last["kernel_ms"]], "streams_per_rank": last["streams"],
+                        "bit_exact": b.verify(torch), "rccl": last["rccl"]}
+            del b
+        finally:
+            node.close()
+        torch.cuda.empty_cache()
+    res["one_rank"]["over_ctx_kernel_ms"] = round(res["one_rank"]["wall_ms_best"] - ctx_ms, 3)
+    res["what"] = "brx_node_decode_batch, BRX_MEM_DEVICE, wall time of the synchronous call (the decode kernels + the call; two ranks: + scatter, compaction, gather, expansion)"
+    return res
+
+
+def node_main(args):
+    """`--gpus N --node host|device`: ONE process, N GPUs, brx_node_decode_batch (the C ABI's node entry; no torch.distributed).  The
+    batch is N x the per-GPU workload; `host`: pinned host buffers used in place by every GPU (no exchange, PCIe inside the time);
+    `device`: everything on GPU 0, shards scattered over xGMI, results gathered back (RCCL or peer copies) -- the exchange is INSIDE
+    the time here, unlike the driver's one-process-per-GPU mode whose `value` has the inputs resident on every GPU."""
+    import numpy as np
+    import torch
+    from brotli_rs_amd import brx
+    if torch.cuda.device_count() < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to print a number\n" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(3)
+    fixtures, n = WORKLOADS[args.workload]
+    if args.streams:
+        n = args.streams
+    fx = [load_fixture(f) for f in fixtures]
+    N = n * args.gpus
+    node = brx.Node(list(range(args.gpus)))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    b = Batch(torch, np, dev, fx, N)
+    if args.node == "host":
+        hin, hout = brx.host_alloc(int(b.blob.numel())), brx.host_alloc(N * b.cap)
+        hin[:] = b.blob.cpu().numpy()
+        io, oo = b.in_off.cpu().numpy().astype(np.uint64), b.out_off.cpu().numpy().astype(np.uint64)
+
+    def step(timing=False):
+        if args.node == "host":
+            return node.decode_batch_host_raw(hin.ctypes.data, io, N, hout.ctypes.data, oo, deal=args.deal, use_gpus=args.gpus, timing=timing)
+        node.decode_batch_device(b.blob.data_ptr(), b.in_off.data_ptr(), N, b.out.data_ptr(), b.out_off.data_ptr(), b.out_len.data_ptr(),
+                                 b.status.data_ptr(), deal=args.deal, use_gpus=args.gpus, timing=timing)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k == args.steps - 1 and args.node == "device":
+            b.poison(torch)
+        r = step(timing=(k == args.steps - 1))
+    dt = time.perf_counter() - t0
+    last = node.last()
+    if args.node == "host":
+        st, ln = r
+        ok = (not st.any()) and all(hout[i * b.cap:i * b.cap + len(fx[i % len(fx)][1])].tobytes() == fx[i % len(fx)][1] for i in (0, N // 2, N - 1))
+    else:
+        ok = b.verify(torch)
+    res = {"metric": "decompressed MB/s (whole node), %s batch, single process through brx_node_decode_batch (%s pointers)" % (args.workload, args.node),
+           "value": round(b.out_bytes * args.steps / dt / 1e6, 1), "unit": "MB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+           "data": "synthetic (fixture(s) %s replicated)" % ",".join(fixtures[:8]),
+           "config": {"workload": "%d x %s per GPU" % (n, "|".join(f + ".compressed" for f in fixtures[:8])), "streams_per_gpu": n, "streams_total": N,
+                      "sharding": "one process, brx_node_decode_batch: %s deal over %d GPUs; %s" % (args.deal, args.gpus,
+                                  "pinned host buffers used in place by every GPU, PCIe inside the time" if args.node == "host" else
+                                  "batch resident on GPU 0, scatter + ragged gather over xGMI INSIDE the time (%s)" % ("RCCL" if last["rccl"] else "peer copies"))},
+           "exchange_inclusive": True, "bit_exact": bool(ok), "kernel_ms_per_rank": [round(v, 4) for v in last["kernel_ms"]], "streams_per_rank": last["streams"],
+           "last_call_wall_ms": round(last["wall_ms"], 3), "scatter_ms": round(last["scatter_ms"], 3)}
+    node.close()
+    print(json.dumps(res), flush=True)
+    sys.exit(0 if ok else 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,7 +577,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", type=int, default=1)
     ap.add_argument("--gather", action="store_true", help="also time the ragged gather of the outputs to rank 0 (N>1: always)")
+    ap.add_argument("--node", choices=["host", "device"], default=None, help="ONE process for all N GPUs through brx_node_decode_batch (the C ABI's node entry) instead of one rank per GPU")
+    ap.add_argument("--deal", choices=["ranges", "bytes", "snake"], default="ranges", help="--node: how the batch is dealt over the GPUs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (config 5's per-GPU share, the cut-stream batch) and `node_abi`")
     args = ap.parse_args()
+
+    if args.node and not STUB:
+        node_main(args)  # does not return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
@@ -689,6 +857,15 @@ def main():
                 res["copy_path"] = copy_path(torch, np, dev, ctx, barrier)
             except Exception as e:  # never takes the headline down with it
                 res["copy_path"] = {"error": repr(e)[:200]}
+        if not args.no_configs and world == 1 and args.workload == "alice29x4096":
+            try:
+                res["configs"] = other_configs(torch, np, dev, ctx, barrier, with_traffic=not args.no_traffic and not under_profiler())
+            except Exception as e:
+                res["configs"] = {"error": repr(e)[:200]}
+            try:
+                res["node_abi"] = node_abi(torch, np, dev, local_rank, fx, n, kavg)
+            except Exception as e:
+                res["node_abi"] = {"error": repr(e)[:200]}
         if cb and world == 1 and K == 1:
             # informational, never part of `value`: the same batch from pinned HOST buffers to pinned host buffers through the
             # C ABI's host-pointer path (the kernel reads the input and stores the output over PCIe while it decodes)
@@ -723,7 +900,7 @@ def main():
                     raise KeyError("no file")
                 fixture_path = os.path.join(C5 if fixtures[0].startswith("c5_") else GOLD, fixtures[0] + ".compressed")
                 o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), fixture_path, "4"],
-                                   capture_output=True, text=True, timeout=120)
+                                   capture_output=True, text=True, timeout=180)
                 res["cpu_all_cores"] = json.loads(o.stdout.strip().splitlines()[-1])
             except Exception:
                 pass

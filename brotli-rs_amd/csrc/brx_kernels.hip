@@ -2452,9 +2452,11 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // input), and an insert of RING - 2 bytes or more has overwritten the slots of the bytes in front of the command -- the two
                 // context bytes the re-run's first literals choose their tree by (a wrong tree with two or more literal
                 // trees, silently).  What the failed call produced is flushed, so the last 2 KiB in front of the restored position come
-                // back from the stream's own output, as for a late resume.  (The flush cursor st[12] stays where the failed call left
-                // it: those are good bytes, and the re-run puts them into the ring again before anything reads them.)
-#define BRX_RING_BACK() do { seg_finish(); __threadfence(); seg_resume(); } while (0)
+                // back from the stream's own output, as for a late resume.  And the FLUSH CURSOR goes back to the position: what the failed
+                // call flushed beyond it are good bytes, but the host slides / re-allocates the output window before the next slice and
+                // keeps only what lies in front of the position (round 6, found by the test of the above: the first 4 KiB of such an
+                // insert came back as zeros once the buffer had grown) -- the re-run flushes them again.
+#define BRX_RING_BACK() do { seg_finish(); __threadfence(); if (lane == 0u) s.st[12] = s.st[10] + s.st[11]; seg_resume(); } while (0)
                 if (phase == PH_HEADER) {
                     BRX_ST_BACKUP();
                     st = cold_header();
@@ -2690,6 +2692,10 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                         if (prof_on && lane == 0u) {
                             s.pad[4 + (r & 3u)]++;
                         }
+                        // (the loop came back with its cursor BEYOND the end: everything since the checkpoint is void -- and the C++ loop must
+                        // not see this state: "bits left" = end - cursor wraps, and it would decode zeros to the end of the meta-block at
+                        // ~3 000 cycles a symbol: that, not the redo, was most of a cut stream's time)
+                        if (spec && have_ck && get64(s, 3) > get64(s, 5)) break;
                         // (bit 4 of the exit word: "the cursor is at the poison point, the loop would only hand straight back" -- true of the
                         // last one; behind the first one the loop goes on, with the checkpoint taken)
                         st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | (((r & 16u) && !stage1) ? HC_TO_END : 0u));
