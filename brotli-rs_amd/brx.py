@@ -131,7 +131,7 @@ def status_str(code: int) -> str:
 
 # brx_ctx_set_option (include/brx.h, BRX_OPTION_*): explicit knobs -- neither the library nor this module reads the environment
 OPTIONS = {"command_loop": 1, "loop_build": 2, "queue_order": 3, "hand_up": 4, "levels": 5, "tiny_bytes": 6,
-           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10, "trace": 11, "reader_window": 12, "level4": 13}
+           "host_in_place": 7, "grid_cap": 8, "small_bytes": 9, "small_waves": 10, "trace": 11, "reader_window": 12, "level4": 13, "reader_mb_room": 14}
 
 
 class Context:

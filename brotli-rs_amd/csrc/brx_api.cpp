@@ -111,6 +111,7 @@ struct brx_ctx {
     hipEvent_t ev_fork[BRX_COUNTER_RING] = {}, ev_join[BRX_COUNTER_RING][3] = {};
     uint32_t *d_handup = nullptr;                 // state records of the late lists: BRX_COUNTER_RING x BRX_LATE_CAP x 16 words
     bool level4 = true;                           // BRX_OPTION_LEVEL4: the level-4 launch behind every batch launch
+    bool reader_mb_room = true;                   // BRX_OPTION_READER_MB_ROOM: bounded readers make room for whole meta-blocks (A/B)
     uint32_t *d_handup2 = nullptr;                // ... of the second late lists (level 3 -> level 4): BRX_COUNTER_RING x BRX_LATE2_CAP x 16 words
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last = nullptr; // recorded after the most recent launch (pool growth waits for it)
@@ -379,6 +380,7 @@ extern "C" int brx_ctx_set_option(brx_ctx *c, uint32_t option, int64_t value) {
     case BRX_OPTION_SMALL_BYTES: c->small_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), BRX_SMALL_MAX_BYTES); break;
     case BRX_OPTION_TRACE: c->trace_on = value != 0; break;
     case BRX_OPTION_LEVEL4: c->level4 = value != 0; break;
+    case BRX_OPTION_READER_MB_ROOM: c->reader_mb_room = value != 0; break;
     case BRX_OPTION_READER_WINDOW:
         if (value < (1 << 20) || value > (256 << 20)) return fail(BRX_ERR_INVALID_ARGUMENT, "brx_ctx_set_option: reader window is 1 MiB .. 256 MiB");
         c->reader_window = ((size_t)value + 65535u) & ~(size_t)65535;
@@ -1182,6 +1184,8 @@ struct brx_stream {
     bool pull_broken = false;                  // the read callback returned more than it was given room for
     size_t buf_size = 0;                       // size of d_buf: BRX_BOUNDED_BUFSIZE, more once a single command needed more
     uint64_t want_room = 0;                    // the output position the item in front of the last pause runs to (BrxResume::need_room), or 0
+    bool want_room_optional = false;           // ... it is a whole META-BLOCK (round 6): without the room it still decodes, in the slower loop
+    bool no_mb_room = false;                   // that room could not be had once: the kernel is told not to pause in front of meta-blocks any more
     uint8_t *d_inwin = nullptr, *d_buf = nullptr;
     size_t in_window = (8u << 20);     // size of d_inwin (the context's reader_window when the stream started decoding)
     size_t in_fill = 0, in_cursor = 0; // bytes resident in d_inwin; the decoder's cursor in it (after the last good slice)
@@ -1226,6 +1230,7 @@ static int bounded_init(brx_stream *s) {
     brx_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     s->in_window = c->reader_window;
+    s->no_mb_room = !c->reader_mb_room;
     s->buf_size = BRX_BOUNDED_BUFSIZE;
     HIP_TRY(hipMalloc(&s->d_inwin, s->in_window + 16)); // (the option's size, not the default's: ADVICE r4)
     HIP_TRY(hipMalloc(&s->d_buf, s->buf_size));
@@ -1372,7 +1377,8 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
     if (s->want_room > BRX_STREAM_LIMIT) return BRX_ERR_OUT_OF_MEMORY; // (the stream runs past the 4 GiB - 256 B of the position arithmetic)
     if (s->want_room > s->shift + s->buf_size) { // (the item the last slice paused in front of: still beyond the capacity after the slide)
         int rc = bounded_grow_out(s, s->want_room);
-        if (rc) return BRX_ERR_OUT_OF_MEMORY;
+        if (rc && s->want_room_optional) s->no_mb_room = true; // (a meta-block decodes without: one command per call, each checked against the capacity)
+        else if (rc) return BRX_ERR_OUT_OF_MEMORY;
     }
     s->want_room = 0;
     // the input side: keep at least half a window of compressed bytes in front of the cursor while the source has any
@@ -1411,8 +1417,8 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
         // MSKIPLEN, Q10 -- is not taken back by the kernel: ST_EOF_FORMAT in brx_kernels.hip.)
         const size_t margin = s->in_window / BRX_IN_MARGIN_DIV;
         const uint64_t in_low = s->src_eof || s->in_fill <= margin || s->stalled ? ~0ull : 8ull * (s->in_fill - margin);
-        const uint64_t pz[3] = {pause_at, s->in_slide_pending, in_low};
-        HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), pz, 24, hipMemcpyHostToDevice, c->stream));
+        const uint64_t pz[4] = {pause_at, s->in_slide_pending, in_low, s->no_mb_room ? 1ull : 0ull}; // (need_room on the way in: 1 = no pause in front of whole meta-blocks)
+        HIP_TRY(hipMemcpyAsync((uint8_t *)s->d_rec + offsetof(BrxResume, pause_at), pz, 32, hipMemcpyHostToDevice, c->stream));
         int rc = launch(c, c->stream, false, s->d_inwin, s->d_meta, 1, virt, s->d_meta + 2, s->d_meta + 4,
                         (int32_t *)(s->d_meta + 5), nullptr, s->d_rec, s->d_pool);
         if (rc) return rc;
@@ -1440,6 +1446,8 @@ static int bounded_step(brx_stream *s, std::unique_lock<std::mutex> &lk) {
             // One item (a long copy or insert, an uncompressed meta-block) runs to `need_room` and did not fit behind the window: the
             // kernel took it back and paused in front of it.  The next slice first slides the window; if the item still does not
             // fit, the buffer grows to hold it (bounded_grow_out) -- nothing is decoded twice, nothing is put back.
+            s->want_room_optional = (need_room >> 63) != 0;
+            need_room &= ~(1ull << 63);
             s->want_room = need_room;
             if (need_room) c->stream_regrown++;
             s->no_progress = cursor == s->in_cursor && res[0] == pos0 && need_room == 0;

@@ -114,6 +114,8 @@ struct BrxResume {
                      // more, and what is resident ends soon (~0 = the resident input is all there is)
     uint64_t need_room; // written at a pause: 0, or the output position the NEXT item (a command, an uncompressed meta-block) runs to --
                         // it did not fit the window's capacity and was taken back; the host makes that room and goes on
+                        // (bit 63: the item is a whole compressed meta-block the slice paused in FRONT of -- room for it lets the assembly loop
+                        // run it; without, it decodes command by command.  On the way IN: 1 = do not pause in front of meta-blocks)
     uint32_t lds[2560];
 };
 #define BRX_RESUME_CURSOR_WORD (2432u + 3u) // index into BrxResume::lds of the parked input cursor (Lds::st[3..4], bits from the

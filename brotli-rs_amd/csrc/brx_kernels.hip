@@ -2426,6 +2426,8 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 st = (phase == PH_LOOP || phase == PH_ASMEXIT) ? HC_CONTINUE : 0u;
             }
             const u64 pause_at = rec->pause_at, in_low = rec->in_low;
+            const bool no_mb_pause = rec->need_room == 1ull; // (on the way in: the host could not make room for a whole meta-block before)
+            bool room_optional = false;
             if (lane == 0u) {
                 s.st[ST_PAUSE_AT] = (u32)pause_at; s.st[ST_PAUSE_AT + 1] = (u32)(pause_at >> 32);
                 s.st[ST_IN_LOW] = (u32)in_low; s.st[ST_IN_LOW + 1] = (u32)(in_low >> 32);
@@ -2458,6 +2460,21 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 // insert came back as zeros once the buffer had grown) -- the re-run flushes them again.
 #define BRX_RING_BACK() do { seg_finish(); __threadfence(); if (lane == 0u) s.st[12] = s.st[10] + s.st[11]; seg_resume(); } while (0)
                 if (phase == PH_HEADER) {
+                    // Room for the WHOLE meta-block behind the window?  The assembly loop runs a meta-block only when it fits the capacity
+                    // (it has no capacity test per command), so a large meta-block that started deep in the window used to run in the C++
+                    // loop, one command per call -- ~3 MB/s instead of ~25 for exactly the streams a reader is for (big files in 16 MiB
+                    // meta-blocks).  Now the slice pauses in FRONT of such a meta-block and says how far it runs: the host
+                    // slides the window and, if need be, lets the buffer grow to window + meta-block (BrxResume::need_room, as for one
+                    // oversized command); nothing has been parsed yet, nothing is taken back.
+                    {
+                        const u64 mb_end = (u64)rfl(s.st[10]) + rfl(s.st[ST_MLEN]);
+                        if (pause_at != ~0ull && !no_mb_pause && mb_end > (u64)rfl(s.st[9]) && mb_end <= 0xffffff00ull) {
+                            need_room = (u32)mb_end;
+                            room_optional = true; // (bit 63 of BrxResume::need_room: the host may fail to make this room, the meta-block decodes anyway)
+                            paused = true;
+                            break;
+                        }
+                    }
                     BRX_ST_BACKUP();
                     st = cold_header();
                     if (st == ST_OK) st = generic_commands(HC_START);
@@ -2505,7 +2522,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
             if (paused) {
                 const u32 *src = (const u32 *)&s;
                 for (u32 w = lane; w < BRX_LDS_BYTES / 4u; w += 64u) rec->lds[w] = src[w];
-                if (lane == 0u) { rec->state = 1u; rec->phase = phase; rec->need_room = need_room; }
+                if (lane == 0u) { rec->state = 1u; rec->phase = phase; rec->need_room = (u64)need_room | (room_optional ? 1ull << 63 : 0ull); }
                 st = BRX_PAUSED;
             } else {
                 const u32 *slab = (const u32 *)(uintptr_t)get64(s, 20);

@@ -146,11 +146,15 @@ enum {
     BRX_OPTION_TRACE = 11,        /* 1 = every launch records when and where each stream was decoded (brx_last_trace); default 0 */
     BRX_OPTION_READER_WINDOW = 12, /* compressed bytes a bounded / pulled stream keeps resident on the device (default 8 MiB; 1 .. 256
                                      MiB): streams started afterwards */
-    BRX_OPTION_LEVEL4 = 13        /* 1 = behind every batch launch one more (usually empty, 4 us) launch of the level-4 instance -- 150 KiB
+    BRX_OPTION_LEVEL4 = 13,       /* 1 = behind every batch launch one more (usually empty, 4 us) launch of the level-4 instance -- 150 KiB
                                      of LDS, one per CU -- takes the streams whose prefix-code tables spill even level 3 (pieces of several
                                      MiB compressed in one go) (default); 0 = no such launch: those meta-blocks run in the C++ loop from a
                                      slab (~3 MB/s per stream).  For callers whose batches are tens of microseconds long and never hold
                                      such streams */
+    BRX_OPTION_READER_MB_ROOM = 14 /* 1 = a bounded / pulled stream pauses in front of a compressed meta-block that does not fit behind its output
+                                     window and lets the buffer grow to window + meta-block (at most ~34 MiB), so that the fast loop runs it
+                                     (default); 0 = such meta-blocks decode command by command in the ~22 MiB buffer (~8 x slower): streams
+                                     started afterwards */
 };
 int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
 
