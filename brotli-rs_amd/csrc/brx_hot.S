@@ -27,7 +27,7 @@
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
-// command and hands back: copies longer than 512 bytes (or long and closer than 64 bytes), any error (the C++ side re-decodes and
+// command and hands back: copies longer than 512 bytes, any error (the C++ side re-decodes and
 // raises it), the dword the dispatcher names in mbw[MBW_WSAFE] (resumable decode: END_MARGIN dwords in front of the end of the
 // input, so that every bit consumed below is a real bit; batches: see "speculative end" in brx_kernels.hip), a ragged first flush
 // block, extra-bit fields wider than the window, and the block switches the loop does not take itself: a block type / block count
@@ -2190,16 +2190,50 @@
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
 
-// ---- a copy of 65..512 bytes at a distance >= 64: 64-byte chunks, each read (ring or the stream's own HBM output), waited
-// for and written before the next one.  Anything longer or closer goes to the C++ side (1 KiB steps, periodic fills).
+// ---- a copy of 65..512 bytes: 64-byte chunks, each read (ring or the stream's own HBM output), waited for and written before
+// the next one (a distance below 64: see below).  Anything longer goes to the C++ side (1 KiB steps, periodic fills).
 .Lcopy_long:
     s_min_u32 T0, MBLEFT, 512
     s_cmp_gt_u32 CPY, T0
     s_cbranch_scc1 .Lx_r2
-    s_cmp_lt_u32 DIST, 64
-    s_cbranch_scc1 .Lx_r2
     s_call_b64 LINKB, .Lland
     s_mov_b32 T5, CPY                                   // bytes left
+    s_cmp_lt_u32 DIST, 64
+    s_cbranch_scc0 .Lcl_chunk
+    // Round 6: 65..512 bytes at a distance below 64 -- a run, a short period ("=====", zeros, a repeated record) -- used to leave for
+    // the C++ side (one such copy is a third of what a 400-byte stream like monkey spends outside this loop).  The first 64 bytes
+    // go as in .Lcopy_overlap (lane mod distance from the final bytes in the ring); from then on ANY multiple of the period that
+    // is >= 64 serves as the distance, and the chunk loop below takes the rest: DIST << (6 - floor(log2 DIST)) lies in [64, 128).
+    // (DIST itself is free here: the ring of last distances took it at .Ldist_push_ok / gave it at .Ldist_zero, and nothing
+    // leaves through an exit that reports it before the next distance is decoded.)
+    s_mov_b64 exec, -1
+    v_mov_b32 VT0, VLANE
+    .irp k, 5, 4, 3, 2, 1, 0
+    s_lshl_b32 T2, DIST, \k
+    v_subrev_u32 VT1, T2, VT0
+    v_cmp_le_u32 vcc, T2, VT0
+    v_cndmask_b32 VT0, VT0, VT1, vcc
+    .endr
+    s_sub_u32 T1, POS, DIST
+    s_add_u32 T1, T1, SKEW
+    v_add_u32 VT0, T1, VT0
+    v_and_b32 VT0, RMASK, VT0
+    ds_read_u8 VT3, VT0
+    s_add_u32 T1, POS, SKEW
+    v_add_u32 VT0, T1, VLANE
+    v_and_b32 VT0, RMASK, VT0
+    s_waitcnt lgkmcnt(0)
+    ds_write_b8 VT0, VT3
+    s_mov_b64 exec, XLOOP
+    s_add_u32 POS, POS, 64
+    s_sub_u32 T5, T5, 64
+    s_mov_b32 PBASE, POS
+    s_flbit_i32_b32 T0, DIST                            // 31 - floor(log2 DIST)  (DIST >= 1)
+    s_sub_u32 T0, T0, 25                                // 6 - floor(log2 DIST)
+    s_lshl_b32 DIST, DIST, T0
+    s_cmp_ge_u32 POS, FLUSHAT
+    s_cbranch_scc0 .Lcl_chunk
+    s_call_b64 LINKC, .Lflush
 .Lcl_chunk:
     s_mov_b64 exec, -1
     s_min_u32 T0, T5, 64

@@ -701,8 +701,65 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
     const u32 lane = d.lane;
     u32 clv = 0; // lane sy < 18: length of code-length symbol sy
     u32 sum = 0, nonzero = 0, single = 0;
+    // Round 6: the up to 18 symbols of the fixed code, lane-parallel.  The serial loop below costs ~6 800 cycles per prefix code (a
+    // fifth of a header: profiles/r06_phases.txt); here every lane L decodes "the symbol that would start at bit L" (2 .. 4 bits),
+    // the chain 0 -> 0 + len(0) -> ... is followed by pointer doubling (five shuffles) and lane k picks hop^k(0) by the bits of k
+    // (five more): lane k then holds symbol k's position, length and value, a prefix sum finds where the code space fills up
+    // (the reference's `sum == 32: break` / `sum > 32: error`, src/lib.rs:700-745, decided by the FIRST symbol that gets there) and
+    // exactly the bits the serial loop would have consumed are skipped.  Chains that leave the 64 lanes (more than ~15 four-bit
+    // symbols: lengths 1 and 5 throughout) take the serial loop.
+    bool parallel_done = false;
+    {
+        const u32 w0 = hb_word(d, d.ww), w1 = hb_word(d, d.ww + 1u);
+        const u64 lo = d.nav < 64u ? (d.win | ((u64)w0 << d.nav)) : d.win;
+        const u64 hi = ((u64)w0 >> (64u - d.nav)) | ((u64)w1 << (d.nav - 32u));
+        const u32 p = (u32)((lo >> lane) | (lane ? hi << ((64u - lane) & 63u) : 0ull)) & 15u;
+        // fixed code (src/lib.rs:120-125), stream order: 00->0 01->3 10->4 110->2 1110->1 1111->5 -- selects, no per-lane branch
+        const u32 len = (p & 1u) == 0u ? 2u : (p & 2u) == 0u ? 2u : (p & 4u) == 0u ? 3u : 4u;
+        const u32 val = (p & 1u) == 0u ? ((p & 2u) ? 3u : 0u) : (p & 2u) == 0u ? 4u : (p & 4u) == 0u ? 2u : ((p & 8u) ? 5u : 1u);
+        const u32 lv = len | (val << 4);
+        const u32 nx = lane + len;
+        const u32 j1 = nx < 63u ? nx : 63u;
+        const u32 j2 = (u32)__shfl((int)j1, (int)j1), j4 = (u32)__shfl((int)j2, (int)j2), j8 = (u32)__shfl((int)j4, (int)j4),
+                  j16 = (u32)__shfl((int)j8, (int)j8);
+        u32 pos = 0; // lane k: hop^k(0) -- every lane shuffles at every step, the select keeps what its k wants
+        {
+            const u32 t1 = (u32)__shfl((int)j1, (int)pos); pos = (lane & 1u) ? t1 : pos;
+            const u32 t2 = (u32)__shfl((int)j2, (int)pos); pos = (lane & 2u) ? t2 : pos;
+            const u32 t4 = (u32)__shfl((int)j4, (int)pos); pos = (lane & 4u) ? t4 : pos;
+            const u32 t8 = (u32)__shfl((int)j8, (int)pos); pos = (lane & 8u) ? t8 : pos;
+            const u32 t16 = (u32)__shfl((int)j16, (int)pos); pos = (lane & 16u) ? t16 : pos;
+        }
+        const u32 mine = (u32)__shfl((int)lv, (int)pos); // symbol k = lane: len | val << 4, at bit `pos`
+        const u32 n = 18u - hskip;
+        const u32 myval = lane < n ? mine >> 4 : 0u, mylen = mine & 15u;
+        const u32 space = myval ? 32u >> myval : 0u;
+        const u32 sc = row_scan_add(space);
+        const u32 cum = lane >= 16u ? sc + rdl(sc, 15) : sc; // (18 lanes: two DPP rows)
+        const u64 hit = ballot(lane < n && cum >= 32u);
+        const u32 count = hit ? (u32)__builtin_ctzll(hit) + 1u : n;
+        const u32 last_end = rdl(pos + mylen, count - 1u);
+        if (last_end <= 60u) { // (every position that mattered is a real lane: nothing was clamped)
+            sum = rdl(cum, count - 1u);
+            const u64 nzm = ballot(lane < count && myval != 0u);
+            nonzero = (u32)__builtin_popcountll(nzm);
+            // transmission index i -> symbol: 1,2,3,4,0,5,17,6,16,7,8,...,15; its inverse for lane sy
+            const u32 inv = lane == 0u ? 4u : lane <= 4u ? lane - 1u : lane == 5u ? 5u : lane == 6u ? 7u : lane == 16u ? 8u : lane == 17u ? 6u : lane + 2u;
+            const u32 k = inv - hskip; // (wraps for inv < hskip: then >= count)
+            const u32 got = (u32)__shfl((int)myval, (int)(k & 63u));
+            clv = (lane < 18u && k < count) ? got : 0u;
+            if (nzm) {
+                const u32 kl = 63u - (u32)__builtin_clzll(nzm), il = hskip + kl;
+                single = il < 4u ? il + 1u : il == 4u ? 0u : il == 5u ? 5u : il == 6u ? 17u : il == 7u ? 6u : il == 8u ? 16u : il - 2u;
+            }
+            hb_skip(d, last_end > 32u ? 32u : last_end);
+            if (last_end > 32u) hb_skip(d, last_end - 32u);
+            if (sum > 32u) return ST_CODE_LENGTHS_CHECKSUM;
+            parallel_done = true;
+        }
+    }
     // order of transmission: 1,2,3,4,0,5,17,6,16,7,8,...,15 (src/lib.rs:669)
-    for (u32 i = hskip; i < 18u; i++) {
+    for (u32 i = hskip; i < 18u && !parallel_done; i++) {
         // fixed code (src/lib.rs:120-125), stream order: 00->0 01->3 10->4 110->2 1110->1 1111->5
         const u32 p = hb_peek(d) & 15u;
         u32 len, val;
@@ -2713,6 +2770,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                         // not see this state: "bits left" = end - cursor wraps, and it would decode zeros to the end of the meta-block at
                         // ~3 000 cycles a symbol: that, not the redo, was most of a cut stream's time)
                         if (spec && have_ck && get64(s, 3) > get64(s, 5)) break;
+                        // (the loop left because the meta-block is complete -- R1 with nothing left: the C++ side would load the whole state
+                        // only to find that out; ~8 k cycles per meta-block, 2 - 4 % of a stream flushed every KiB)
+                        if ((r & 3u) == 1u && rfl(s.mbw[MBW_MBLEFT]) == 0u) { st = ST_OK; break; }
                         // (bit 4 of the exit word: "the cursor is at the poison point, the loop would only hand straight back" -- true of the
                         // last one; behind the first one the loop goes on, with the checkpoint taken)
                         st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | (((r & 16u) && !stage1) ? HC_TO_END : 0u));

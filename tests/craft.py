@@ -905,13 +905,28 @@ def takeback_stream(seed, units, commands, mode=2, wbits=22):
             b.put(*code_bits(iacs, sym))
             b.put(*ie)
             b.put(*ce)
-            for _ in range(n):
-                p1 = out[-1] if len(out) >= 1 else 0
-                p2 = out[-2] if len(out) >= 2 else 0
-                t = trees[cmap[context_id(mode, p1, p2)]]
-                s = rng.choice(t)
-                b.put(*code_bits(t, s))
-                out.append(s)
+            if mode == 0 and n >= 4096:
+                # (fast path for the hundreds of thousands of literals of one insert: a literal costs one bit under either tree -- its
+                # index in the tree -- so the bits are random bits, and the bytes follow from a 64 x 2 table of the LSB6 context)
+                import numpy as np
+                raw = rng.randbytes((n + 7) // 8)
+                bits = np.unpackbits(np.frombuffer(raw, dtype=np.uint8), bitorder="little")[:n].tolist()
+                tab = [(trees[cmap[c]][0], trees[cmap[c]][1]) for c in range(64)]
+                p1 = out[-1] if out else 0
+                run = bytearray(n)
+                for k, bit in enumerate(bits):
+                    p1 = tab[p1 & 63][bit]
+                    run[k] = p1
+                out += run
+                b.put(int.from_bytes(raw, "little") & ((1 << n) - 1), n)
+            else:
+                for _ in range(n):
+                    p1 = out[-1] if len(out) >= 1 else 0
+                    p2 = out[-2] if len(out) >= 2 else 0
+                    t = trees[cmap[context_id(mode, p1, p2)]]
+                    s = rng.choice(t)
+                    b.put(*code_bits(t, s))
+                    out.append(s)
             dcode, dn, dx = _explicit_distance(d)
             b.put(*code_bits(dists, dcode))
             b.put(dx, dn)

@@ -1952,14 +1952,24 @@ def test_generated_streams_through_the_bounded_reader(ctx):
 
 
 # ---- round 6 ---------------------------------------------------------------------------------------------------------------------
+_TAKEBACK = []
+
+
+def _takeback_input_stream():
+    if not _TAKEBACK:  # (made once for both parameters: 19 M literals)
+        import craft
+        _TAKEBACK.append(craft.takeback_stream(6, 16, [(1200000, 4, 3000), (6, 2, 1500)], mode=0))
+    return _TAKEBACK[0]
+
+
 @pytest.mark.parametrize("loop", [0, 6])
 def test_command_taken_back_under_a_reader_gets_its_ring_back(loop):
     """ADVICE r5 (high).  A command of the C++ loop inserts its literals BEFORE its copy finds no room behind the output window, or
     its next field no resident input; the bounded reader takes such a command back (Lds::st restored) and runs it again later.  An
     insert of 2 046 bytes or more has by then overwritten the LDS ring slots of the bytes in front of the command -- the two context
     bytes its first literals choose their literal tree by.  Two literal trees over disjoint symbols, so a wrong tree is a wrong byte:
-    (a) 5 000 literals, then a copy of 7 MiB + 5 (more than the room behind a full window: BrxResume::need_room); (b) 300 000
-    literals of one bit each (37 KB of input: more than the reader's 32 KiB margin under a 1 MiB window) straddling the end of the
+    (a) 5 000 literals, then a copy of 7 MiB + 5 (more than the room behind a full window: BrxResume::need_room); (b) 1 200 000
+    literals of one bit each (150 KB of input: several times the reader's 32 KiB margin under a 1 MiB window) straddling the end of the
     resident input.  Both with the default loop and with every meta-block in the C++ loop (command_loop = 6)."""
     import craft
     from brotli_rs_amd import brx
@@ -1973,8 +1983,8 @@ def test_command_taken_back_under_a_reader_gets_its_ring_back(loop):
         assert len(got) == len(want) and got == want
         assert c2.stream_regrown() > before
         c2.set_option("reader_window", 1 << 20)
-        s, want = craft.takeback_stream(6, 30, [(300000, 4, 3000), (6, 2, 1500)], mode=0)
-        assert len(s) > (1 << 20) + (1 << 16)  # (the 1 MiB window ends inside a 37 KB literal run)
+        s, want = _takeback_input_stream()
+        assert len(s) > (2 << 20)  # (16 inserts of 150 KB of input each: the 1 MiB window ends inside one whatever the slices do)
         before = c2.stream_short_slices()
         d = brx.Decompressor(io.BytesIO(s), c2, streaming=True)
         got = d.read()
@@ -2129,7 +2139,8 @@ def test_reader_makes_room_for_a_whole_meta_block(ctx):
     (window + meta-block), and the loop runs it.  24 MiB of text in two meta-blocks of 16 MiB / 8 MiB: bit-exact, and the pause is counted."""
     from brotli_rs_amd import brx
     corpus = _read("lcet10.txt") + _read("plrabn12.txt") + _read("alice29.txt")
-    src = (corpus * 20)[:24 << 20]
+    src = (corpus * 30)[:24 << 20]
+    assert len(src) == 24 << 20
     comp = ctx.generate_batch([src], metablock_bytes=1 << 24, adaptive=True)[0]
     before = ctx.stream_regrown()
     d = brx.Decompressor(io.BytesIO(comp), ctx, streaming=True)
@@ -2137,3 +2148,44 @@ def test_reader_makes_room_for_a_whole_meta_block(ctx):
     d.close()
     assert len(got) == len(src) and got == src
     assert ctx.stream_regrown() > before
+
+
+@pytest.mark.parametrize("build", [0, 1])
+def test_runs_and_short_periods_stay_in_the_assembly_loop(build):
+    """Round 6: copies of 65 .. 512 bytes at a distance below 64 (runs, short periods) are taken inside the assembly loop -- first 64
+    bytes by lane mod distance, the rest in 64-byte chunks at a power-of-two multiple of the period -- instead of leaving for the C++
+    side.  Every distance 1 .. 63 with lengths around the chunk boundaries, a few literals in between (so that pending lanes, ring
+    wrap and flush blocks fall everywhere), in several streams with different output alignments; both builds of the loop."""
+    import craft
+    c2 = brx_knobs.context(0, loop_build=build)
+    try:
+        streams, want = [], []
+        for seed in range(6):
+            rng = random.Random(900 + seed)
+            cmds, out = [], bytearray()
+            first = bytes(rng.randrange(256) for _ in range(64 + seed))
+            cmds.append((first, 2, 1))
+            out += first + first[-1:] * 2
+            dists = list(range(1, 64))
+            rng.shuffle(dists)
+            for d in dists:
+                for L in rng.sample([65, 66, 100, 127, 128, 129, 191, 192, 193, 300, 448, 511, 512], 3):
+                    lits = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 9)))
+                    out += lits
+                    cmds.append((lits, L, d))
+                    period = bytes(out[-d:])
+                    out += (period * (L // d + 1))[:L]
+            b = craft.Bits()
+            craft.stream_header(b, 22)
+            craft.MetaBlock(cmds, mlen=len(out)).emit(b, True, len(out))
+            s = b.bytes()
+            st, o = oracle.decode(s, 0, cap=len(out) + 64)
+            assert st == 0 and o == bytes(out)
+            streams.append(s)
+            want.append(bytes(out))
+        caps = [len(w) + 16 + 7 * i for i, w in enumerate(want)]  # (different slot alignments)
+        outs, status, out_len = c2.decode_batch(streams * 3, caps * 3)
+        assert [int(x) for x in status] == [0] * len(outs)
+        assert all(o == want[i % len(want)] for i, o in enumerate(outs))
+    finally:
+        c2.close()
