@@ -53,6 +53,9 @@ WORKLOADS = {
     "text64k_q11x4096": (["enc:e042_text64k", "enc:e043_text64k", "enc:e051_text64k", "enc:e062_text64k"], 4096),
     # 40 KB of text at quality 0 .. 4 (what a server compressing on the fly emits): ONE literal tree, no contexts, literal-heavy
     "text40k_lowqx4096": (["enc:e000_text40k", "enc:e001_text40k", "enc:e002_text40k", "enc:e004_text40k"], 4096),
+    # streams FLUSHED every KiB or so (an encoder behind a chatty protocol): a third of their time is meta-block headers
+    "flush1k_textx4096": (["enc:e046_text64k"], 4096),
+    "flush1k_mixedx4096": (["enc:e093_mixed"], 4096),
     # small streams (a launch of many short messages): 47 / 69 / 425 compressed bytes
     "quickfoxx16384": (["quickfox"], 16384),
     "ukkonooax16384": (["ukkonooa"], 16384),

@@ -2190,6 +2190,35 @@
     s_mov_b32 PBASE, POS
     s_branch .Lcopy_tail
 
+// min(T5, 64) bytes of a periodic copy at POS: byte i = period[(\off + i) mod DIST], period = the DIST < 64 final bytes at ring
+// coordinate T3 (lane mod distance by binary long division, as .Lcopy_overlap).  EXEC = all lanes; the lanes beyond the count redo
+// its last byte.  Moves POS and T5; clobbers T0 - T2, VT0 - VT3, vcc.
+.macro PERIOD_CHUNK off
+    s_min_u32 T0, T5, 64
+    s_sub_u32 T1, T0, 1
+    v_min_u32 VT2, T1, VLANE
+    .if \off
+    v_add_u32 VT0, \off, VT2
+    .else
+    v_mov_b32 VT0, VT2
+    .endif
+    .irp k, 6, 5, 4, 3, 2, 1, 0
+    s_lshl_b32 T2, DIST, \k
+    v_subrev_u32 VT1, T2, VT0
+    v_cmp_le_u32 vcc, T2, VT0
+    v_cndmask_b32 VT0, VT0, VT1, vcc
+    .endr
+    v_add_u32 VT0, T3, VT0
+    v_and_b32 VT0, RMASK, VT0
+    ds_read_u8 VT3, VT0
+    s_add_u32 T1, POS, SKEW
+    v_add_u32 VT0, T1, VT2
+    v_and_b32 VT0, RMASK, VT0
+    s_waitcnt lgkmcnt(0)
+    ds_write_b8 VT0, VT3
+    s_add_u32 POS, POS, T0
+    s_sub_u32 T5, T5, T0
+.endm
 // ---- a copy of 65..512 bytes: 64-byte chunks, each read (ring or the stream's own HBM output), waited for and written before
 // the next one (a distance below 64: see below).  Anything longer goes to the C++ side (1 KiB steps, periodic fills).
 .Lcopy_long:
@@ -2200,40 +2229,34 @@
     s_mov_b32 T5, CPY                                   // bytes left
     s_cmp_lt_u32 DIST, 64
     s_cbranch_scc0 .Lcl_chunk
+#ifdef BRX_NO_PERIOD_COPY
+    s_branch .Lx_r2
+#endif
     // Round 6: 65..512 bytes at a distance below 64 -- a run, a short period ("=====", zeros, a repeated record) -- used to leave for
-    // the C++ side (one such copy is a third of what a 400-byte stream like monkey spends outside this loop).  The first 64 bytes
-    // go as in .Lcopy_overlap (lane mod distance from the final bytes in the ring); from then on ANY multiple of the period that
-    // is >= 64 serves as the distance, and the chunk loop below takes the rest: DIST << (6 - floor(log2 DIST)) lies in [64, 128).
-    // (DIST itself is free here: the ring of last distances took it at .Ldist_push_ok / gave it at .Ldist_zero, and nothing
-    // leaves through an exit that reports it before the next distance is decoded.)
+    // the C++ side (one such copy is a third of what a 400-byte stream like monkey spends outside this loop).  The first 128 bytes
+    // go as in .Lcopy_overlap, (offset + lane) mod distance from the final bytes in the ring; from then on ANY multiple of the
+    // period between 64 and the bytes written so far serves as the distance, and the chunk loop below takes the rest:
+    // DIST << (6 - floor(log2 DIST)) lies in [64, 128).  (Not after 64 bytes already: the smallest POWER-OF-TWO multiple can exceed
+    // 64 + DIST -- 31 -> 124 -- and would read in front of the period.)  DIST itself is free here: the ring of last distances took
+    // it at .Ldist_push_ok / gave it at .Ldist_zero, and nothing leaves through an exit that reports it before the next distance
+    // is decoded.
     s_mov_b64 exec, -1
-    v_mov_b32 VT0, VLANE
-    .irp k, 5, 4, 3, 2, 1, 0
-    s_lshl_b32 T2, DIST, \k
-    v_subrev_u32 VT1, T2, VT0
-    v_cmp_le_u32 vcc, T2, VT0
-    v_cndmask_b32 VT0, VT0, VT1, vcc
-    .endr
-    s_sub_u32 T1, POS, DIST
-    s_add_u32 T1, T1, SKEW
-    v_add_u32 VT0, T1, VT0
-    v_and_b32 VT0, RMASK, VT0
-    ds_read_u8 VT3, VT0
-    s_add_u32 T1, POS, SKEW
-    v_add_u32 VT0, T1, VLANE
-    v_and_b32 VT0, RMASK, VT0
-    s_waitcnt lgkmcnt(0)
-    ds_write_b8 VT0, VT3
+    s_sub_u32 T3, POS, DIST
+    s_add_u32 T3, T3, SKEW                              // skewed ring coordinate of the period's first byte
+    PERIOD_CHUNK 0
+    PERIOD_CHUNK 64                                     // (CPY > 64: at least one byte)
     s_mov_b64 exec, XLOOP
-    s_add_u32 POS, POS, 64
-    s_sub_u32 T5, T5, 64
     s_mov_b32 PBASE, POS
     s_flbit_i32_b32 T0, DIST                            // 31 - floor(log2 DIST)  (DIST >= 1)
     s_sub_u32 T0, T0, 25                                // 6 - floor(log2 DIST)
     s_lshl_b32 DIST, DIST, T0
     s_cmp_ge_u32 POS, FLUSHAT
-    s_cbranch_scc0 .Lcl_chunk
+    s_cbranch_scc0 .Lcp_noflush
     s_call_b64 LINKC, .Lflush
+.Lcp_noflush:
+    s_cmp_lg_u32 T5, 0
+    s_cbranch_scc1 .Lcl_chunk
+    s_branch .Lflush_back_cmd
 .Lcl_chunk:
     s_mov_b64 exec, -1
     s_min_u32 T0, T5, 64

@@ -709,6 +709,7 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
     // exactly the bits the serial loop would have consumed are skipped.  Chains that leave the 64 lanes (more than ~15 four-bit
     // symbols: lengths 1 and 5 throughout) take the serial loop.
     bool parallel_done = false;
+#ifndef BRX_NO_PAR_CLCODE
     {
         const u32 w0 = hb_word(d, d.ww), w1 = hb_word(d, d.ww + 1u);
         const u64 lo = d.nav < 64u ? (d.win | ((u64)w0 << d.nav)) : d.win;
@@ -758,6 +759,7 @@ FI u32 read_complex_lens(Dec &d, Lds &s, u32 hskip, u32 alphabet) {
             parallel_done = true;
         }
     }
+#endif
     // order of transmission: 1,2,3,4,0,5,17,6,16,7,8,...,15 (src/lib.rs:669)
     for (u32 i = hskip; i < 18u && !parallel_done; i++) {
         // fixed code (src/lib.rs:120-125), stream order: 00->0 01->3 10->4 110->2 1110->1 1111->5
@@ -2772,7 +2774,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                         if (spec && have_ck && get64(s, 3) > get64(s, 5)) break;
                         // (the loop left because the meta-block is complete -- R1 with nothing left: the C++ side would load the whole state
                         // only to find that out; ~8 k cycles per meta-block, 2 - 4 % of a stream flushed every KiB)
+#ifndef BRX_NO_SKIP_END
                         if ((r & 3u) == 1u && rfl(s.mbw[MBW_MBLEFT]) == 0u) { st = ST_OK; break; }
+#endif
                         // (bit 4 of the exit word: "the cursor is at the poison point, the loop would only hand straight back" -- true of the
                         // last one; behind the first one the loop goes on, with the checkpoint taken)
                         st = generic_commands((HC_RESUME_R0 + ((r & 3u) > 2u ? 1u : (r & 3u))) | (((r & 16u) && !stage1) ? HC_TO_END : 0u));

@@ -859,7 +859,7 @@ def periodic_stream_parts(seed, commands=700, literals=90, raw=False, single_iac
     return prefix, b.bytes(), b"\x03", bytes(out)
 
 
-def takeback_stream(seed, units, commands, mode=2, wbits=22):
+def takeback_stream(seed, units, commands, mode=2, wbits=22, tree_syms=2):
     """Round 6: streams for the bounded reader's take-back paths.  `units` compressed meta-blocks, each with TWO literal
     trees over disjoint symbol pairs behind a context map (so every output byte tells which context the decoder computed: a literal
     decoded under the wrong tree is a wrong byte) and the same `commands`: (number of literals, copy length, distance) with explicit
@@ -879,8 +879,8 @@ def takeback_stream(seed, units, commands, mode=2, wbits=22):
     mlen = sum(n + c for n, c, d in commands)
     nib = 4 if mlen <= 1 << 16 else 5 if mlen <= 1 << 20 else 6
     for u in range(units):
-        trees = [sorted(rng.sample(range(256), 2)), None]
-        trees[1] = sorted(rng.sample([x for x in range(256) if x not in trees[0]], 2))
+        trees = [sorted(rng.sample(range(256), tree_syms)), None]  # (4 symbols: two bits per literal -- a compression ratio of 4)
+        trees[1] = sorted(rng.sample([x for x in range(256) if x not in trees[0]], tree_syms))
         cmap = [rng.randrange(2) for _ in range(64)]
         b.put(0, 1)            # ISLAST = 0
         b.put(nib - 4, 2)
@@ -909,16 +909,18 @@ def takeback_stream(seed, units, commands, mode=2, wbits=22):
                 # (fast path for the hundreds of thousands of literals of one insert: a literal costs one bit under either tree -- its
                 # index in the tree -- so the bits are random bits, and the bytes follow from a 64 x 2 table of the LSB6 context)
                 import numpy as np
-                raw = rng.randbytes((n + 7) // 8)
-                bits = np.unpackbits(np.frombuffer(raw, dtype=np.uint8), bitorder="little")[:n].tolist()
-                tab = [(trees[cmap[c]][0], trees[cmap[c]][1]) for c in range(64)]
+                w = 1 if tree_syms == 2 else 2  # bits per literal; the field of sorted index i is i (two symbols) / i bit-reversed (four)
+                raw = rng.randbytes((n * w + 7) // 8)
+                bits = np.unpackbits(np.frombuffer(raw, dtype=np.uint8), bitorder="little")[:n * w]
+                idx = (bits if w == 1 else bits[0::2] * 2 + bits[1::2]).tolist()  # (first stream bit = the code's MSB)
+                tab = [tuple(trees[cmap[c]]) for c in range(64)]
                 p1 = out[-1] if out else 0
                 run = bytearray(n)
-                for k, bit in enumerate(bits):
-                    p1 = tab[p1 & 63][bit]
+                for k, i in enumerate(idx):
+                    p1 = tab[p1 & 63][i]
                     run[k] = p1
                 out += run
-                b.put(int.from_bytes(raw, "little") & ((1 << n) - 1), n)
+                b.put(int.from_bytes(raw, "little") & ((1 << (n * w)) - 1), n * w)
             else:
                 for _ in range(n):
                     p1 = out[-1] if len(out) >= 1 else 0

@@ -1956,9 +1956,9 @@ _TAKEBACK = []
 
 
 def _takeback_input_stream():
-    if not _TAKEBACK:  # (made once for both parameters: 19 M literals)
+    if not _TAKEBACK:  # (made once for both parameters: 10 M literals)
         import craft
-        _TAKEBACK.append(craft.takeback_stream(6, 16, [(1200000, 4, 3000), (6, 2, 1500)], mode=0))
+        _TAKEBACK.append(craft.takeback_stream(6, 16, [(600000, 4, 3000), (6, 2, 1500)], mode=0, tree_syms=4))
     return _TAKEBACK[0]
 
 
@@ -1968,9 +1968,9 @@ def test_command_taken_back_under_a_reader_gets_its_ring_back(loop):
     its next field no resident input; the bounded reader takes such a command back (Lds::st restored) and runs it again later.  An
     insert of 2 046 bytes or more has by then overwritten the LDS ring slots of the bytes in front of the command -- the two context
     bytes its first literals choose their literal tree by.  Two literal trees over disjoint symbols, so a wrong tree is a wrong byte:
-    (a) 5 000 literals, then a copy of 7 MiB + 5 (more than the room behind a full window: BrxResume::need_room); (b) 1 200 000
-    literals of one bit each (150 KB of input: several times the reader's 32 KiB margin under a 1 MiB window) straddling the end of the
-    resident input.  Both with the default loop and with every meta-block in the C++ loop (command_loop = 6)."""
+    (a) 5 000 literals, then a copy of 7 MiB + 5 (more than the room behind a full window: BrxResume::need_room); (b) 600 000
+    literals of two bits each (150 KB of input: several times the reader's 32 KiB margin under a 1 MiB window; a ratio of 4, so that a
+    slice meets the end of the resident input before it has its 4 MiB of output) straddling the end of the resident input.  Both with the default loop and with every meta-block in the C++ loop (command_loop = 6)."""
     import craft
     from brotli_rs_amd import brx
     c2 = brx_knobs.context(0, command_loop=loop)
@@ -1984,7 +1984,7 @@ def test_command_taken_back_under_a_reader_gets_its_ring_back(loop):
         assert c2.stream_regrown() > before
         c2.set_option("reader_window", 1 << 20)
         s, want = _takeback_input_stream()
-        assert len(s) > (2 << 20)  # (16 inserts of 150 KB of input each: the 1 MiB window ends inside one whatever the slices do)
+        assert len(s) > (2 << 20)  # (16 inserts of 150 KB of input each)
         before = c2.stream_short_slices()
         d = brx.Decompressor(io.BytesIO(s), c2, streaming=True)
         got = d.read()
