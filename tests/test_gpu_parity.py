@@ -398,7 +398,9 @@ def test_pulled_reader_holds_a_window_of_input_and_of_output(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     f = out.stdout.split()
     assert int(f[2]) == K * len(parts[3]), out.stdout
-    assert float(f[4]) < 64.0 and float(f[6]) - float(f[10]) < 16.0, out.stdout  # device peak; host growth over the stream
+    if not os.environ.get("BRX_SUITE_CONCURRENT"):  # (the device peak is read from the GPU's free memory: two other suites allocate next to this one)
+        assert float(f[4]) < 64.0, out.stdout  # device peak
+    assert float(f[6]) - float(f[10]) < 16.0, out.stdout  # host growth over the stream
     out = subprocess.run([exe] + names + [str(K), str(50 * len(parts[1]) + 777)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK error after" in out.stdout, out.stdout + out.stderr
     assert int(out.stdout.split()[3]) >= 49 * len(parts[3])  # (the prefix: at least every whole unit before the cut, bar the last)

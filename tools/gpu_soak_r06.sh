@@ -12,7 +12,7 @@ mkdir -p gpurun_out /tmp/soak
 run() {  # run "<env>" tool args...  -> one summary line
   local env="$1"; shift
   local tag="$(echo "$env $*" | tr ' =/' '___')"
-  ( env $env timeout 900 python tools/$1.py "${@:2}" > /tmp/soak/$tag.log 2>&1; echo "== $env $* :: $(grep -i 'mismatch' /tmp/soak/$tag.log | tail -2 | tr '\n' ' ') rc=$?" >> $O ) &
+  ( env $env timeout 900 python tools/$1.py "${@:2}" > /tmp/soak/$tag.log 2>&1; rc=$?; echo "== $env $* :: $(grep -i 'mismatch' /tmp/soak/$tag.log | tail -2 | tr '\n' ' ') rc=$rc" >> $O ) &
 }
 for SEED in ${1:-701 702}; do
   run "X=1" reader_fuzz 8 $SEED; run "X=1" reader_fuzz 8 $((SEED + 50)); run "X=1" reader_fuzz 8 $((SEED + 100)); wait
