@@ -860,7 +860,7 @@ def main():
                 res["copy_path"] = copy_path(torch, np, dev, ctx, barrier)
             except Exception as e:  # never takes the headline down with it
                 res["copy_path"] = {"error": repr(e)[:200]}
-        if not args.no_configs and world == 1 and args.workload == "alice29x4096":
+        if not args.no_configs and world == 1 and args.workload == "alice29x4096" and not under_profiler():  # (under rocprofv3 the kernel statistics must be the headline's alone)
             try:
                 res["configs"] = other_configs(torch, np, dev, ctx, barrier, with_traffic=not args.no_traffic and not under_profiler())
             except Exception as e:

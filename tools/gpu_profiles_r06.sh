@@ -20,14 +20,14 @@ echo "== residency of the mixed batches (plan B)"
 cd /tmp && export TMPDIR=/tmp
 for wl in $WLS; do
   rm -rf /tmp/kt
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o t -- python $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --verify 0 > /tmp/kt.log 2>/dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o t -- python $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --no-configs --verify 0 > /tmp/kt.log 2>/dev/null
   tail -1 /tmp/kt.log > $O/bench_${TAG}_${wl}_under_rocprof.json
   f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv
 done
 for wl in alice29x4096 config5_1MiBx1024 gen_c5x1024 lcet10x4096 farcopy_1MiBx4096 backward65536x4096 quickfox_repeatedx8192; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
-    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --verify 0 > /dev/null 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --no-configs --verify 0 > /dev/null 2>&1
   done
   python3 - $wl $TAG <<'PY'
 import csv,sys,glob,json,os
@@ -48,7 +48,7 @@ echo "== SQ counters, alice29 x 4096"
 : > $O/${TAG}_pmc.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS"; do
   rm -rf /tmp/pmc_out
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_out -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --verify 0 > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_out -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-copy-path --no-chain-floor --no-configs --verify 0 > /dev/null 2>&1
   python3 - <<'PY' | tee -a $O/${TAG}_pmc.txt
 import csv,glob,collections
 agg=collections.defaultdict(float); disp=collections.defaultdict(set)
