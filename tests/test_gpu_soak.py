@@ -110,4 +110,9 @@ def test_parity_suite_again_under_forced_knobs():
             continue
         if p.returncode != 0:
             failed.append((knob, p.returncode, out[-3000:] + err[-1000:]))
+            try:  # (the assertion's repr cuts the text short: the whole log goes where gpurun brings it back from)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                open(os.path.join(ROOT, "gpurun_out", "forced_knob_%s.log" % knob.replace("=", "_")), "w").write(out + "\n---- stderr ----\n" + err)
+            except OSError:
+                pass
     assert not failed, failed
