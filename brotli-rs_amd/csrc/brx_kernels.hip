@@ -1688,11 +1688,16 @@ __device__ __noinline__ u32 asm_commands_sw() {
 //   mode 1 MSB6:   info = (p >> 2) << 2                MA 0xfc MB 0    SB 0
 //   mode 2 UTF8:   info = Lut0[p] << 2 | Lut1[p]       MA 0xfc MB 3    SB 2
 //   mode 3 signed: info = Lut2[p] << 5 | Lut2[p] << 2  MA 0xe0 MB 0x1c SB 0
-FI u32 context_info(const u8 *lut, u32 mode, u32 b) {
+// (round 6: the three 256-byte LUTs sit across the lanes of the wave constants v_lut0 .. 2 -- lane l = bytes 4l .. 4l + 3 -- so a
+// PER-LANE byte index is one shuffle instead of a load from global memory: the four steps over a literal tree's 256 entries waited
+// ~1 us each for those loads, most of what HC_START cost a meta-block)
+FI u32 lut_lane(u32 vec, u32 b) { return ((u32)__shfl((int)vec, (int)(b >> 2)) >> ((b & 3u) * 8u)) & 0xffu; }
+FI u32 context_info(const Dec &d, u32 mode, u32 b) { // mode wave-uniform, b per lane (< 256); every lane must be active
     if (mode == 0u) return (b & 63u) << 2;
     if (mode == 1u) return (b >> 2) << 2;
-    if (mode == 2u) return ((u32)lut[b] << 2) | (u32)lut[256u + b];
-    return ((u32)lut[512u + b] << 5) | ((u32)lut[512u + b] << 2);
+    if (mode == 2u) return (lut_lane(d.v_lut0, b) << 2) | lut_lane(d.v_lut1, b);
+    const u32 l2 = lut_lane(d.v_lut2, b);
+    return (l2 << 5) | (l2 << 2);
 }
 // Payload form of one distance symbol (decode_distance, src/lib.rs:1412-1481).  A symbol whose base does not fit (only
 // distances far beyond any window: 24 extra bits and more) becomes BRX_DIST_UNFIT | code: the assembly loop hands such
@@ -1714,7 +1719,6 @@ FI u32 distance_payload(u32 code, u32 npostfix, u32 ndirect) {
 // Always true since round 5 (the one shape that had no payload form -- a ONE-symbol distance tree whose symbol is not a last-distance
 // code: its 16-bit slot in the info word cannot hold a base -- is materialised as a table, below).
 FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mode, bool uniform) {
-    const u8 *lut = (const u8 *)d.t_lut;
     for (u32 t = 0; t < m.ntd; t++) {
         const u32 h = rfl(s.tm[m.hd + t]);
         const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
@@ -1765,14 +1769,17 @@ FI bool prepare_fast_tables(const Dec &d, Lds &s, const MB &m, u32 n_iac, u32 mo
         const u32 info = rfl(s.tm[h + BRX_HDR_INFO]);
         if ((info & 3u) == 1u) { // one-symbol tree: the symbol lives in the info word
             const u32 sym = (info >> 16) & 0xffu;
-            if (d.lane == 0u) s.tm[h + BRX_HDR_INFO] = (info & 0xffffu) | ((sym | (context_info(lut, mode, sym) << 8)) << 16);
+            const u32 ci = context_info(d, mode, sym);
+            if (d.lane == 0u) s.tm[h + BRX_HDR_INFO] = (info & 0xffffu) | ((sym | (ci << 8)) << 16);
             continue;
         }
         const u32 nnz = info >> 16;
         u16 *sy = (u16 *)&s.tm[h + BRX_HDR_WORDS];
-        for (u32 k = d.lane; k < nnz; k += 64u) {
-            const u32 sym = sy[k] & 0xffu;
-            sy[k] = (u16)(sym | (context_info(lut, mode, sym) << 8));
+        for (u32 k0 = 0; k0 < nnz; k0 += 64u) { // (uniform trip count: the shuffles of context_info want every lane)
+            const u32 k = k0 + d.lane;
+            const u32 sym = (k < nnz ? sy[k] : 0u) & 0xffu;
+            const u32 ci = context_info(d, mode, sym);
+            if (k < nnz) sy[k] = (u16)(sym | (ci << 8));
         }
     }
     return true;
