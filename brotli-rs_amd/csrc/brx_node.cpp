@@ -302,7 +302,7 @@ int decode_host(brx_node *nd, const uint8_t *in, const uint64_t *in_off, uint32_
             std::vector<int32_t> st(m, 0);
             for (uint32_t i = 0; i < m; i++) {
                 io[i + 1] = io[i] + (in_off[idx[i] + 1] - in_off[idx[i]]);
-                oo[i + 1] = oo[i] + (((out_off[idx[i] + 1] - out_off[idx[i]]) + 15u) & ~(uint64_t)15);
+                oo[i + 1] = oo[i] + (out_off[idx[i] + 1] - out_off[idx[i]]); // (the caller's capacity EXACTLY: a slot is its stream's capacity)
             }
             k.in_bytes = io[m];
             if (grow_pinned(k.h_in, (size_t)io[m] + 16) || grow_pinned(k.h_out, (size_t)oo[m] + 16))
@@ -436,7 +436,8 @@ int decode_device(brx_node *nd, const uint8_t *in, const uint64_t *d_in_off, uin
         for (uint32_t i = 0; i < m; i++) {
             const uint32_t g = idx_of(a + i);
             io[i + 1] = io[i] + (in_off[g + 1] - in_off[g]);
-            oo[i + 1] = oo[i] + (((out_off[g + 1] - out_off[g]) + 15u) & ~(uint64_t)15);
+            oo[i + 1] = oo[i] + (out_off[g + 1] - out_off[g]); // (the caller's capacity EXACTLY: rounded up, a stream that overruns its slot by
+                                                               // a few bytes would come back with status 0 and spill into its neighbour's slot at the root)
         }
         q.src_at = permuted ? dense[a] : in_off[a];
         q.bytes = io[m];

@@ -348,7 +348,7 @@ enum {
 /* devices: n_devices HIP device indices, rank r on devices[r]; NULL / 0 = every visible GPU, one rank each.  Fails like
  * brx_ctx_create (BRX_ERR_NO_DEVICE without a GPU: there is no CPU fallback). */
 int brx_node_create(brx_node **out, const int *devices, int n_devices);
-void brx_node_destroy(brx_node *node);
+void brx_node_destroy(brx_node *node); /* (not while a call on the node is in flight on another thread) */
 int brx_node_size(const brx_node *node);
 /* The context of a rank (owned by the node): for brx_ctx_set_option / brx_last_timing on one GPU.  Do not destroy it. */
 brx_ctx *brx_node_ctx(brx_node *node, int rank);

@@ -195,6 +195,43 @@ def test_device_pointers_scatter_decode_gather_over_virtual_ranks(deal):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("deal", ["ranges", "snake"])
+def test_capacities_are_the_callers_on_every_rank(deal):
+    """A slot is its stream's capacity, whatever GPU decodes it: capacities that are no multiple of 16 and a few bytes too small must
+    give status 25 and the length needed -- not status 0 and bytes in the neighbour's slot -- exactly as one context does."""
+    node = brx.Node([0] * 3)
+    ctx = brx.Context(0)
+    try:
+        names = ("alice29.txt", "asyoulik.txt", "monkey", "ukkonooa", "x", "quickfox_repeated")
+        streams = [_read(n + ".compressed") for n in names] * 5
+        sizes = [len(_read(n)) for n in names] * 5
+        caps = [sz + (7, -1, -5, 3, 0, -13)[i % 6] for i, sz in enumerate(sizes)]
+        caps = [max(c, 0) for c in caps]
+        ref_outs, ref_status, ref_len = ctx.decode_batch(streams, caps)
+        assert 25 in list(ref_status) and 0 in list(ref_status)
+        outs, status, out_len = node.decode_batch(streams, caps, deal=deal, use_gpus=3)
+        assert list(status) == list(ref_status) and list(out_len) == list(ref_len) and outs == ref_outs
+        t, out_off = _device_batch(streams, caps)
+        # (exact capacities in the device tables too)
+        import torch
+        oo = np.zeros(len(caps) + 1, dtype=np.int64)
+        np.cumsum(caps, out=oo[1:])
+        t["out_off"] = torch.from_numpy(oo).to(t["out"].device)
+        t["out"].fill_(0xEE)
+        node.decode_batch_device(t["in"].data_ptr(), t["in_off"].data_ptr(), len(streams), t["out"].data_ptr(), t["out_off"].data_ptr(),
+                                 t["out_len"].data_ptr(), t["status"].data_ptr(), deal=deal, use_gpus=3, root=1)
+        st, ln, out = t["status"].cpu().numpy(), t["out_len"].cpu().numpy(), t["out"].cpu().numpy()
+        assert list(st) == list(ref_status) and list(ln) == [int(x) for x in ref_len]
+        for i in range(len(streams)):
+            if st[i] == 0:
+                assert out[int(oo[i]):int(oo[i]) + int(ln[i])].tobytes() == ref_outs[i], i
+        assert (out[int(oo[-1]):int(oo[-1]) + 16] == 0xEE).all()  # nothing behind the last slot
+    finally:
+        ctx.close()
+        node.close()
+
+
+@pytest.mark.gpu
 def test_rccl_exchange_at_world_size_one():
     """The RCCL leg -- librccl loaded on demand, ncclCommInitAll, grouped ncclSend / ncclRecv for the scatter and for the ragged
     gather -- on the one GPU of the box: the root's own shard travels through it (BRX_NODE_OPTION_EXCHANGE_ROOT)."""
