@@ -563,7 +563,9 @@ def node_main(args):
            "last_call_wall_ms": round(last["wall_ms"], 3), "scatter_ms": round(last["scatter_ms"], 3)}
     node.close()
     print(json.dumps(res), flush=True)
-    sys.exit(0 if ok else 2)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0 if ok else 2)  # (RCCL prints its banner to stdout from a destructor at interpreter exit: the JSON line stays the last one)
 
 
 def main():
