@@ -6,12 +6,16 @@
 // its size): capacities start at 8 x the compressed size and every stream that reports status 25 (capacity too small) is
 // decoded again, alone with the others that did, at 8 x the capacity -- the size-discovery retry of SURVEY 8f-2.
 //
-//   brx_walk <dir> [--suffix S] [--check] [--out DIR] [--quiet]
+//   brx_walk <dir> [--suffix S] [--check] [--out DIR] [--quiet] [--gpus N | --ranks d0,d1,...]
 //     --suffix S   file-name ending to look for (default "compressed", as the reference)
 //     --check      compare each output with the file named by the part before ".compressed" when it exists
 //                  (the layout of the reference's data/ directory); exit status 1 on any mismatch
 //     --out DIR    write each output to DIR/<name>.out
 //     --quiet      only the summary
+//     --gpus N     (round 6) the batch over the first N GPUs of the machine through brx_node_decode_batch -- one process, one host
+//                  thread per GPU, files dealt by compressed size (snake deal: files differ), every GPU reads / writes the pinned
+//                  buffers in place, no exchange between GPUs; --ranks 0,0,1 names the device of every rank instead (a device may
+//                  repeat: several ranks on one GPU)
 // Host code above the C ABI only: no HIP calls here, no decoding on the CPU (there is none in the library).
 #include <dirent.h>
 #include <sys/stat.h>
@@ -53,9 +57,12 @@ uint64_t align16(uint64_t v) { return (v + 15u) & ~(uint64_t)15u; }
 int main(int argc, char **argv) {
     std::string dir, suffix = "compressed", out_dir;
     bool check = false, quiet = false;
+    std::vector<int> ranks;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--suffix" && i + 1 < argc) suffix = argv[++i];
+        else if (a == "--gpus" && i + 1 < argc) { const int g = atoi(argv[++i]); for (int r = 0; r < g; r++) ranks.push_back(r); }
+        else if (a == "--ranks" && i + 1 < argc) { for (const char *p = argv[++i]; *p;) { ranks.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } }
         else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
         else if (a == "--check") check = true;
         else if (a == "--quiet") quiet = true;
@@ -83,7 +90,10 @@ int main(int argc, char **argv) {
     if (n == 0) { printf("no files ending with \"%s\" in %s\n", suffix.c_str(), dir.c_str()); return 0; }
 
     brx_ctx *ctx = nullptr;
-    if (brx_ctx_create(&ctx, 0) != BRX_SUCCESS) { fprintf(stderr, "brx_ctx_create: %s\n", brx_last_error()); return 3; }
+    brx_node *node = nullptr;
+    if (!ranks.empty()) {
+        if (brx_node_create(&node, ranks.data(), (int)ranks.size()) != BRX_SUCCESS) { fprintf(stderr, "brx_node_create: %s\n", brx_last_error()); return 3; }
+    } else if (brx_ctx_create(&ctx, 0) != BRX_SUCCESS) { fprintf(stderr, "brx_ctx_create: %s\n", brx_last_error()); return 3; }
 
     // ingest: every file straight into one pinned buffer
     std::vector<uint64_t> in_off(n + 1, 0);
@@ -125,8 +135,10 @@ int main(int argc, char **argv) {
             r_in = gathered;
         }
         brx_opts o = {BRX_MEM_HOST, 0, nullptr};
+        brx_node_opts no = {BRX_MEM_HOST, BRX_NODE_DEAL_SNAKE, (int32_t)ranks.size(), 0, nullptr};
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = brx_decode_batch(ctx, r_in, r_in_off.data(), k, arena, r_out_off.data(), r_len.data(), r_st.data(), &o);
+        const int rc = node ? brx_node_decode_batch(node, r_in, r_in_off.data(), k, arena, r_out_off.data(), r_len.data(), r_st.data(), &no)
+                            : brx_decode_batch(ctx, r_in, r_in_off.data(), k, arena, r_out_off.data(), r_len.data(), r_st.data(), &o);
         decode_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (gathered) brx_host_free(gathered);
         if (rc != BRX_SUCCESS) { fprintf(stderr, "brx_decode_batch: %s\n", brx_last_error()); return 3; }
@@ -188,14 +200,16 @@ int main(int argc, char **argv) {
             fclose(f);
         }
     }
-    printf("%u files, %u decoded, %u errors; %llu B in, %llu B out; %d batch call(s), %.2f ms in brx_decode_batch "
+    printf("%u files, %u decoded, %u errors; %llu B in, %llu B out; %d batch call(s), %.2f ms in %s "
            "(host buffers: copies included, %.1f MB/s decompressed)",
            n, n_ok, n_err, (unsigned long long)total_in, (unsigned long long)total_out, rounds, decode_ms,
-           decode_ms > 0 ? total_out / decode_ms / 1e3 : 0.0);
+           node ? "brx_node_decode_batch" : "brx_decode_batch", decode_ms > 0 ? total_out / decode_ms / 1e3 : 0.0);
+    if (node) printf("; %d ranks", (int)ranks.size());
     if (check) printf("; %u compared with their expected files, %u differ", n_checked, n_mismatch);
     printf("\n");
     for (uint8_t *a : arenas) brx_host_free(a);
     brx_host_free(in);
+    if (node) brx_node_destroy(node);
     brx_ctx_destroy(ctx);
     return n_mismatch ? 1 : 0;
 }

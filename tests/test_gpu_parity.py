@@ -778,6 +778,11 @@ def test_file_walker(ctx, tmp_path):
     assert ("res = Err(\"%s\")  [status %d]" % (brx.status_str(want[0]), want[0])) in r.stdout if want[0] else True
     assert (out / "alice29.txt.compressed.out").read_bytes() == _read("alice29.txt")
     assert (out / "backward65536.compressed.out").read_bytes() == _read("backward65536")
+    # round 6: the same walk over three (virtual) ranks of a node -- brx_node_decode_batch, files dealt by size, pinned buffers in place
+    r = subprocess.run([exe, d, "--check", "--quiet", "--ranks", "0,0,0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    summary = r.stdout.strip().splitlines()[-1]
+    assert summary.startswith("%d files, " % n_files) and " 0 differ" in summary and "brx_node_decode_batch" in summary and "3 ranks" in summary, summary
 
 
 def test_encoder_streams_batch(ctx):
