@@ -2197,3 +2197,50 @@ def test_runs_and_short_periods_stay_in_the_assembly_loop(build):
         assert all(o == want[i % len(want)] for i, o in enumerate(outs))
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("loop", [0, 6])
+def test_every_vector_through_the_pulled_reader(loop):
+    """The reference's API object is a reader over a reader (src/lib.rs:377-410): every data/ stream (43 valid, 9 rejects), every
+    inline vector of tests/lib.rs and every hand-assembled quirk stream through brx_stream_new_reader -- the resumable kernel, input
+    pulled a few bytes at a time -- must give the oracle's status, and the oracle's bytes in front of it.  (The batch path has had
+    this from round 1; the reader met the same vectors only piecemeal.)"""
+    import crafted_sets
+    from brotli_rs_amd import brx
+    c2 = brx_knobs.context(0, command_loop=loop)
+    try:
+        streams = [_read(e["stream"]) for e in MANIFEST]
+        streams += [bytes.fromhex(v["input_hex"]) if "input_hex" in v else _read(v["input_file"]) for v in INLINE]
+        streams += [s_ for _, s_, _, _ in crafted_sets.all_sets()]
+        rng = random.Random(17 + loop)
+        bad = []
+        for i, s_ in enumerate(streams):
+            want_st, want = oracle.decode(s_, 0, cap=1 << 22)[:2]
+
+            class Src(io.RawIOBase):
+                at = 0
+
+                def read(self, k=-1):
+                    k = min(k if k >= 0 else 1 << 16, rng.choice((1, 3, 64, 4096, 1 << 16)))
+                    out = s_[self.at:self.at + k]
+                    self.at += len(out)
+                    return out
+
+            d = brx.Decompressor(Src(), c2, streaming=True)
+            got, st = bytearray(), 0
+            try:
+                while True:
+                    chunk = d.read(rng.choice((1, 100, 65536)) if len(got) < 300 else 1 << 20)
+                    if not chunk:
+                        break
+                    got += chunk
+            except ValueError as e:
+                st = [k for k in range(1, 28) if brx.status_str(k) == str(e)][0]
+            d.close()
+            m = min(len(got), len(want))
+            if st != want_st or (st == 0 and bytes(got) != want) or bytes(got[:m]) != want[:m]:
+                bad.append((i, len(s_), st, want_st, len(got), len(want)))
+        assert not bad, bad[:10]
+        assert len(streams) > 120
+    finally:
+        c2.close()
