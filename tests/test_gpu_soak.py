@@ -109,6 +109,18 @@ def test_parity_suite_again_under_forced_knobs():
             failed.append((knob, "TIMEOUT", out[-1500:]))
             continue
         if p.returncode != 0:
+            # (three suites share the GPU here: a failure is taken seriously only if the knob's suite also fails ALONE)
+            name, value = knob.split("=")
+            alone = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                                   env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **{name: value}), capture_output=True, text=True, timeout=1000, cwd=ROOT)
+            if alone.returncode == 0:
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    open(os.path.join(ROOT, "gpurun_out", "forced_knob_%s_concurrent_only.log" % knob.replace("=", "_")), "w").write(out + "\n---- stderr ----\n" + err)
+                except OSError:
+                    pass
+                continue
+            out, err = alone.stdout, alone.stderr
             failed.append((knob, p.returncode, out[-3000:] + err[-1000:]))
             try:  # (the assertion's repr cuts the text short: the whole log goes where gpurun brings it back from)
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
