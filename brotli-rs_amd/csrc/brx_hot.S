@@ -27,7 +27,7 @@
 //   entry : always at resume point R1 (insert_len / copy_len / implicit_zero of the current command known)
 //   exit  : mbw[MBW_EXIT] = 0 (R0: insert&copy symbol due), 1 (R1), 2 (R2: distance of the current command known).
 // Everything unusual leaves through one of those points and is handled by generic_commands() in C++, which runs one
-// command and hands back: copies longer than 512 bytes, any error (the C++ side re-decodes and
+// command and hands back: copies longer than 512 bytes (8 191 when the source is in the ring), any error (the C++ side re-decodes and
 // raises it), the dword the dispatcher names in mbw[MBW_WSAFE] (resumable decode: END_MARGIN dwords in front of the end of the
 // input, so that every bit consumed below is a real bit; batches: see "speculative end" in brx_kernels.hip), a ragged first flush
 // block, extra-bit fields wider than the window, and the block switches the loop does not take itself: a block type / block count
@@ -2219,10 +2219,19 @@
     s_add_u32 POS, POS, T0
     s_sub_u32 T5, T5, T0
 .endm
-// ---- a copy of 65..512 bytes: 64-byte chunks, each read (ring or the stream's own HBM output), waited for and written before
-// the next one (a distance below 64: see below).  Anything longer goes to the C++ side (1 KiB steps, periodic fills).
+// ---- a copy of 65 bytes and more: 64-byte chunks, each read (ring or the stream's own HBM output), waited for and written before
+// the next one (a distance below 64: see below).  Up to 512 bytes when the source is older than the ring -- every chunk then waits
+// out a round trip to HBM, and from there on the C++ side's 16 B/lane steps win -- and up to COPY_NEAR_MAX when it is in the ring
+// (round 6: a chunk is ~50 cycles there, a hand-over to the C++ side and back ~18 k: the break-even is far beyond the 8 KiB from
+// which the C++ side has its periodic fills and direct far copies).  Anything longer goes to the C++ side.
+#ifndef COPY_NEAR_MAX
+#define COPY_NEAR_MAX 8191
+#endif
 .Lcopy_long:
-    s_min_u32 T0, MBLEFT, 512
+    s_mov_b32 T0, COPY_NEAR_MAX
+    s_cmp_gt_u32 DIST, RING
+    s_cselect_b32 T0, 512, T0
+    s_min_u32 T0, MBLEFT, T0
     s_cmp_gt_u32 CPY, T0
     s_cbranch_scc1 .Lx_r2
     s_call_b64 LINKB, .Lland

@@ -2183,6 +2183,17 @@ def test_runs_and_short_periods_stay_in_the_assembly_loop(build):
                     cmds.append((lits, L, d))
                     period = bytes(out[-d:])
                     out += (period * (L // d + 1))[:L]
+            # ... and the ring-source copies of 513 .. 8 191 bytes that stay in the loop since round 6 (COPY_NEAR_MAX), next to the
+            # lengths and distances just beyond (the C++ side's): the ring's edge 2 047 / 2 048 / 2 049, the limit 8 191 / 8 192
+            far = [1, 7, 63, 64, 65, 500, 2047, 2048, 2049, 3000]
+            rng.shuffle(far)
+            for d in far:
+                for L in rng.sample([513, 1000, 2048, 4095, 8191, 8192, 9000], 3):
+                    lits = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 9)))
+                    out += lits
+                    cmds.append((lits, L, d))
+                    period = bytes(out[-d:])
+                    out += (period * (L // d + 1))[:L]
             b = craft.Bits()
             craft.stream_header(b, 22)
             craft.MetaBlock(cmds, mlen=len(out)).emit(b, True, len(out))
