@@ -2710,6 +2710,7 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                 st = generic_commands(HC_START);
                 u32 k = 0;
                 while (st == HC_CONTINUE) {
+                    if (lane == 0u) { const u32 we = (u32)(get64(s, 5) >> 5); s.mbw[MBW_WSAFE] = we > BRX_END_MARGIN ? we - BRX_END_MARGIN : 0u; } // (what the emulated loop reads)
                     if (a.dump != nullptr && rfl(s.mbw[MBW_ASM]) != 0u && (k % a.dump_interval) == 0u) {
                         u32 slot = rdl(atomicAdd(a.dump, lane == 0u ? 1u : 0u), 0);
                         if (slot < a.dump_max) {
