@@ -177,7 +177,7 @@ _CL_ORDER = [1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15]
 _CL_FIXED = {0: (0b00, 2), 3: (0b10, 2), 4: (0b01, 2), 2: (0b011, 3), 1: (0b0111, 4), 5: (0b1111, 4)}  # LSB-first fields
 
 
-def complex_code(b, lengths, zero_run_17=False):
+def complex_code(b, lengths, zero_run_17=False, cl_len=None):
     """Complex prefix code (HSKIP = 0) for the per-symbol `lengths` (0 = absent).  Lengths after the point where the
     Kraft sum completes must be 0 and are not transmitted.  With zero_run_17 runs of >= 3 zeros use code 17.
     Returns the canonical {symbol: (code, len)} map."""
@@ -207,10 +207,14 @@ def complex_code(b, lengths, zero_run_17=False):
         i += 1
     assert all(l == 0 for l in lengths[i:]), "symbols after the code is complete"
     used = sorted({t[0] for t in toks})
-    cl_len = [0] * 18
-    if len(used) == 1:
+    if cl_len is not None:  # the caller's code-length code (lengths of the 18 symbols: complete, covering every token)
+        assert all(cl_len[u] for u in used) and sum(32 >> l for l in cl_len if l) == 32
+        cl_len = list(cl_len)
+    elif len(used) == 1:
+        cl_len = [0] * 18
         cl_len[used[0]] = 1  # one code-length symbol: zero bits each (the 18 entries never sum to 32)
     else:
+        cl_len = [0] * 18
         for s, l in zip(used, _cl_code_lengths(len(used))):
             cl_len[s] = l
     b.put(0, 2)  # HSKIP = 0 (kind 0 = complex, nothing skipped)
@@ -271,11 +275,12 @@ class MetaBlock:
     a near-uniform insert&copy code over the symbols the commands use and a uniform distance code over the 64 symbols
     of NPOSTFIX = NDIRECT = 0.  Commands: (literal bytes, copy_len, distance) -- distance None = no copy (last command)."""
 
-    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0, lit_lengths=None, single_iac=False, single_dist=False):
+    def __init__(self, commands, mlen=None, npostfix=0, ndirect=0, lit_lengths=None, single_iac=False, single_dist=False, lit_cl_len=None):
         self.commands, self.mlen, self.npostfix, self.ndirect = commands, mlen, npostfix, ndirect
         self.single_dist = single_dist  # a ONE-symbol distance code (every copy has the same distance code; zero bits per symbol; the
                                         # copies may still differ in the code's extra bits)
         self.lit_lengths = lit_lengths  # code lengths of the 256 literals (default: 8 bits each)
+        self.lit_cl_len = lit_cl_len    # ... sent with THIS code-length code (18 lengths) and every zero spelled out, instead of the default one
         self.single_iac = single_iac    # keep a ONE-symbol insert&copy code (zero bits per symbol)
 
     def emit(self, b, is_last, out_len_hint):
@@ -294,7 +299,7 @@ class MetaBlock:
         b.put(0, 2)   # context mode LSB6 (irrelevant: one tree)
         b.put(0, 1)   # NTREESL = 1
         b.put(0, 1)   # NTREESD = 1
-        lit = complex_code(b, self.lit_lengths or [8] * 256, zero_run_17=self.lit_lengths is not None)
+        lit = complex_code(b, self.lit_lengths or [8] * 256, zero_run_17=self.lit_lengths is not None and self.lit_cl_len is None, cl_len=self.lit_cl_len)
         syms = sorted({iac_symbol(len(l), c if c else 2)[0] for l, c, d in self.commands})
         if len(syms) == 1 and not self.single_iac:
             syms.append(syms[0] + 1 if syms[0] + 1 < 704 else syms[0] - 1)  # (a 1-symbol insert&copy code never enters the asm loop)

@@ -2255,3 +2255,44 @@ def test_every_vector_through_the_pulled_reader(loop):
         assert len(streams) > 120
     finally:
         c2.close()
+
+
+def test_code_length_code_that_leaves_the_lanes(ctx):
+    """Round 6: the 18 symbols of a complex code's code-length code are decoded lane-parallel over a 64-bit window; a chain of more
+    than 60 bits -- fifteen four-bit symbols (lengths 1 and 5) and the two-bit ones between them -- falls back to the serial loop.  A
+    literal code with every length 1 .. 15 sent through a code-length code of lengths {0: 1, 15: 4, 1 .. 14: 5} is such a chain (66
+    bits); the same literal code through the default code-length code takes the parallel path.  Both against the oracle, cut at every
+    byte of the header as well (the deferred end-of-input check must come out the same either way)."""
+    import craft
+    lens = [0] * 256
+    for k, l in enumerate(list(range(1, 15)) + [15, 15]):
+        lens[2 * k] = l
+    cl = [0] * 18
+    cl[0], cl[15] = 1, 4
+    for x in range(1, 15):
+        cl[x] = 5
+    rng = random.Random(4)
+    syms = [2 * k for k in range(16)]
+    streams = []
+    for cl_len in (cl, None):
+        lits = bytes(rng.choice(syms[:6]) for _ in range(50))
+        out = bytearray(lits)
+        cmds = [(lits, 10, 3)]
+        out += (bytes(out[-3:]) * 4)[:10]
+        l2 = bytes(syms)
+        out += l2
+        cmds.append((l2, 5, 60))
+        out += out[-60:-55]
+        b = craft.Bits()
+        craft.stream_header(b, 18)
+        craft.MetaBlock(cmds, mlen=len(out), lit_lengths=lens, lit_cl_len=cl_len).emit(b, True, len(out))
+        s_ = b.bytes()
+        assert oracle.decode(s_, 0, cap=1 << 12)[:2] == (0, bytes(out))
+        streams.append(s_)
+    cuts = [s_[:k] for s_ in streams for k in range(1, len(s_) + 1)]
+    cuts += [s_[:k - 1] + bytes([s_[k - 1] & ((1 << j) - 1)]) for s_ in streams for k in range(2, len(s_), 3) for j in (1, 4, 6)]
+    want = [oracle.decode(c, 0, cap=1 << 12) for c in cuts]
+    outs, status, out_len = ctx.decode_batch(cuts, 1 << 12)
+    bad = [(i, len(cuts[i]), w[0], int(st)) for i, (w, o, st) in enumerate(zip(want, outs, status)) if w[0] != st or (st == 0 and o != w[1])]
+    assert not bad, bad[:8]
+    assert sum(1 for w in want if w[0] == 0) >= 2
