@@ -281,6 +281,46 @@ def test_how_many_gpus_a_batch_is_dealt_over():
 
 
 @pytest.mark.gpu
+def test_bad_arguments_are_refused_not_run():
+    """Library-level errors (BRX_ERR_INVALID_ARGUMENT with a text in brx_last_error), never a crash: more GPUs than the node has, a root
+    outside the ranks used, an unknown deal, NULL tables, decreasing offsets, a device index that does not exist, an unknown option."""
+    import ctypes
+    L = brx.load_library()
+    with pytest.raises(brx.BrxError):
+        brx.Node([0, 99])
+    node = brx.Node([0, 0])
+    try:
+        comp, exp = _read("monkey.compressed"), _read("monkey")
+        with pytest.raises(brx.BrxError):
+            node.decode_batch([comp] * 4, 1024, use_gpus=3)
+        t, out_off = _device_batch([comp] * 4, [1024] * 4)
+        with pytest.raises(brx.BrxError):
+            _run_device(node, t, 4, use_gpus=1, root=1)
+        with pytest.raises(brx.BrxError):
+            node.set_option("transport", 7)
+        with pytest.raises(brx.BrxError):
+            node.set_option("command_loop", 3)  # (a BRX_OPTION_* value the contexts refuse)
+        opts = brx._NodeOpts(0, 9, 0, 0, None)  # unknown deal
+        one = np.zeros(2, dtype=np.uint64)
+        assert L.brx_node_decode_batch(node._h, None, one.ctypes.data, 1, None, one.ctypes.data, one.ctypes.data, one.ctypes.data, ctypes.byref(opts)) == -1
+        opts = brx._NodeOpts(0, 0, 0, 0, None)
+        assert L.brx_node_decode_batch(node._h, None, None, 1, None, None, None, None, ctypes.byref(opts)) == -1  # NULL tables
+        assert L.brx_node_decode_batch(node._h, None, None, 0, None, None, None, None, None) == 0  # an empty batch is fine
+        bad_off = np.array([5, 3], dtype=np.uint64)
+        buf = np.zeros(64, dtype=np.uint8)
+        st = np.zeros(1, dtype=np.int32)
+        assert L.brx_node_decode_batch(node._h, buf.ctypes.data, bad_off.ctypes.data, 1, buf.ctypes.data, one.ctypes.data, one.ctypes.data, st.ctypes.data,
+                                       ctypes.byref(opts)) == -1
+        assert b"non-decreasing" in L.brx_last_error()
+        assert L.brx_node_ctx(node._h, 5) is None and L.brx_node_size(None) == 0 and L.brx_node_last_timing(None, 0, 0) < 0
+        # ... and the node still works afterwards
+        outs, status, _ = node.decode_batch([comp] * 4, len(exp) + 16, use_gpus=2)
+        assert list(status) == [0] * 4 and all(o == exp for o in outs)
+    finally:
+        node.close()
+
+
+@pytest.mark.gpu
 def test_two_real_gpus_with_rccl():
     """shard.py's world-2 test in the C ABI: needs two GPUs (the driver's 8-GPU node; skipped on a gpurun box)."""
     import torch
