@@ -406,8 +406,12 @@ FI u32 in_byte_tail(Dec &d) {
 #define MBW_DISTBAD 37
 #define MBW_EXIT 38
 #define BRX_END_MARGIN 5u          // = END_MARGIN of brx_hot.S: what the loop may consume between a poisoned refill and its next exit test
+#ifndef BRX_SPEC_CK_DWORDS
 #define BRX_SPEC_CK_DWORDS 64u     // speculative end: a long stream's loop is first poisoned this far in front of the end of the input (the checkpoint)
+#endif
+#ifndef BRX_SPEC_CK_MIN_DWORDS
 #define BRX_SPEC_CK_MIN_DWORDS 1024u // ... if it is entered with more input than this left; shorter ones take their checkpoint at the first entry
+#endif
 #define MBW_WSAFE 39 // the dword at which the assembly loop is poisoned (brx_hot.S, .Lspecial): set by the dispatcher before every call
 
 #ifndef BRX_SMALL
@@ -2279,6 +2283,15 @@ __device__ __noinline__ void seg_resume() {
         const u32 v = vend - 16u + d.lane;
         s.ring[v & RMASK] = (u8)__builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, v - BRX_RING_BYTES - d.a, 0, 0);
     }
+    // ... and the unit that holds the stream's FIRST byte, while the window still reaches back to it (fewer than a ring's length of
+    // output so far): with an output slot that is not 16-byte aligned that unit starts IN FRONT of the slot, its 16-byte load is out of
+    // range as a whole and comes back as zeros -- the stream's first 15 bytes at most, which a copy from ~pos bytes back then read as
+    // zeros (round 6: found by tools/node_fuzz.py -- a truncated stream whose speculative end goes back to a checkpoint at output
+    // byte ~1 300, in a slot at offset 1 / 5; the late resume of rounds 4 / 5 had the same hole for hand-ups within the first 2 KiB).
+#ifndef BRX_NO_FIRST_UNIT_FIX  // (A/B: tools/gpu_first_unit_ab.sh shows the test that fails without it)
+    if (d.a != 0u && vend <= BRX_RING_BYTES && d.lane >= d.a && d.lane < 16u && d.lane < top)
+        s.ring[d.lane] = (u8)__builtin_amdgcn_raw_buffer_load_b8(d.out_rsrc, d.lane - d.a, 0, 0);
+#endif
 }
 __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(BrxKernelArgs a) {
     Lds &s = g_lds;
@@ -2796,6 +2809,9 @@ __global__ __launch_bounds__(BRX_WAVE, BRX_WAVES_PER_SIMD) void BRX_KERNEL_NAME(
                     __threadfence();
                     if (lane < 48u && lane != 20u && lane != 21u) s.st[lane] = ck_st; // (a slab claimed meanwhile stays claimed)
                     if (lane < 48u) s.mbw[lane] = ck_mbw;
+#ifdef BRX_CK_VFL_POS
+                    if (lane == 0u) s.st[12] = s.st[10] + s.st[11];
+#endif
                     seg_resume();
                     spec = false;
                     st = HC_CONTINUE;

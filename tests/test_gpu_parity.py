@@ -1181,6 +1181,55 @@ def test_late_resume_with_every_alignment_of_the_output_slot(levels):
         c2.close()
 
 
+@pytest.mark.parametrize("levels", [0, 2])
+def test_ring_reload_in_the_first_two_kib_keeps_the_streams_first_bytes(levels):
+    """Round 6 (tools/node_fuzz.py seeds 6 / 7).  The ring reload (seg_resume) reads the output back in 16-byte units of the ring;
+    with a slot that is not 16-byte aligned the unit holding the stream's FIRST byte starts in front of the slot, its load was out of
+    range as a whole and the first 15 bytes (at most) came back as zeros -- visible only while the window still reaches back to them
+    (fewer than 2 048 bytes so far) and a later copy reads them.  (a) The late resume of rounds 4 / 5: a stream whose SECOND
+    meta-block outgrows the regular instance ~340 bytes in and opens with a copy from the stream's first bytes, every such distance x
+    16 slot alignments.  (b) The speculative end's checkpoint: the truncated stream the fuzz found (tests/golden/regress_r06/: its
+    checkpoint is taken at output byte ~1 300, its rollback reloads the ring, and a copy 1 297 bytes back read zeros -- status and
+    length right, six bytes wrong, slots at offset 1 and 5), at all 16 alignments: the oracle's prefix."""
+    import craft
+    c2 = brx_knobs.context(0, levels=levels)
+    try:
+        st1, out1 = craft.growing_tables_stream(77, [2], mode=1, n_cmds=40)  # (the same first meta-block: its length)
+        L1 = len(out1)
+        streams, want = [], []
+        for D in range(L1 + 6 - 16, L1 + 7):  # the second meta-block's first copy (behind 6 or 7 literals) reads position 0 .. 16
+            st_, out_ = craft.growing_tables_stream(77, [2, 150], mode=1, n_cmds=40, first_dist=D)
+            assert out_[:L1] == out1
+            streams += [st_] * 16
+            want += [out_] * 16
+        for i in range(0, len(streams), 16):
+            w = oracle.decode(streams[i], 0, cap=1 << 16)
+            assert w[0] == 0 and w[1] == want[i]
+        cap = max(len(w) for w in want)
+        cap += (1 - cap) % 16 + 16  # = 1 (mod 16): stream i's slot starts at i (mod 16)
+        for rep in range(2):
+            outs, status, out_len = c2.decode_batch(streams, cap)
+            bad = [(i // 16, i % 16, int(t)) for i, (o, w, t) in enumerate(zip(outs, want, status)) if t != 0 or o != w]
+            assert not bad, bad[:8]
+        # (b)
+        cut = open(os.path.join(GOLDEN, "regress_r06", "cut_ck1300.compressed"), "rb").read()
+        st, exp = oracle.decode(cut, 0, cap=1 << 16)
+        assert st == 24 and len(exp) == 13850
+        n, cap = 16, 16001
+        blob = np.frombuffer(cut * n, dtype=np.uint8).copy()
+        in_off = (np.arange(n + 1) * len(cut)).astype(np.uint64)
+        out_off = (np.arange(n + 1) * cap).astype(np.uint64)
+        for rep in range(2):
+            arena = np.full(n * cap + 16, 0xEE, dtype=np.uint8)
+            status, out_len = c2.decode_batch_host_raw(blob.ctypes.data, in_off, n, arena.ctypes.data, out_off)
+            assert [int(t) for t in status] == [24] * n and [int(x) for x in out_len] == [len(exp)] * n
+            bad = [i for i in range(n) if arena[i * cap:i * cap + len(exp)].tobytes() != exp]
+            assert not bad, bad
+            assert (arena[n * cap:] == 0xEE).all()
+    finally:
+        c2.close()
+
+
 # (first instance, receiving instance) by the literal trees of the first / third meta-block: the regular instance holds ~88 of these
 # two-symbol trees, level 1 ~121, level 2 ~222
 HANDUP_PAIRS = {"regular_to_l1": [2, 2, 100], "regular_to_l2": [2, 2, 150], "regular_to_l3": [2, 2, 240], "l1_to_l2": [100, 2, 150],

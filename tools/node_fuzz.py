@@ -83,6 +83,11 @@ for r in range(rounds):
         got = (arena, np.asarray(st_), np.asarray(ln_).astype(np.int64))
     total += 1
     ok = (got[1] == want[1]).all() and (got[2] == want[2]).all()
+    why = ""
+    if not ok:
+        d = [i for i in range(n) if got[1][i] != want[1][i] or got[2][i] != want[2][i]][:5]
+        why = "status / length differ at %s: got %s want %s (sizes %s caps %s)" % (d, [(int(got[1][i]), int(got[2][i])) for i in d],
+                                                                                  [(int(want[1][i]), int(want[2][i])) for i in d], [len(streams[i]) for i in d], [guess[i] for i in d])
     if ok:
         for i in range(n):
             k = 0 if want[1][i] == 25 else min(int(want[2][i]), guess[i])  # what is in the slot: the stream, or the bytes in front of the
@@ -90,12 +95,15 @@ for r in range(rounds):
             a, b = int(out_off[i]), int(out_off[i]) + k
             if not (got[0][a:b] == want[0][a:b]).all():
                 ok = False
+                first = int(np.argmax(got[0][a:b] != want[0][a:b]))
+                why = "bytes of stream %d differ from offset %d of %d (status %d, size %d, cap %d)" % (i, first, k, int(want[1][i]), len(streams[i]), guess[i])
                 break
-        if mode != 2 and not (got[0][int(out_off[-1]):] == 0xEE).all():
+        if ok and mode != 2 and not (got[0][int(out_off[-1]):] == 0xEE).all():
             ok = False
+            why = "bytes behind the last slot were written"
     if not ok:
         bad += 1
-        print("MISMATCH round %d: %d streams, %s" % (r, n, what))
+        print("MISMATCH round %d: %d streams, %s: %s" % (r, n, what, why))
     else:
         print("ok round %d: %d streams (%d fail), %s" % (r, n, int((want[1] != 0).sum()), what))
 node.close()
