@@ -164,7 +164,10 @@ int brx_ctx_set_option(brx_ctx *ctx, uint32_t option, int64_t value);
  *   in_off   n+1 offsets
  *   out      output arena; stream i may write out[out_off[i] .. out_off[i+1])  (capacity, not size)
  *   out_off  n+1 offsets
- *   out_len  n  decoded sizes (valid for status 0; "needed so far" for status 25)
+ *   out_len  n  decoded sizes (valid for status 0; "needed so far" for status 25).  For the other statuses: how far the decoder got --
+ *               the slot's bytes [0, min(out_len, capacity)) are the stream's output in front of the error (the prefix a streaming
+ *               reader has been handed; tools/prefix_fuzz.py holds it to the oracle); how far INTO the failing command that is, is
+ *               not specified (nor by the reference: src/lib.rs:2173-2193 drops what the failing decompress() call had written)
  *   status   n  per-stream status codes (see above).  One bad stream never affects another.
  * Synchronous with respect to the host unless opts->hip_stream is given and BRX_MEM_DEVICE is set, in
  * which case the call only enqueues work on that stream -- EXCEPT under launch plan B (BRX_OPTION_LEVELS = 2, or a context that

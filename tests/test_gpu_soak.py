@@ -36,10 +36,13 @@ SECTIONS += [({"BRX_DEBUG_STOP": "8"}, "big_fuzz", ["1", "48"])]  # the C++ comm
 SECTIONS += [({}, "reader_fuzz", ["5", "43"]), ({}, "reader_fuzz", ["5", "44"])]
 # ... and the node entry over virtual ranks: random batches / capacities / deals / ranks / roots, host and device pointers, RCCL to itself
 SECTIONS += [({}, "node_fuzz", ["30", "43"])]
+# ... and what a slot holds when its stream fails, against the oracle (odd capacities: every slot alignment): seed 3 is the one that finds
+# seg_resume's first-unit hole when the fix is compiled out (profiles/r06_prefix_fuzz.txt)
+SECTIONS += [({}, "prefix_fuzz", ["30", "3"]), ({}, "prefix_fuzz", ["30", "43"])]
 
 
 def _needs_encoder(tool):
-    return tool in ("wide_fuzz", "big_fuzz", "small_fuzz", "device_fuzz")  # (reader_fuzz / node_fuzz / gen_fuzz make or hold their streams)
+    return tool in ("wide_fuzz", "big_fuzz", "small_fuzz", "device_fuzz")  # (reader_fuzz / node_fuzz / prefix_fuzz / gen_fuzz make or hold their streams)
 
 
 def _section_id(sec):
@@ -50,7 +53,7 @@ def _section_id(sec):
 # Round 6 (788 s of the driver's 1 200 s): the sections are independent processes whose time is mostly the host's
 # (encoder, oracle), so they run THREE AT A TIME -- longest first, so that a group's members take about equally long.  Same sections,
 # same seeds, same assertions per section.
-_COST = {"wide_fuzz": 50, "big_fuzz": 18, "gen_fuzz": 3, "small_fuzz": 9, "device_fuzz": 5, "reader_fuzz": 8, "node_fuzz": 1}
+_COST = {"wide_fuzz": 50, "big_fuzz": 18, "gen_fuzz": 3, "small_fuzz": 9, "device_fuzz": 5, "reader_fuzz": 8, "node_fuzz": 1, "prefix_fuzz": 1}
 _ORDERED = sorted(SECTIONS, key=lambda sec: -_COST.get(sec[1], 10) * int(sec[2][0]))
 GROUPS = [_ORDERED[i:i + 3] for i in range(0, len(_ORDERED), 3)]
 
