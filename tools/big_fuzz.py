@@ -14,10 +14,12 @@ import brotli_enc  # noqa: E402
 import oracle_py  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
 import brx_knobs  # noqa: E402
+import fuzz_slots  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
 pool = [open(os.path.join(G, f), "rb").read() for f in ("alice29.txt", "lcet10.txt", "plrabn12.txt", "asyoulik.txt")]
 assert brotli_enc.available()
 ctx = brx_knobs.context(0)
@@ -74,12 +76,7 @@ for r in range(rounds):
         else:
             s = s[:rng.randrange(1, len(s) + 1)]
         cs.append(bytes(s))
-    exp = [oracle_py.decode(s, cap=1 << 21) for s in cs]
-    outs, status, out_len = ctx.decode_batch(cs, [1 << 21] * len(cs))
-    for i, (e, o, st) in enumerate(zip(exp, outs, status)):
-        if int(st) != e[0] or (e[0] == 0 and o != e[1]):
-            bad += 1
-            print("MISMATCH corrupted stream", r, i, int(st), e[0], cs[i][:24].hex())
+    bad += fuzz_slots.check_corrupted(ctx, cs, 1 << 21, seed * 1000 + r, lambda i, st, want, what: print("MISMATCH corrupted stream", r, i, st, want, what, cs[i][:24].hex()))
     print("round", r, "done, mismatches so far", bad, flush=True)
 ctx.close()
 sys.exit(1 if bad else 0)

@@ -10,13 +10,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import oracle_py  # noqa: E402
 from brotli_rs_amd import brx  # noqa: E402
 import brx_knobs  # noqa: E402
+import fuzz_slots  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden", "data")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
 pool = [open(os.path.join(G, f), "rb").read() for f in ("alice29.txt", "lcet10.txt", "plrabn12.txt", "asyoulik.txt")]
 ctx = brx_knobs.context(0)
 bad = total = 0
@@ -69,13 +72,8 @@ for r in range(rounds):
         else:
             m += rng.randbytes(rng.randrange(1, 6))
         cs.append(bytes(m))
-    exp = [oracle_py.decode(s, cap=1 << 19) for s in cs]
-    outs, status, out_len = ctx.decode_batch(cs, [1 << 19] * len(cs))
-    for i, (e, o, st) in enumerate(zip(exp, outs, status)):
-        total += 1
-        if int(st) != e[0] or (e[0] == 0 and o != e[1]):
-            bad += 1
-            print("MISMATCH corrupted", r, i, int(st), e[0], mb, sw, ad, cs[i][:16].hex())
+    total += len(cs)
+    bad += fuzz_slots.check_corrupted(ctx, cs, 1 << 19, seed * 1000 + r, lambda i, st, want, what: print("MISMATCH corrupted", r, i, st, want, what, mb, sw, ad, cs[i][:16].hex()))
     print("round %d (meta-blocks of %d, %s): %d streams so far, %d mismatches" % (r, mb, "adaptive" if ad else "switches %s" % sw, total, bad), flush=True)
 ctx.close()
 sys.exit(1 if bad else 0)
