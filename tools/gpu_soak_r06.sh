@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-O=gpurun_out/r06_soak.txt
+O=gpurun_out/${OUT:-r06_soak.txt}
 mkdir -p gpurun_out /tmp/soak
 : > $O
 run() {  # run "<env>" tool args...  -> one summary line
@@ -21,6 +21,7 @@ for SEED in ${1:-701 702}; do
     wait
   done
   run "BRX_PLAN_A=1" wide_fuzz 1 $SEED big; run "BRX_PLAN_B=1" wide_fuzz 1 $SEED big; run "BRX_GRID_CAP=64" wide_fuzz 2 $SEED; wait
+  run "X=1" node_fuzz 30 $SEED; run "X=1" prefix_fuzz 30 $SEED; run "X=1" prefix_fuzz 30 $((SEED + 50)); wait
 done
 echo "MISMATCH lines: $(grep -c 'MISMATCH' $O)   sections: $(grep -c '^==' $O)" >> $O
 tail -3 $O
