@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 n = 0
-for pat in ("bench_%s_*.json", "%s_*_kernel_stats.csv", "%s_sweep.txt", "%s_pcie.txt", "%s_pmc.txt", "%s_spec_ab.txt", "%s_fetchcal.txt", "%s_soak.txt", "%s_residency.txt", "%s_plan_ab.txt"):
+for pat in ("bench_%s_*.json", "%s_*_kernel_stats.csv", "%s_sweep.txt", "%s_pcie.txt", "%s_pmc.txt", "%s_spec_ab.txt", "%s_fetchcal.txt", "%s_residency.txt", "%s_plan_ab.txt"):
     for f in glob.glob(os.path.join(G, pat % tag)):
         shutil.copy(f, os.path.join(P, os.path.basename(f)))
         n += 1
