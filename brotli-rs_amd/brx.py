@@ -302,6 +302,10 @@ class Context:
         """Slabs of the context's spill pool right now (brx_last_timing 13)."""
         return int(self._lib.brx_last_timing(self._h, 13))
 
+    def facade_batches(self):
+        """(batches, streams) the Read facade has launched for queued streams on this context (brx_last_timing 14 / 15)."""
+        return int(self._lib.brx_last_timing(self._h, 14)), int(self._lib.brx_last_timing(self._h, 15))
+
     def stream_regrown(self):
         """Slices of bounded / pulled streams of this context run again with a larger output buffer (one command beyond the slack)."""
         return int(self._lib.brx_last_timing(self._h, 9))

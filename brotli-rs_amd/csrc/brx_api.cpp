@@ -12,10 +12,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -135,10 +138,21 @@ struct brx_ctx {
     size_t st_gen_cap = 0;
     uint64_t *st_meta = nullptr;
     size_t st_in_cap = 0, st_out_cap = 0, st_meta_cap = 0;
-    // Read facade: streams created but not yet decoded (decoded together by the first read of any of them)
+    // Read facade: streams created but not yet decoded (decoded together by the first read of any of them).  Round 6: `pending` and
+    // `live` have a lock of their own (qmu; order: mu before qmu), so that a stream can be made while a batch is running -- the streams
+    // that host threads make in the meantime queue up and go out together as the next batch.  One reader at a time leads a batch
+    // (facade_busy); the others wait on qcv for THEIR stream, not for the context.
+    std::mutex qmu;
+    std::condition_variable qcv;
+    bool facade_busy = false;
+    std::vector<brx_stream *> waitq; // readers waiting for their stream, in order of arrival (each on its own condition variable: a batch
+                                     // that ends wakes the owners of ITS streams and one reader to lead the next, not everybody)
     std::vector<brx_stream *> pending;
     // every live stream object of this context, bounded ones included: brx_ctx_destroy detaches them all
     std::vector<brx_stream *> live;
+    uint8_t *fa_in = nullptr, *fa_out = nullptr; // the Read facade's batches: pinned, mapped staging the kernel reads and writes in place
+    size_t fa_in_cap = 0, fa_out_cap = 0;        // (brx_host_alloc; kept between batches: no page faults, no copy of unused capacity)
+    uint64_t facade_batches = 0, facade_streams = 0; // batches decode_pending_locked launched / streams in them (brx_last_timing 14 / 15)
 };
 
 extern "C" const char *brx_last_error(void) { return g_err.c_str(); }
@@ -207,6 +221,8 @@ static void ctx_release(brx_ctx *c) {
     (void)hipFree(c->pool.bitmap);
     (void)hipFree(c->pool.slabs);
     (void)hipFree(c->st_in);
+    if (c->fa_in) (void)hipHostFree(c->fa_in);
+    if (c->fa_out) (void)hipHostFree(c->fa_out);
     (void)hipFree(c->st_out);
     (void)hipFree(c->st_meta);
     (void)hipFree(c->d_gen_header);
@@ -397,6 +413,7 @@ extern "C" void brx_ctx_destroy(brx_ctx *c) {
         std::vector<brx_stream *> orphans;
         {
             std::lock_guard<std::mutex> lk(c->mu);
+            std::lock_guard<std::mutex> ql(c->qmu);
             orphans.swap(c->live);
             c->pending.clear();
         }
@@ -985,6 +1002,8 @@ extern "C" double brx_last_timing(brx_ctx *c, int which) {
         }
         return (double)(c->slab_waits + w);
     }
+    if (which == 14) return (double)c->facade_batches; // the Read facade: batches launched for queued streams ...
+    if (which == 15) return (double)c->facade_streams; // ... and the streams in them (status-25 retries count again)
     if (which == 9) return (double)c->stream_regrown; // bounded streams of this context: pauses in front of one item that needed more room behind the window
     if (which == 8) return (double)c->stream_short_slices; // bounded streams of this context: slices that paused in front of an item the resident input did not hold
     if ((which >= 2 && which <= 7) || which == 10 || which == 11) { // counters of the most recent launch (waits for it): 2..4 = streams decoded at level >= which - 1
@@ -1169,7 +1188,9 @@ struct brx_stream {
     std::vector<uint8_t> in;
     std::vector<uint8_t> out;
     size_t served = 0;
-    bool decoded = false;
+    std::atomic<bool> decoded{false}; // (set by whichever thread led the batch; read without a lock by the stream's owner)
+    std::condition_variable cv;       // its owner waits here while another reader's batch carries it (or runs ahead of it)
+    bool waiting = false;             // ... and is listed in brx_ctx::waitq (both under the queue's lock)
     int32_t status = 0;
     int lib_rc = BRX_SUCCESS;
     // bounded mode (large streams, and every stream over a reader): decoded slice by slice into a sliding device window of
@@ -1200,6 +1221,7 @@ struct brx_stream {
 #define BRX_BOUNDED_WINDOW (16u << 20) // the largest Brotli window, (1 << 24) - 16, rounded up
 #define BRX_BOUNDED_CHUNK (4u << 20)   // output decoded per slice
 #define BRX_BOUNDED_SLACK ((1u << 20) + 65536u) // room for the command that crosses the slice end
+#define BRX_FACADE_PINNED_MAX ((size_t)1 << 30) // pinned staging the Read facade keeps per context, at most
 #define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
 #define BRX_BOUNDED_SLIDE_MIN (1u << 20)        // the window slides only once it is over by this much (see bounded_step)
 #define BRX_BOUNDED_BUFSIZE ((size_t)BRX_BOUNDED_WINDOW + BRX_BOUNDED_SLIDE_MIN + BRX_BOUNDED_CHUNK + BRX_BOUNDED_SLACK)
@@ -1481,12 +1503,12 @@ static brx_stream *stream_new_impl(brx_ctx *ctx, const uint8_t *in, size_t n, bo
     try {
         s->in.assign(in, in + n);
         s->bounded = force_bounded || n >= BRX_BOUNDED_THRESHOLD;
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        std::lock_guard<std::mutex> ql(ctx->qmu); // (never the context's lock: a running batch does not hold up the making of streams)
         ctx->live.push_back(s);
         if (!s->bounded) ctx->pending.push_back(s);
     } catch (...) {
         try {
-            std::lock_guard<std::mutex> lk(ctx->mu);
+            std::lock_guard<std::mutex> ql(ctx->qmu);
             auto &l = ctx->live;
             l.erase(std::remove(l.begin(), l.end(), s), l.end());
         } catch (...) {
@@ -1519,7 +1541,12 @@ extern "C" brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, voi
 // the next round with the size the kernel asked for (at least x4), up to the 4 GiB - 256 B per-stream limit.
 static void decode_pending_locked(brx_ctx *c) {
     std::vector<brx_stream *> todo;
-    todo.swap(c->pending);
+    {
+        std::lock_guard<std::mutex> ql(c->qmu); // (under the context's lock: brx_stream_free takes both, so nothing in `todo` goes away)
+        todo.swap(c->pending);
+    }
+    const std::vector<brx_stream *> all(todo);
+    try {
     std::vector<size_t> cap(todo.size());
     for (size_t i = 0; i < todo.size(); i++) cap[i] = todo[i]->in.size() * 8 + 65536;
     while (!todo.empty()) {
@@ -1530,10 +1557,39 @@ static void decode_pending_locked(brx_ctx *c) {
             in_off[i + 1] = in_off[i] + todo[i]->in.size();
             out_off[i + 1] = out_off[i] + ((cap[i] + 15) & ~(size_t)15);
         }
-        std::vector<uint8_t> in((size_t)in_off[n] + 1), out((size_t)out_off[n] + 1);
+        // Staging: the context's pinned arenas while the batch fits BRX_FACADE_PINNED_MAX (the kernel reads the compressed bytes and
+        // writes the decoded ones in place over PCIe: nothing of the slots' unused capacity is copied, no fresh pages are touched);
+        // beyond that, plain host memory for this one batch.
+        const size_t in_need = (size_t)in_off[n] + 16, out_need = (size_t)out_off[n] + 16;
+        std::unique_ptr<uint8_t[]> in_own, out_own;
+        uint8_t *in_p = nullptr, *out_p = nullptr;
+        if (in_need + out_need <= BRX_FACADE_PINNED_MAX && hipSetDevice(c->device) == hipSuccess) {
+            auto grow_pinned = [](uint8_t **p, size_t *cap, size_t need) {
+                if (*p && need <= *cap) return true;
+                if (*p) (void)hipHostFree(*p);
+                *p = nullptr;
+                *cap = 0;
+                const size_t want = need + need / 4 + (1u << 20);
+                *p = (uint8_t *)brx_host_alloc(want);
+                if (*p) *cap = want;
+                return *p != nullptr;
+            };
+            if (grow_pinned(&c->fa_in, &c->fa_in_cap, in_need) && grow_pinned(&c->fa_out, &c->fa_out_cap, out_need)) {
+                in_p = c->fa_in;
+                out_p = c->fa_out;
+            }
+        }
+        if (!in_p) {
+            in_own.reset(new uint8_t[in_need]);
+            out_own.reset(new uint8_t[out_need]);
+            in_p = in_own.get();
+            out_p = out_own.get();
+        }
         for (uint32_t i = 0; i < n; i++)
-            if (!todo[i]->in.empty()) memcpy(in.data() + in_off[i], todo[i]->in.data(), todo[i]->in.size());
-        int rc = decode_batch_locked(c, in.data(), in_off.data(), n, out.data(), out_off.data(), out_len.data(), st.data(), nullptr);
+            if (!todo[i]->in.empty()) memcpy(in_p + in_off[i], todo[i]->in.data(), todo[i]->in.size());
+        int rc = decode_batch_locked(c, in_p, in_off.data(), n, out_p, out_off.data(), out_len.data(), st.data(), nullptr);
+        c->facade_batches++;
+        c->facade_streams += n;
         std::vector<brx_stream *> again;
         std::vector<size_t> again_cap;
         for (uint32_t i = 0; i < n; i++) {
@@ -1556,9 +1612,9 @@ static void decode_pending_locked(brx_ctx *c) {
             }
             s->status = st[i];
             const size_t produced = (size_t)std::min<uint64_t>(out_len[i], cap[i]);
-            s->out.assign(out.data() + out_off[i], out.data() + out_off[i] + produced);
-            s->decoded = true;
+            s->out.assign(out_p + out_off[i], out_p + out_off[i] + produced);
             std::vector<uint8_t>().swap(s->in);
+            s->decoded = true; // (last: from here on the stream is its owner's alone -- it may be read and freed at once)
         }
         for (size_t i = n; i < todo.size(); i++) { // (more than 2^20 pending streams: next round)
             again.push_back(todo[i]);
@@ -1566,6 +1622,14 @@ static void decode_pending_locked(brx_ctx *c) {
         }
         todo.swap(again);
         cap.swap(again_cap);
+    }
+    } catch (...) { // (a host allocation failed: no owner may be left waiting for a stream this batch took)
+        for (brx_stream *s : all)
+            if (!s->decoded) {
+                s->lib_rc = BRX_ERR_OUT_OF_MEMORY;
+                s->decoded = true;
+            }
+        throw;
     }
 }
 
@@ -1610,17 +1674,82 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
                 bounded_release(s);
                 s->bounded = false;
                 s->served = (size_t)s->delivered;
-                c->pending.push_back(s);
+                {
+                    std::lock_guard<std::mutex> ql(c->qmu);
+                    c->pending.push_back(s);
+                }
                 decode_pending_locked(c);
+                c->qcv.notify_all(); // (streams of other threads went out with it)
                 break;
             }
             if (rc) { bounded_release(s); s->lib_rc = rc; }
         }
     }
-    if (!s->decoded) {
+    if (!s->decoded.load(std::memory_order_acquire)) {
+        // One reader leads: it decodes everything queued on the context -- its own stream and whatever other threads have made since the
+        // last batch went out -- while the others wait for THEIR stream on the queue's condition variable (not on the context's lock:
+        // a reader whose stream is done must not sit out the next batch).  Streams made while a batch runs queue up behind it and go
+        // out together as the next one: host threads that each make a Decompressor and read it coalesce into batches by themselves
+        // (512 threads on alice29: 24 MB/s -> GB/s, tests/cpp/stream_threads.cpp).
         brx_ctx *c = s->ctx;
-        std::lock_guard<std::mutex> lk(c->mu);
-        if (!s->decoded) decode_pending_locked(c);
+        if (!c) return -(int64_t)1000 + BRX_ERR_INVALID_ARGUMENT;
+        std::unique_lock<std::mutex> ql(c->qmu);
+        auto unlist = [&] {
+            if (s->waiting) {
+                auto &q = c->waitq;
+                q.erase(std::remove(q.begin(), q.end(), s), q.end());
+                s->waiting = false;
+            }
+        };
+        auto batch_over = [&] { // wake the owners of what is decoded, and the longest-waiting other reader: it leads the next batch
+            c->facade_busy = false;
+            bool leader = false;
+            auto &q = c->waitq;
+            size_t keep = 0;
+            for (size_t i = 0; i < q.size(); i++) {
+                brx_stream *w = q[i];
+                if (w->decoded.load(std::memory_order_acquire)) {
+                    w->waiting = false;
+                    w->cv.notify_one();
+                    continue;
+                }
+                if (!leader) {
+                    leader = true;
+                    w->cv.notify_one();
+                }
+                q[keep++] = w;
+            }
+            q.resize(keep);
+            c->qcv.notify_all(); // (brx_stream_free of a stream inside the batch)
+        };
+        while (!s->decoded.load(std::memory_order_acquire)) {
+            if (c->facade_busy) {
+                if (!s->waiting) {
+                    s->waiting = true;
+                    c->waitq.push_back(s);
+                }
+                s->cv.wait(ql);
+                continue;
+            }
+            unlist();
+            c->facade_busy = true;
+            ql.unlock();
+            try {
+                std::lock_guard<std::mutex> lk(c->mu);
+                decode_pending_locked(c);
+            } catch (...) {
+                ql.lock();
+                batch_over();
+                throw;
+            }
+            ql.lock();
+            batch_over();
+            if (!s->decoded.load(std::memory_order_acquire)) { // (cannot happen: a stream that is not decoded is pending)
+                s->lib_rc = BRX_ERR_INVALID_ARGUMENT;
+                s->decoded.store(true, std::memory_order_release);
+            }
+        }
+        unlist();
     }
     if (s->lib_rc != BRX_SUCCESS) {
         if (s->lib_rc == BRX_ERR_OUT_OF_MEMORY) fail(s->lib_rc, "stream expands past the 4 GiB - 256 B per-stream output limit (or allocation failed)");
@@ -1639,11 +1768,17 @@ extern "C" void brx_stream_free(brx_stream *s) {
     if (!s) return;
     bounded_release(s);
     try {
-        if (s->ctx) {
-            std::lock_guard<std::mutex> lk(s->ctx->mu);
-            auto &p = s->ctx->pending;
-            p.erase(std::remove(p.begin(), p.end(), s), p.end());
-            auto &l = s->ctx->live;
+        if (brx_ctx *c = s->ctx) {
+            // Only the queue's lock: freeing a stream that has been read does not wait for the batch that is running (its owner's
+            // next stream would miss that batch's successor).  A stream that is neither decoded nor pending IS in the running batch:
+            // that one is waited for.
+            std::unique_lock<std::mutex> ql(c->qmu);
+            auto &p = c->pending;
+            const auto at = std::find(p.begin(), p.end(), s);
+            if (at != p.end()) p.erase(at);
+            else if (!s->bounded)
+                while (!s->decoded.load(std::memory_order_acquire)) c->qcv.wait(ql);
+            auto &l = c->live;
             l.erase(std::remove(l.begin(), l.end(), s), l.end());
         }
     } catch (...) {

@@ -213,6 +213,40 @@ def test_cpp_decompressor_facade(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_decompressors_on_many_threads_coalesce_into_batches(tmp_path):
+    """The reference's usage from a threaded host: every thread makes a Decompressor over its bytes, reads it to the end, drops it
+    (tests/lib.rs's pattern, src/lib.rs:398-410 + 2173-2193, on every worker of a server).  Until round 6 the first read of a stream
+    decoded what was queued WHILE HOLDING the context's lock, and making a stream needed that lock too: threads took turns with
+    batches of ONE (24 MB/s however many threads -- a host core does 280).  Now streams made while a batch runs queue up under a lock
+    of their own and go out together as the next batch; readers wait for their own stream, one of them leads.  A C++ program against
+    include/brx.h only (tests/cpp/stream_threads.cpp): 64 threads x 8 streams of alice29 -- every byte right, and far fewer batches
+    than streams; the same with a truncated file (every stream must end with UnexpectedEOF after its prefix), and one thread alone."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stream_threads")
+    lib = os.path.join(root, "brotli-rs_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "cpp", "stream_threads.cpp"), "-o", exe, "-L", lib, "-lbrx",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    d = os.path.join(GOLDEN, "data")
+
+    def run(*args):
+        out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = [ln for ln in out.stdout.splitlines() if "batches" in ln][-1]
+        return float(line.split(";")[1].split()[0]), line  # batches
+
+    batches, line = run(os.path.join(d, "alice29.txt.compressed"), os.path.join(d, "alice29.txt"), 64, 8)
+    assert batches <= 128, line  # 512 streams (64 at a time can be queued): ~16 batches when they coalesce, 512 when they do not
+    batches, line = run(os.path.join(d, "alice29.txt.compressed"), os.path.join(d, "alice29.txt"), 1, 5)
+    assert batches == 5, line
+    cut = tmp_path / "cut.compressed"
+    cut.write_bytes(open(os.path.join(d, "alice29.txt.compressed"), "rb").read()[:30000])
+    batches, line = run(cut, "-", 32, 6, 24)
+    assert batches <= 96, line
+    batches, line = run(os.path.join(d, "monkey.compressed"), os.path.join(d, "monkey"), 48, 20)
+    assert batches < 960, line
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("levels", [1, 2])
 def test_truncation_sweep_through_the_first_headers(levels):
