@@ -247,6 +247,31 @@ def test_decompressors_on_many_threads_coalesce_into_batches(tmp_path):
     assert batches < 960, line
 
 
+def test_facade_locking_under_mixed_use(tmp_path):
+    """The locks behind the test above (queue lock, one leading reader, a condition variable per stream; the bounded / pulled readers take
+    the context's lock slice by slice in between) under everything a host does with streams at the same time: 24 threads, each 25 times
+    one of -- read to the end in chunks of random size; pulled through a callback with short reads; two made, one freed unread; made
+    and freed at once; read halfway and freed; bounded -- over text, tiny streams, streams that expand 3 000 x (capacity retries:
+    status 25 inside the facade), an empty stream and a truncated one.  tests/cpp/stream_mix.cpp compares every byte delivered; a
+    deadlock is the timeout."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stream_mix")
+    lib = os.path.join(root, "brotli-rs_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "cpp", "stream_mix.cpp"), "-o", exe, "-L", lib, "-lbrx",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    d = os.path.join(GOLDEN, "data")
+    cut = tmp_path / "cut.compressed"
+    cut.write_bytes(open(os.path.join(d, "alice29.txt.compressed"), "rb").read()[:30000])
+    args = []
+    for name in ("alice29.txt", "monkey", "quickfox_repeated", "compressed_repeated", "empty", "x", "asyoulik.txt"):
+        args += [os.path.join(d, name + ".compressed"), os.path.join(d, name)]
+    args += [str(cut), "-24"]
+    out = subprocess.run([exe, "24", "25"] + args, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "600 done, 0 wrong" in out.stdout, out.stdout
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("levels", [1, 2])
 def test_truncation_sweep_through_the_first_headers(levels):
