@@ -152,6 +152,8 @@ struct brx_ctx {
     std::vector<brx_stream *> live;
     uint8_t *fa_in = nullptr, *fa_out = nullptr; // the Read facade's batches: pinned, mapped staging the kernel reads and writes in place
     size_t fa_in_cap = 0, fa_out_cap = 0;        // (brx_host_alloc; kept between batches: no page faults, no copy of unused capacity)
+    uint32_t fa_readers = 0;                     // owners that still have to copy their stream out of fa_out (under qmu): the next batch
+    std::condition_variable fa_cv;               // waits for them before it touches the arena
     uint64_t facade_batches = 0, facade_streams = 0; // batches decode_pending_locked launched / streams in them (brx_last_timing 14 / 15)
 };
 
@@ -1191,6 +1193,8 @@ struct brx_stream {
     std::atomic<bool> decoded{false}; // (set by whichever thread led the batch; read without a lock by the stream's owner)
     std::condition_variable cv;       // its owner waits here while another reader's batch carries it (or runs ahead of it)
     bool waiting = false;             // ... and is listed in brx_ctx::waitq (both under the queue's lock)
+    const uint8_t *view = nullptr;    // its bytes still in the context's staging: the owner (blocked in brx_stream_read when the batch ended)
+    size_t view_len = 0;              // copies them out itself -- N owners copy at once instead of the leading thread N times
     int32_t status = 0;
     int lib_rc = BRX_SUCCESS;
     // bounded mode (large streams, and every stream over a reader): decoded slice by slice into a sliding device window of
@@ -1539,7 +1543,7 @@ extern "C" brx_stream *brx_stream_new_reader(brx_ctx *ctx, brx_read_fn read, voi
 
 // Decode every pending stream of the context in one batch; streams whose guessed capacity was too small go into
 // the next round with the size the kernel asked for (at least x4), up to the 4 GiB - 256 B per-stream limit.
-static void decode_pending_locked(brx_ctx *c) {
+static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
     std::vector<brx_stream *> todo;
     {
         std::lock_guard<std::mutex> ql(c->qmu); // (under the context's lock: brx_stream_free takes both, so nothing in `todo` goes away)
@@ -1561,6 +1565,10 @@ static void decode_pending_locked(brx_ctx *c) {
         // writes the decoded ones in place over PCIe: nothing of the slots' unused capacity is copied, no fresh pages are touched);
         // beyond that, plain host memory for this one batch.
         const size_t in_need = (size_t)in_off[n] + 16, out_need = (size_t)out_off[n] + 16;
+        { // the owners of the batch before this one copy their streams out of the arena themselves: they are done in a moment
+            std::unique_lock<std::mutex> ql(c->qmu);
+            c->fa_cv.wait(ql, [&] { return c->fa_readers == 0; });
+        }
         std::unique_ptr<uint8_t[]> in_own, out_own;
         uint8_t *in_p = nullptr, *out_p = nullptr;
         if (in_need + out_need <= BRX_FACADE_PINNED_MAX && hipSetDevice(c->device) == hipSuccess) {
@@ -1592,6 +1600,7 @@ static void decode_pending_locked(brx_ctx *c) {
         c->facade_streams += n;
         std::vector<brx_stream *> again;
         std::vector<size_t> again_cap;
+        std::vector<uint32_t> ready; // decoded (or failed with a stream status): their bytes are in the staging
         for (uint32_t i = 0; i < n; i++) {
             brx_stream *s = todo[i];
             if (rc != BRX_SUCCESS) {
@@ -1611,8 +1620,28 @@ static void decode_pending_locked(brx_ctx *c) {
                 continue;
             }
             s->status = st[i];
-            const size_t produced = (size_t)std::min<uint64_t>(out_len[i], cap[i]);
-            s->out.assign(out_p + out_off[i], out_p + out_off[i] + produced);
+            ready.push_back(i);
+        }
+        // Who copies a stream out of the staging: its owner, when the owner is blocked in brx_stream_read right now (N owners copy at
+        // once; the arena is the context's and nothing else wants it before the next batch, which waits for them) -- else this thread.
+        std::vector<uint8_t> by_owner(n, 0);
+        if (out_p == c->fa_out && again.empty() && todo.size() == n) {
+            std::lock_guard<std::mutex> ql(c->qmu);
+            for (uint32_t i : ready) {
+                brx_stream *s = todo[i];
+                if (!s->waiting && s != self) continue;
+                s->view = out_p + out_off[i];
+                s->view_len = (size_t)std::min<uint64_t>(out_len[i], cap[i]);
+                c->fa_readers++;
+                by_owner[i] = 1;
+            }
+        }
+        for (uint32_t i : ready) {
+            brx_stream *s = todo[i];
+            if (!by_owner[i]) {
+                const size_t produced = (size_t)std::min<uint64_t>(out_len[i], cap[i]);
+                s->out.assign(out_p + out_off[i], out_p + out_off[i] + produced);
+            }
             std::vector<uint8_t>().swap(s->in);
             s->decoded = true; // (last: from here on the stream is its owner's alone -- it may be read and freed at once)
         }
@@ -1678,7 +1707,7 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
                     std::lock_guard<std::mutex> ql(c->qmu);
                     c->pending.push_back(s);
                 }
-                decode_pending_locked(c);
+                decode_pending_locked(c, s);
                 c->qcv.notify_all(); // (streams of other threads went out with it)
                 break;
             }
@@ -1736,7 +1765,7 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
             ql.unlock();
             try {
                 std::lock_guard<std::mutex> lk(c->mu);
-                decode_pending_locked(c);
+                decode_pending_locked(c, s);
             } catch (...) {
                 ql.lock();
                 batch_over();
@@ -1750,6 +1779,21 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
             }
         }
         unlist();
+    }
+    if (s->view) { // this thread was waiting when its batch ended: the stream's bytes are still in the context's staging
+        brx_ctx *c = s->ctx;
+        bool ok = true;
+        try {
+            s->out.assign(s->view, s->view + s->view_len);
+        } catch (...) {
+            ok = false;
+        }
+        s->view = nullptr;
+        if (c) {
+            std::lock_guard<std::mutex> ql(c->qmu);
+            if (--c->fa_readers == 0) c->fa_cv.notify_all();
+        }
+        if (!ok) s->lib_rc = BRX_ERR_OUT_OF_MEMORY;
     }
     if (s->lib_rc != BRX_SUCCESS) {
         if (s->lib_rc == BRX_ERR_OUT_OF_MEMORY) fail(s->lib_rc, "stream expands past the 4 GiB - 256 B per-stream output limit (or allocation failed)");
