@@ -245,6 +245,30 @@ def test_decompressors_on_many_threads_coalesce_into_batches(tmp_path):
     assert batches <= 96, line
     batches, line = run(os.path.join(d, "monkey.compressed"), os.path.join(d, "monkey"), 48, 20)
     assert batches < 960, line
+    # the same through the Python mirror of the reference's object (brx.Decompressor; ctypes releases the GIL inside the library)
+    import threading
+    from brotli_rs_amd import brx
+    c2 = brx_knobs.context(0)
+    try:
+        comp, want = _read("alice29.txt.compressed"), _read("alice29.txt")
+        wrong = []
+
+        def worker():
+            for _ in range(4):
+                dd = brx.Decompressor(io.BytesIO(comp), c2)
+                if dd.read() != want:
+                    wrong.append(1)
+                dd.close()
+
+        b0 = c2.facade_batches()
+        ths = [threading.Thread(target=worker) for _ in range(32)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        b1 = c2.facade_batches()
+        assert not wrong
+        assert b1[1] - b0[1] == 128 and b1[0] - b0[0] < 100, (b0, b1)
+    finally:
+        c2.close()
 
 
 def test_facade_locking_under_mixed_use(tmp_path):
