@@ -1549,9 +1549,11 @@ static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
         std::lock_guard<std::mutex> ql(c->qmu); // (under the context's lock: brx_stream_free takes both, so nothing in `todo` goes away)
         todo.swap(c->pending);
     }
-    const std::vector<brx_stream *> all(todo);
+    std::vector<brx_stream *> all(todo); // what this batch still owns: an entry goes to nullptr the moment its stream is flagged decoded
+                                         // (its owner may free it at once)
     try {
-    std::vector<size_t> cap(todo.size());
+    std::vector<size_t> cap(todo.size()), ai(todo.size());
+    std::iota(ai.begin(), ai.end(), (size_t)0);
     for (size_t i = 0; i < todo.size(); i++) cap[i] = todo[i]->in.size() * 8 + 65536;
     while (!todo.empty()) {
         const uint32_t n = (uint32_t)std::min<size_t>(todo.size(), 1u << 20);
@@ -1599,12 +1601,13 @@ static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
         c->facade_batches++;
         c->facade_streams += n;
         std::vector<brx_stream *> again;
-        std::vector<size_t> again_cap;
+        std::vector<size_t> again_cap, again_ai;
         std::vector<uint32_t> ready; // decoded (or failed with a stream status): their bytes are in the staging
         for (uint32_t i = 0; i < n; i++) {
             brx_stream *s = todo[i];
             if (rc != BRX_SUCCESS) {
                 s->lib_rc = rc;
+                all[ai[i]] = nullptr;
                 s->decoded = true;
                 continue;
             }
@@ -1612,10 +1615,12 @@ static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
                 size_t want = std::max<size_t>(cap[i] * 4, (size_t)out_len[i]);
                 again.push_back(s);
                 again_cap.push_back((size_t)std::min<uint64_t>(want, BRX_STREAM_LIMIT));
+                again_ai.push_back(ai[i]);
                 continue;
             }
             if (st[i] == BRX_OUTPUT_TOO_SMALL) { // the stream expands past the per-stream limit: a definite error
                 s->lib_rc = BRX_ERR_OUT_OF_MEMORY;
+                all[ai[i]] = nullptr;
                 s->decoded = true;
                 continue;
             }
@@ -1643,18 +1648,21 @@ static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
                 s->out.assign(out_p + out_off[i], out_p + out_off[i] + produced);
             }
             std::vector<uint8_t>().swap(s->in);
+            all[ai[i]] = nullptr;
             s->decoded = true; // (last: from here on the stream is its owner's alone -- it may be read and freed at once)
         }
         for (size_t i = n; i < todo.size(); i++) { // (more than 2^20 pending streams: next round)
             again.push_back(todo[i]);
             again_cap.push_back(cap[i]);
+            again_ai.push_back(ai[i]);
         }
         todo.swap(again);
         cap.swap(again_cap);
+        ai.swap(again_ai);
     }
     } catch (...) { // (a host allocation failed: no owner may be left waiting for a stream this batch took)
         for (brx_stream *s : all)
-            if (!s->decoded) {
+            if (s && !s->decoded) {
                 s->lib_rc = BRX_ERR_OUT_OF_MEMORY;
                 s->decoded = true;
             }
