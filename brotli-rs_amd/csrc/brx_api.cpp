@@ -145,6 +145,8 @@ struct brx_ctx {
     std::mutex qmu;
     std::condition_variable qcv;
     bool facade_busy = false;
+    std::condition_variable new_cv; // a stream was queued (the leading reader's short wait for the others, below)
+    size_t facade_prev_n = 0;       // streams of the batch before (under qmu)
     std::vector<brx_stream *> waitq; // readers waiting for their stream, in order of arrival (each on its own condition variable: a batch
                                      // that ends wakes the owners of ITS streams and one reader to lead the next, not everybody)
     std::vector<brx_stream *> pending;
@@ -1225,6 +1227,9 @@ struct brx_stream {
 #define BRX_BOUNDED_WINDOW (16u << 20) // the largest Brotli window, (1 << 24) - 16, rounded up
 #define BRX_BOUNDED_CHUNK (4u << 20)   // output decoded per slice
 #define BRX_BOUNDED_SLACK ((1u << 20) + 65536u) // room for the command that crosses the slice end
+#define BRX_FACADE_LINGER_QUIET_US 120         // the leading reader goes once no stream has been queued for this long ...
+#define BRX_FACADE_LINGER_MAX_US 1500          // ... or after this long
+#define BRX_FACADE_LINGER_BELOW 96             // ... and only waits at all while batches are smaller than this
 #define BRX_FACADE_PINNED_MAX ((size_t)1 << 30) // pinned staging the Read facade keeps per context, at most
 #define BRX_BOUNDED_THRESHOLD (4u << 20)        // brx_stream_new: compressed inputs from this size on are decoded bounded
 #define BRX_BOUNDED_SLIDE_MIN (1u << 20)        // the window slides only once it is over by this much (see bounded_step)
@@ -1509,7 +1514,10 @@ static brx_stream *stream_new_impl(brx_ctx *ctx, const uint8_t *in, size_t n, bo
         s->bounded = force_bounded || n >= BRX_BOUNDED_THRESHOLD;
         std::lock_guard<std::mutex> ql(ctx->qmu); // (never the context's lock: a running batch does not hold up the making of streams)
         ctx->live.push_back(s);
-        if (!s->bounded) ctx->pending.push_back(s);
+        if (!s->bounded) {
+            ctx->pending.push_back(s);
+            if (ctx->facade_busy) ctx->new_cv.notify_one();
+        }
     } catch (...) {
         try {
             std::lock_guard<std::mutex> ql(ctx->qmu);
@@ -1548,6 +1556,7 @@ static void decode_pending_locked(brx_ctx *c, brx_stream *self) {
     {
         std::lock_guard<std::mutex> ql(c->qmu); // (under the context's lock: brx_stream_free takes both, so nothing in `todo` goes away)
         todo.swap(c->pending);
+        c->facade_prev_n = todo.size();
     }
     std::vector<brx_stream *> all(todo); // what this batch still owns: an entry goes to nullptr the moment its stream is flagged decoded
                                          // (its owner may free it at once)
@@ -1770,6 +1779,22 @@ extern "C" int64_t brx_stream_read(brx_stream *s, uint8_t *buf, size_t len) {
             }
             unlist();
             c->facade_busy = true;
+            // Where threads work in a closed loop (make, read, free, again) the owners of the batch that has just ended are back
+            // within a few hundred microseconds; a batch costs about the same whether it carries half of the threads or all of
+            // them, so the leader gives them that moment: it waits while streams keep arriving (quiet for 120 us = go), 1.5 ms at
+            // most -- and only when there IS company (the last batch had more than one stream, or more than one is queued: a lone
+            // Decompressor never waits) but not a crowd (from ~100 streams a batch on, the host's copies begin to weigh as much as the kernel
+            // and threads that outnumber the cores do not come back in time: 512 threads lost a quarter with the wait).
+            const size_t company = std::max(c->facade_prev_n, c->pending.size());
+            if (company > 1 && company < BRX_FACADE_LINGER_BELOW) {
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(BRX_FACADE_LINGER_MAX_US);
+                size_t seen = c->pending.size();
+                for (;;) {
+                    c->new_cv.wait_for(ql, std::chrono::microseconds(BRX_FACADE_LINGER_QUIET_US));
+                    if (c->pending.size() == seen || std::chrono::steady_clock::now() >= t_end) break;
+                    seen = c->pending.size();
+                }
+            }
             ql.unlock();
             try {
                 std::lock_guard<std::mutex> lk(c->mu);

@@ -271,8 +271,8 @@ int brx_compact_batch(brx_ctx *ctx, const uint8_t *out, const uint64_t *out_off,
  * ANY queued stream decodes ALL streams queued on that context in one batch (N live Decompressors cost about one
  * batch, not N launches).  Threads coalesce by themselves (round 6): making a stream never waits for a running batch, so the streams
  * that other threads make while one batch runs go out together as the next one -- ONE reader leads it, the others wait for their
- * own stream only (T threads that each make a stream, read it and free it ride batches of ~T / 2: 64 threads on alice29 668 MB/s,
- * 512 threads 3.1 GB/s, where turns of one stream each gave 24 MB/s; profiles/r06_stream_threads.txt; the context keeps the pinned staging of its largest facade batch, at most 1 GiB).  Later reads serve slices:  n>0 bytes read, 0 at end of stream forever after (reference
+ * own stream only (T threads that each make a stream, read it and free it ride batches of T / 2 .. T -- the leading reader waits a moment, 120 us of
+ * quiet and 1.5 ms at most, for the others while batches are small: 16 threads on alice29 324 MB/s, 64 threads 1.15 GB/s, 512 threads 2.9 GB/s, where turns of one stream each gave 24 MB/s; profiles/r06_stream_threads.txt; the context keeps the pinned staging of its largest facade batch, at most 1 GiB).  Later reads serve slices:  n>0 bytes read, 0 at end of stream forever after (reference
  * src/lib.rs:2155-2166).  For an invalid stream the bytes produced before the error are served first, then every
  * read returns -status (the reference returns io::ErrorKind::InvalidData carrying brx_status_str(status) after an
  * unspecified prefix, src/lib.rs:2177).  Values below -900 are library failures (-1000 + BRX_ERR_*),
